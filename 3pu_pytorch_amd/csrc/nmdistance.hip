@@ -1,0 +1,167 @@
+// nmdistance.hip -- Chamfer "nm-distance" forward / backward for gfx950.
+// Replaces losses.nmdistance_forward / nmdistance_backward (reference:
+// losses/nmdistance_cuda.cu:11-193).
+//
+// Forward: for every point of set A the squared distance to, and the index of, its nearest
+// point of set B (lowest index on exact ties: strict '<' inside a tile and strict '>' across
+// tiles in the reference, :36,:125).  O(n*m) fp32 VALU work on 12 B/point of input, so the
+// kernel is compute-bound: B is staged through LDS in float4 (x,y,z,pad) tiles that every
+// lane reads as wave-uniform ds_read_b128 broadcasts, and each lane carries NQ query points in
+// registers so one LDS read feeds NQ distance evaluations.
+// Backward: two scatter passes with hardware fp32 atomics (:154-173).
+#include "tpu3_dev.h"
+
+namespace {
+
+constexpr int NM_THREADS = 256;
+constexpr int NM_TILE = 2048;   // 32 KiB of LDS per workgroup
+
+template <int NQ>
+__global__ __launch_bounds__(NM_THREADS) void nmdist_fwd_kernel(int n, int m,
+                                                               const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2,
+                                                               float *__restrict__ dist,
+                                                               int32_t *__restrict__ idx)
+{
+    __shared__ float4 tile[NM_TILE];
+    const int b = blockIdx.y;
+    const float *A = xyz1 + (size_t)b * n * 3;
+    const float *B = xyz2 + (size_t)b * m * 3;
+    const int j0 = blockIdx.x * (NM_THREADS * NQ) + threadIdx.x;
+    float ax[NQ], ay[NQ], az[NQ], best[NQ];
+    int besti[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = j0 + q * NM_THREADS;
+        const bool live = j < n;
+        ax[q] = live ? A[j * 3 + 0] : 0.f;
+        ay[q] = live ? A[j * 3 + 1] : 0.f;
+        az[q] = live ? A[j * 3 + 2] : 0.f;
+        best[q] = 0.f;
+        besti[q] = 0;
+    }
+    for (int k0 = 0; k0 < m; k0 += NM_TILE) {
+        const int len = min(NM_TILE, m - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += NM_THREADS) {
+            const float *p = B + (size_t)(k0 + i) * 3;
+            tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        int k = 0;
+        if (k0 == 0) {      // the first candidate initialises the running best (:36 `k==0 ||`)
+            const float4 p = tile[0];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                best[q] = tpu3_sqdist3(p.x - ax[q], p.y - ay[q], p.z - az[q]);
+                besti[q] = 0;
+            }
+            k = 1;
+        }
+#pragma unroll 4
+        for (; k < len; ++k) {
+            const float4 p = tile[k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float d = tpu3_sqdist3(p.x - ax[q], p.y - ay[q], p.z - az[q]);
+                if (d < best[q]) {
+                    best[q] = d;
+                    besti[q] = k0 + k;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = j0 + q * NM_THREADS;
+        if (j < n) {
+            dist[(size_t)b * n + j] = best[q];
+            idx[(size_t)b * n + j] = besti[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nmdist_bwd_kernel(int n, int m,
+                                                         const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2,
+                                                         const float *__restrict__ grad_dist1,
+                                                         const int32_t *__restrict__ idx1,
+                                                         float *__restrict__ grad_xyz1,
+                                                         float *__restrict__ grad_xyz2)
+{
+    const int b = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const size_t a = ((size_t)b * n + j) * 3;
+        const int j2 = idx1[(size_t)b * n + j];
+        const size_t c = ((size_t)b * m + j2) * 3;
+        const float g = grad_dist1[(size_t)b * n + j] * 2;
+        const float vx = g * (xyz1[a + 0] - xyz2[c + 0]);
+        const float vy = g * (xyz1[a + 1] - xyz2[c + 1]);
+        const float vz = g * (xyz1[a + 2] - xyz2[c + 2]);
+        atomicAdd(grad_xyz1 + a + 0, vx);
+        atomicAdd(grad_xyz1 + a + 1, vy);
+        atomicAdd(grad_xyz1 + a + 2, vz);
+        atomicAdd(grad_xyz2 + c + 0, -vx);
+        atomicAdd(grad_xyz2 + c + 1, -vy);
+        atomicAdd(grad_xyz2 + c + 2, -vz);
+    }
+}
+
+int nm_dir(hipStream_t s, int b, int n, int m, const float *a, const float *bb, float *dist, int32_t *idx)
+{
+    if (n == 0) return TPU3_OK;
+    // enough workgroups to cover 256 CUs: fewer queries per lane for small problems
+    const long total = (long)b * n;
+    if (total >= 256L * NM_THREADS * 4 * 2) {
+        const dim3 g((n + NM_THREADS * 4 - 1) / (NM_THREADS * 4), b);
+        hipLaunchKernelGGL(nmdist_fwd_kernel<4>, g, dim3(NM_THREADS), 0, s, n, m, a, bb, dist, idx);
+    } else if (total >= 256L * NM_THREADS * 2) {
+        const dim3 g((n + NM_THREADS * 2 - 1) / (NM_THREADS * 2), b);
+        hipLaunchKernelGGL(nmdist_fwd_kernel<2>, g, dim3(NM_THREADS), 0, s, n, m, a, bb, dist, idx);
+    } else {
+        const dim3 g((n + NM_THREADS - 1) / NM_THREADS, b);
+        hipLaunchKernelGGL(nmdist_fwd_kernel<1>, g, dim3(NM_THREADS), 0, s, n, m, a, bb, dist, idx);
+    }
+    return tpu3_launch_status();
+}
+
+} // namespace
+
+extern "C" int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
+                                   const float *xyz2, float *dist1, float *dist2, int32_t *idx1,
+                                   int32_t *idx2)
+{
+    if (b < 0 || n < 0 || m < 0) return TPU3_EINVAL;
+    if (b == 0) return TPU3_OK;
+    if (n == 0 || m == 0) return TPU3_EINVAL;   // nearest neighbour in an empty set is undefined
+    if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    int r = nm_dir(s, b, n, m, xyz1, xyz2, dist1, idx1);
+    if (r) return r;
+    return nm_dir(s, b, m, n, xyz2, xyz1, dist2, idx2);
+}
+
+extern "C" int tpu3_nmdist_bwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
+                                   const float *xyz2, float *gradxyz1, float *gradxyz2,
+                                   const float *graddist1, const float *graddist2,
+                                   const int32_t *idx1, const int32_t *idx2)
+{
+    if (b < 0 || n < 0 || m < 0) return TPU3_EINVAL;
+    if (b == 0 || (n == 0 && m == 0)) return TPU3_OK;
+    if (!xyz1 || !xyz2 || !gradxyz1 || !gradxyz2 || !graddist1 || !graddist2 || !idx1 || !idx2)
+        return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0) {
+        const dim3 g(min((n + 255) / 256, 1024), b);
+        hipLaunchKernelGGL(nmdist_bwd_kernel, g, dim3(256), 0, s, n, m, xyz1, xyz2, graddist1, idx1,
+                           gradxyz1, gradxyz2);
+    }
+    if (m > 0) {
+        const dim3 g(min((m + 255) / 256, 1024), b);
+        hipLaunchKernelGGL(nmdist_bwd_kernel, g, dim3(256), 0, s, m, n, xyz2, xyz1, graddist2, idx2,
+                           gradxyz2, gradxyz1);
+    }
+    return tpu3_launch_status();
+}

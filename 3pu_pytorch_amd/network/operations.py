@@ -1,0 +1,245 @@
+"""Point-set operators of the patch-upsampling path -- the `network.operations` call sites of the
+reference (network/operations.py:12-323), same names, argument order, defaults and return
+tuples, running on the gfx950 kernels of lib3pu_hip.so.
+
+What differs from the reference, by design:
+  * group_knn never materialises the (B,M,N) distance matrix and never leaves the device
+    (the reference copies the points to the host for np.unique on every unique=True call,
+    operations.py:194-203);
+  * every operator also exists in a *ragged / batched* form (``knn_query``, ``fps``) so that
+    the patch pipeline can process all outer patches of a cloud in one launch;
+  * device tensors only: there is no CPU path in this package (the reference's FPS / gather
+    are CUDA-only as well, sampling.cpp:20-24; its group_knn also ran on CPU).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+from .. import sampling
+
+
+class HipBackend(object):
+    """The kernels, behind the small interface the operators below use.  Tests swap this object
+    to exercise the host-side wiring without a GPU; the product never does."""
+
+    name = "hip-gfx950"
+
+    def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True):
+        """query (B,M,C), points (Bp,N,C) f32 contiguous device tensors ->
+        idx int64 (B,M,k), dist f32 (B,M,k) | None, grouped f32 (B,M,k,C) | None.
+        layout: None or dict(n_arr=, m_arr=, pts_of=, grp=, groups=) of int32 device tensors."""
+        L.require_device(query, "query")
+        L.require_device(points, "points")
+        L.require_dtype(query, torch.float32, "query")
+        L.require_dtype(points, torch.float32, "points")
+        b, m, c = query.shape
+        bp, n, c2 = points.shape
+        if c2 != c:
+            raise RuntimeError("group_knn: query/points channel mismatch (%d vs %d)" % (c, c2))
+        lay_ref = None
+        keep = []
+        groups = 1
+        if layout is not None:
+            lay = L.KnnLayout()
+            for name in ("n_arr", "m_arr", "pts_of", "grp"):
+                t = layout.get(name)
+                if t is not None:
+                    L.require_device(t, name)
+                    L.require_dtype(t, torch.int32, name)
+                    keep.append(t)
+                setattr(lay, name, L.ptr(t))
+            groups = int(layout.get("groups", 1)) if layout.get("grp") is not None else 1
+            lay.bp, lay.groups = bp, groups
+            lay_ref = ctypes.byref(lay)
+            if layout.get("pts_of") is None and bp != b:
+                raise RuntimeError("group_knn: %d point sets for %d query sets needs pts_of" % (bp, b))
+        elif bp != b:
+            raise RuntimeError("group_knn: batch mismatch (%d vs %d)" % (b, bp))
+        dev = query.device
+        idx = torch.empty((b, m, k), dtype=torch.int64, device=dev)
+        dist = torch.empty((b, m, k), dtype=torch.float32, device=dev) if want_dist else None
+        grouped = torch.empty((b, m, k, c), dtype=torch.float32, device=dev) if want_grouped else None
+        lib = L.lib()
+        with torch.cuda.device(dev):
+            s = L.stream_of(query)
+            dup = uws = None
+            if unique:
+                dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
+                uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
+                L.check(lib.tpu3_knn_unique_prepare_f32(s, b, m, n, c, L.ptr(query), L.ptr(points),
+                                                        lay_ref, L.ptr(dup), L.ptr(uws)),
+                        "tpu3_knn_unique_prepare_f32")
+            L.check(lib.tpu3_knn_f32(s, b, m, n, c, k, L.ptr(query), L.ptr(points), lay_ref, L.ptr(dup),
+                                     L.ptr(uws), L.ptr(idx), 8, L.ptr(dist), L.ptr(grouped)),
+                    "tpu3_knn_f32")
+        return idx, dist, grouped
+
+    def fps(self, xyz, npoint, n_arr=None, m_arr=None):
+        """xyz (B,N,3) f32 contiguous -> idx int32 (B,npoint).  Dense calls go through the
+        drop-in `sampling.furthest_sampling` entry point, ragged ones through the C ABI."""
+        b, n, _ = xyz.shape
+        idx = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
+        if n_arr is None and m_arr is None:
+            sampling.furthest_sampling(b, n, npoint, xyz, temp, idx)
+            return idx
+        L.require_device(xyz, "xyz")
+        L.require_dtype(xyz, torch.float32, "xyz")
+        for t, nm in ((n_arr, "n_arr"), (m_arr, "m_arr")):
+            if t is not None:
+                L.require_device(t, nm)
+                L.require_dtype(t, torch.int32, nm)
+        idx.zero_()
+        with torch.cuda.device(xyz.device):
+            L.check(L.lib().tpu3_fps_ragged_f32(L.stream_of(xyz), b, n, npoint, L.ptr(n_arr), L.ptr(m_arr),
+                                                L.ptr(xyz), L.ptr(temp), L.ptr(idx), None, 0),
+                    "tpu3_fps_ragged_f32")
+        return idx
+
+    def gather_forward(self, features, idx):
+        b, c, n = features.shape
+        npoint = idx.shape[1]
+        out = torch.empty((b, c, npoint), dtype=features.dtype, device=features.device)
+        return sampling.gather_forward(b, c, n, npoint, features, idx, out)
+
+    def gather_backward(self, grad_out, idx, c, n):
+        b, npoint = idx.shape
+        grad = torch.zeros((b, c, n), dtype=grad_out.dtype, device=grad_out.device)
+        return sampling.gather_backward(b, c, n, npoint, grad_out, idx, grad)
+
+    def normalize(self, pc, n_arr=None):
+        """pc (B,3,N) f32 contiguous -> (out (B,3,N), centroid (B,3,1), radius (B,1,1))."""
+        L.require_device(pc, "pc")
+        L.require_dtype(pc, torch.float32, "pc")
+        b, _, n = pc.shape
+        out = torch.empty_like(pc)
+        centroid = torch.empty((b, 3, 1), dtype=torch.float32, device=pc.device)
+        radius = torch.empty((b, 1, 1), dtype=torch.float32, device=pc.device)
+        with torch.cuda.device(pc.device):
+            L.check(L.lib().tpu3_normalize_f32(L.stream_of(pc), b, n, L.ptr(n_arr), L.ptr(pc), L.ptr(out),
+                                               L.ptr(centroid), L.ptr(radius)), "tpu3_normalize_f32")
+        return out, centroid, radius
+
+
+BACKEND = HipBackend()
+
+
+def normalize_point_batch(pc, NCHW=True):
+    """normalize a batch of point clouds (operations.py:12-30)
+    :param
+        pc      [B, N, 3] or [B, 3, N]
+        NCHW    if True, treat the second dimension as channel dimension
+    :return
+        pc      normalized point clouds, same shape as input
+        centroid [B, 1, 3] or [B, 3, 1] center of point clouds
+        furthest_distance [B, 1, 1] scale of point clouds
+    One fused kernel for fp32 3-channel inference input; the differentiable torch formulation of
+    the reference when a gradient is needed (training re-normalises network outputs)."""
+    fused = (pc.dim() == 3 and pc.dtype == torch.float32
+             and not (pc.requires_grad and torch.is_grad_enabled())
+             and pc.size(1 if NCHW else 2) == 3)
+    if fused:
+        x = pc if NCHW else pc.transpose(2, 1)
+        out, centroid, radius = BACKEND.normalize(x.contiguous())
+        if not NCHW:
+            out, centroid = out.transpose(2, 1).contiguous(), centroid.transpose(2, 1).contiguous()
+        return out, centroid, radius
+    point_axis = 2 if NCHW else 1
+    dim_axis = 1 if NCHW else 2
+    centroid = torch.mean(pc, dim=point_axis, keepdim=True)
+    pc = pc - centroid
+    furthest_distance, _ = torch.max(
+        torch.sqrt(torch.sum(pc ** 2, dim=dim_axis, keepdim=True)), dim=point_axis, keepdim=True)
+    pc = pc / furthest_distance
+    return pc, centroid, furthest_distance
+
+
+def knn_query(k, query, points, unique=True, layout=None, want_dist=True, want_grouped=True):
+    """Channel-last kNN: query (B,M,C), points (Bp,N,C) -> (idx int64 (B,M,k), dist (B,M,k),
+    grouped (B,M,k,C)).  The batched / ragged form of group_knn (see HipBackend.knn)."""
+    return BACKEND.knn(k, query.contiguous(), points.contiguous(), unique, layout, want_dist, want_grouped)
+
+
+def group_knn(k, query, points, unique=True, NCHW=True):
+    """group batch of points to neighborhoods (operations.py:165-216)
+    :param
+        k: neighborhood size
+        query: BxCxM or BxMxC
+        points: BxCxN or BxNxC
+        unique: neighborhood contains *unique* points
+        NCHW: if true, the second dimension is the channel dimension
+    :return
+        neighbor_points BxCxMxk (if NCHW) or BxMxkxC (otherwise)
+        index_batch     BxMxk   (int64, ascending distance, ties to the lowest index)
+        distance_batch  BxMxk
+    The neighbours are returned as the reference returns them: a (B,C,M,k) permuted view of
+    (B,M,k,C) storage.  When `points` needs a gradient the gather is a differentiable
+    torch.gather as in the reference (:209-211); indices and distances carry no gradient."""
+    if NCHW:
+        points_trans = points.transpose(2, 1).contiguous()
+        query_trans = query.transpose(2, 1).contiguous()
+    else:
+        points_trans = points.contiguous()
+        query_trans = query.contiguous()
+    batch_size, num_points, _ = points_trans.size()
+    assert(num_points >= k), "points size must be greater or equal to k"
+    need_grad = points_trans.requires_grad and torch.is_grad_enabled()
+    with torch.no_grad():
+        point_indices, distances, knn_trans = BACKEND.knn(
+            k, query_trans.detach(), points_trans.detach(), unique, None, True, not need_grad)
+    if need_grad:
+        knn_trans = torch.gather(points_trans.unsqueeze(1).expand(-1, query_trans.size(1), -1, -1), 2,
+                                 point_indices.unsqueeze(-1).expand(-1, -1, -1, points_trans.size(-1)))
+    if NCHW:
+        knn_trans = knn_trans.permute(0, 3, 1, 2)
+    return knn_trans, point_indices, distances
+
+
+class GatherFunction(torch.autograd.Function):
+    """features (B,C,N), idx (B,npoint) -> (B,C,npoint)   (operations.py:219-263)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        features = features.contiguous()
+        idx = idx.contiguous().to(dtype=torch.int32)
+        _, C, N = features.size()
+        output = BACKEND.gather_forward(features, idx)
+        ctx.save_for_backward(idx)
+        ctx.C = C
+        ctx.N = N
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        grad_features = BACKEND.gather_backward(grad_out.contiguous(), idx, ctx.C, ctx.N)
+        return grad_features, None
+
+
+gather_points = GatherFunction.apply
+
+
+def fps(xyz, npoint, n_arr=None, m_arr=None):
+    """Channel-last FPS: xyz (B,N,3) -> idx int32 (B,npoint); ragged counts optional."""
+    return BACKEND.fps(xyz.contiguous(), npoint, n_arr, m_arr)
+
+
+def furthest_point_sample(xyz, npoint, NCHW=True):
+    """(operations.py:303-323)
+    :param
+        xyz (B, 3, N) or (B, N, 3)
+        npoint a constant
+    :return
+        idx     (B, npoint) int32 indices of the sampled points (non-differentiable)
+        points  (B, 3, npoint) or (B, npoint, 3) sampled point sets"""
+    assert(xyz.dim() == 3), "input for furthest sampling must be a 3D-tensor, but xyz.size() is {}".format(xyz.size())
+    if NCHW:
+        xyz = xyz.transpose(2, 1).contiguous()
+    assert(xyz.size(2) == 3), "furthest sampling is implemented for 3D points"
+    with torch.no_grad():
+        idx = BACKEND.fps(xyz.detach().contiguous(), npoint)
+    sampled_pc = gather_points(xyz.transpose(2, 1).contiguous(), idx)
+    if not NCHW:
+        sampled_pc = sampled_pc.transpose(2, 1).contiguous()
+    return idx, sampled_pc

@@ -1,0 +1,158 @@
+/*
+ * include/tpu3.h -- C ABI of lib3pu_hip.so, the MI355X (gfx950) implementation of the
+ * 3PU patch-upsampling hot path: farthest-point sampling, index gather, ball query,
+ * brute-force kNN grouping and the Chamfer "nm-distance" forward/backward.
+ *
+ * The entry points are what the reference's two pybind11 extension modules bind
+ * (`sampling`: sampling/sampling.cpp:83-88, `losses`: losses/nmdistance.cpp:24-27) plus the
+ * kNN grouping that the reference does in torch (network/operations.py:151-216).  Plain
+ * pointers and sizes only -- no torch types.  All pointers are DEVICE pointers unless said
+ * otherwise; `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ * Every function enqueues work on `stream` and returns immediately (no host synchronisation),
+ * like the reference's launches.
+ *
+ * Return value: 0 on success, a negative TPU3_E* code for a rejected argument, or a positive
+ * hipError_t when the launch failed (the reference prints and exit(-1)s instead,
+ * sampling/cuda_utils.h:26-37).
+ *
+ * "Ragged" batches: functions that take `n_arr` / `m_arr` accept NULL (every batch element
+ * uses the full n / m) or device arrays of `b` int32 holding the live point / query count of
+ * each batch element inside its padded (n, m)-sized slab.  The reference has no such thing;
+ * it is what lets the patch pipeline run all outer patches of a cloud in one launch after the
+ * data-dependent outlier filter (network/upsampler.py:63-80) made their sizes differ.
+ */
+#ifndef TPU3_H
+#define TPU3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPU3_OK 0
+#define TPU3_EINVAL (-1)   /* bad size / NULL pointer / unsupported element size */
+#define TPU3_ELIMIT (-2)   /* size beyond what this build supports             */
+
+typedef void *tpu3_stream_t; /* hipStream_t */
+
+/* Library identification: "3pu-hip <version> gfx950". */
+const char *tpu3_version(void);
+
+/* Human-readable text for a return code of this library (static storage). */
+const char *tpu3_strerror(int code);
+
+/* sampling.furthest_sampling  (sampling/sampling.cpp:26-35,85; kernel
+ * sampling/sampling_cuda.cu:103-174).
+ *   xyz  (b,n,3) f32 contiguous
+ *   temp (b,n)   f32 in/out: running squared distance to the chosen set; the caller
+ *                pre-fills it (1e10 in network/operations.py:291); on return it holds the
+ *                distances after the last update, as the reference leaves them
+ *   idx  (b,m)   i32 out; idx[:,0] = 0
+ * Tie rule identical to the reference's block reduction: among equal maxima the smallest
+ * (k mod bs), then the smallest k, with bs = largest power of two <= n clamped to [1,512]
+ * (sampling/cuda_utils.h:9-14).  Unlike the reference (temp indexed by blockIdx.x,
+ * sampling_cuda.cu:131,146) every batch element uses its own temp row, for any b. */
+int tpu3_fps_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz, float *temp,
+                 int32_t *idx);
+
+/* Ragged form: element i samples m_arr[i] (<= m) of its first n_arr[i] (<= n) points.
+ * `workspace` may be NULL or a device buffer of tpu3_fps_workspace_bytes(b, n) bytes; it is
+ * only needed when n exceeds the register-resident limit. */
+int tpu3_fps_ragged_f32(tpu3_stream_t stream, int b, int n, int m, const int32_t *n_arr,
+                        const int32_t *m_arr, const float *xyz, float *temp, int32_t *idx,
+                        void *workspace, size_t workspace_bytes);
+size_t tpu3_fps_workspace_bytes(int b, int n);
+
+/* sampling.gather_forward  (sampling/sampling.cpp:37-45,86; sampling_cuda.cu:28-41):
+ * out[b,c,j] = points[b,c,idx[b,j]].  elem_size = 2, 4 or 8 bytes (half/float/double: the
+ * reference dispatches on AT_DISPATCH_FLOATING_TYPES_AND_HALF, :48; the op is a copy). */
+int tpu3_gather_fwd(tpu3_stream_t stream, int b, int c, int n, int m, int elem_size,
+                    const void *points, const int32_t *idx, void *out);
+
+/* sampling.gather_backward  (sampling/sampling.cpp:47-53,87; sampling_cuda.cu:66-80):
+ * grad_points[b,c,idx[b,j]] += grad_out[b,c,j] (atomic); grad_points is zeroed by the
+ * caller (network/operations.py:257-258).  elem_size = 2 (f16), 4 (f32) or 8 (f64). */
+int tpu3_gather_bwd(tpu3_stream_t stream, int b, int c, int n, int m, int elem_size,
+                    const void *grad_out, const int32_t *idx, void *grad_points);
+
+/* sampling.ball_query  (sampling/sampling.cpp:59-81,88; sampling_cuda.cu:269-317).
+ * query (b,m,3), xyz (b,n,3) f32 (elem_size 4) or f64 (elem_size 8); idx (b,m,nsample) i32
+ * out.  The binding of the reference allocates idx as zeros (:69-71); this function zeroes
+ * it on the stream before the kernel, so queries without a hit read 0. */
+int tpu3_ball_query(tpu3_stream_t stream, int b, int n, int m, float radius, int nsample,
+                    int elem_size, const void *query, const void *xyz, int32_t *idx);
+
+/* losses.nmdistance_forward  (losses/nmdistance.cpp:12-14,25; nmdistance_cuda.cu:11-153).
+ * xyz1 (b,n,3), xyz2 (b,m,3) f32 -> dist1 (b,n), idx1 (b,n) i32: squared distance to and
+ * index of the nearest point of the other set (lowest index on exact ties); dist2/idx2 the
+ * same for xyz2.  Returns 0 on success (the reference returns 1/0, ignored by its caller;
+ * the Python mirror `losses.nmdistance_forward` maps 0 -> 1). */
+int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
+                        const float *xyz2, float *dist1, float *dist2, int32_t *idx1,
+                        int32_t *idx2);
+
+/* losses.nmdistance_backward  (losses/nmdistance.cpp:17-21,26; nmdistance_cuda.cu:154-193).
+ * Adds into caller-zeroed gradxyz1 (b,n,3), gradxyz2 (b,m,3). */
+int tpu3_nmdist_bwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
+                        const float *xyz2, float *gradxyz1, float *gradxyz2,
+                        const float *graddist1, const float *graddist2, const int32_t *idx1,
+                        const int32_t *idx2);
+
+/* Optional batch layout of a kNN call (host struct, pointers inside are DEVICE pointers).
+ * NULL layout = the reference's dense call: b query sets, b point sets, one group.
+ *   n_arr   (bp)  live points of each point set inside its padded n-slab, or NULL
+ *   m_arr   (b)   live queries of each query set, or NULL (padded queries give unspecified rows)
+ *   pts_of  (b)   which point set each query set searches, or NULL (identity, bp == b).  This is
+ *                 the reference's `previous_xyz.expand(batch_size, -1, -1)` (upsampler.py:319-323)
+ *                 without materialising the copies
+ *   grp     (b)   group of each query set, or NULL (one group).  unique=True adds max(D) taken
+ *                 over one reference call's whole batch (operations.py:204); a launch that fuses
+ *                 several reference calls keeps one maximum per group
+ *   bp, groups    number of point sets / groups (ignored when the pointer is NULL) */
+typedef struct {
+    const int32_t *n_arr;
+    const int32_t *m_arr;
+    const int32_t *pts_of;
+    const int32_t *grp;
+    int bp;
+    int groups;
+} tpu3_knn_layout;
+
+/* Number of u32 words of the unique=True scratch `uws` for `groups` groups (>= 1). */
+#define TPU3_KNN_UWS_WORDS(groups) (4 + (groups))
+
+/* kNN grouping = network.operations.group_knn (network/operations.py:151-216) without the
+ * (B,M,N) distance matrix.  Channel-last inputs: query (b,m,c), points (bp,n,c) f32.
+ *   D[q,p] = fmaf(-2, <q,p>, |q|^2) + |p|^2, dot and norms as ascending-channel fmaf chains
+ *   (the reference leaves torch.matmul's order unspecified; this is the oracle's order).
+ * k smallest per query, ascending, ties to the lowest index.
+ *   idx      (b,m,k) i32 or i64 (idx_elem_size 4 / 8; torch.topk returns int64)
+ *   dist     (b,m,k) f32, may be NULL
+ *   grouped  (b,m,k,c) f32 gathered neighbours, may be NULL (the reference returns this as a
+ *            (b,c,m,k) permuted view of exactly this layout, :209-214)
+ *   dup/uws  unique=True support (:192-204): NULL/NULL for unique=False, else the outputs of
+ *            tpu3_knn_unique_prepare_f32 for the same query/points/layout. */
+int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
+                 const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
+                 const uint32_t *uws, void *idx, int idx_elem_size, float *dist, float *grouped);
+
+/* unique=True pre-pass: dup (bp,n) u8 = 1 iff an identical row exists at a smaller index of
+ * the same point set (complement of np.unique(axis=0, return_index=True), operations.py:194-200)
+ * and, only if any row anywhere is a duplicate, max(D) per group (operations.py:204).
+ * uws = TPU3_KNN_UWS_WORDS(groups) device words: [0] any-dup flag, [1..3] reserved,
+ * [4+g] max(D) of group g as order-preserving bits. */
+int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c,
+                                const float *query, const float *points,
+                                const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws);
+
+/* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
+ * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
+int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
+                       float *out, float *centroid, float *radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPU3_H */

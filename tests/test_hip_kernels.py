@@ -1,0 +1,324 @@
+"""-m gpu: parity of the HIP kernels (through the drop-in modules / C ABI) with the CPU oracle on
+the same seeded inputs.  Integer outputs are compared bit-exactly; float outputs bit-exactly
+where the arithmetic is pinned, otherwise within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg, sphere
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ---- farthest point sampling (a1) ----------------------------------------------------------
+@pytest.mark.parametrize("b,n,m", [(1, 312, 10), (3, 624, 10), (2, 1247, 19), (1, 2496, 40),
+                                   (1, 5000, 48), (2, 6240, 1248), (1, 12480, 2496),
+                                   (1, 24960, 4992), (48, 312, 33), (1, 100, 100), (1, 7, 5),
+                                   (1, 512, 64), (1, 511, 64), (1, 1, 1), (40, 700, 50)])
+def test_fps_bit_exact(orc, dev, b, n, m):
+    sampling = pkg("sampling")
+    xyz = sphere(1000 + n, n, b)
+    ref_idx, ref_temp = orc.fps(xyz, m)
+    x = _t(xyz, dev)
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.empty((b, m), dtype=torch.int32, device=dev)
+    out = sampling.furthest_sampling(b, n, m, x, temp, idx)
+    assert out.data_ptr() == idx.data_ptr()
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+def test_fps_streaming_kernel_large_n(orc, dev):
+    sampling = pkg("sampling")
+    n, m = 30000, 300
+    xyz = sphere(7, n, 1)
+    ref_idx, ref_temp = orc.fps(xyz, m)
+    temp = torch.full((1, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.empty((1, m), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(1, n, m, _t(xyz, dev), temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+@pytest.mark.parametrize("n", [300, 700, 3000])
+def test_fps_tie_rule_with_duplicated_points(orc, dev, n):
+    """Exact ties only arise from duplicated points (pc_utils.load pads clouds that way); the
+    winner must be the reference's (k mod bs, k) order, not simply the lowest index."""
+    sampling = pkg("sampling")
+    rng = np.random.default_rng(n)
+    base = sphere(n, n // 3, 1)[0]
+    xyz = base[rng.integers(0, base.shape[0], size=n)][None]      # every point ~3 times
+    m = n // 2
+    ref_idx, _ = orc.fps(xyz, m)
+    temp = torch.full((1, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.empty((1, m), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(1, n, m, _t(xyz, dev), temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+
+
+def test_fps_ragged_matches_per_element_calls(orc, dev):
+    ops = pkg("network.operations")
+    b, n = 5, 640
+    xyz = sphere(3, n, b)
+    n_arr = np.array([640, 623, 600, 512, 333], np.int32)
+    m_arr = np.array([10, 9, 9, 8, 5], np.int32)
+    idx = ops.fps(_t(xyz, dev), 10, _t(n_arr, dev), _t(m_arr, dev)).cpu().numpy()
+    for i in range(b):
+        ref, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], int(m_arr[i]))
+        np.testing.assert_array_equal(idx[i, :m_arr[i]], ref[0])
+
+
+def test_fps_rejects_cpu_and_noncontiguous(dev):
+    sampling = pkg("sampling")
+    x = torch.zeros(1, 8, 3)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        sampling.furthest_sampling(1, 8, 2, x, torch.zeros(1, 8), torch.zeros(1, 2, dtype=torch.int32))
+    xd = torch.zeros(1, 3, 8, device=dev).transpose(2, 1)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        sampling.furthest_sampling(1, 8, 2, xd, torch.zeros(1, 8, device=dev),
+                                   torch.zeros(1, 2, dtype=torch.int32, device=dev))
+
+
+# ---- gather (a2, a3) -------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+def test_gather_forward(orc, dev, dtype):
+    sampling = pkg("sampling")
+    rng = np.random.default_rng(0)
+    b, c, n, m = 3, 5, 777, 300
+    pts = rng.standard_normal((b, c, n)).astype(dtype)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    out = torch.empty((b, c, m), dtype=_t(pts, dev).dtype, device=dev)
+    sampling.gather_forward(b, c, n, m, _t(pts, dev), _t(idx, dev), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), orc.gather_fwd(pts, idx))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-5), (np.float64, 1e-12)])
+def test_gather_backward(orc, dev, dtype, tol):
+    sampling = pkg("sampling")
+    rng = np.random.default_rng(1)
+    b, c, n, m = 2, 4, 50, 400          # many collisions per target
+    g = rng.standard_normal((b, c, m)).astype(dtype)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    gp = torch.zeros((b, c, n), dtype=_t(g, dev).dtype, device=dev)
+    sampling.gather_backward(b, c, n, m, _t(g, dev), _t(idx, dev), gp)
+    # atomic summation order is unspecified (as in the reference): tolerance, not bits
+    np.testing.assert_allclose(gp.cpu().numpy(), orc.gather_bwd(g, idx, n), rtol=tol, atol=tol)
+
+
+def test_gather_points_autograd(dev):
+    ops = pkg("network.operations")
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 40, dtype=torch.float64, device=dev, requires_grad=True)
+    idx = torch.randint(0, 40, (2, 16), dtype=torch.int32, device=dev)
+    assert torch.autograd.gradcheck(ops.gather_points, (x, idx), eps=1e-6, atol=1e-4)
+
+
+# ---- ball query (a4) -------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ball_query(orc, dev, dtype):
+    sampling = pkg("sampling")
+    b, m, n, ns, r = 4, 312, 5000, 32, 0.1
+    xyz = sphere(11, n, b).astype(dtype)
+    q = xyz[:, :m].copy()
+    q[:, -1] = 50.0                      # a query with no neighbour at all -> zeros
+    out = sampling.ball_query(_t(q, dev), _t(xyz, dev), r, ns)
+    assert out.dtype == torch.int32 and tuple(out.shape) == (b, m, ns)
+    ref = orc.ball_query(q, xyz, r, ns)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert (ref[:, -1] == 0).all()
+
+
+# ---- nm-distance (a5, a6) --------------------------------------------------------------------
+@pytest.mark.parametrize("b,n,m", [(32, 624, 624), (2, 1000, 513), (1, 5000, 4992), (3, 1, 7),
+                                   (1, 20000, 20000)])
+def test_nmdistance_forward_bit_exact(orc, dev, b, n, m):
+    losses = pkg("losses")
+    x1 = sphere(5, n, b)
+    x2 = sphere(6, m, b) * np.float32(1.01)
+    d1 = torch.empty((b, n), device=dev)
+    d2 = torch.empty((b, m), device=dev)
+    i1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    i2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    assert losses.nmdistance_forward(_t(x1, dev), _t(x2, dev), d1, d2, i1, i2) == 1
+    rd1, ri1, rd2, ri2 = orc.nmdistance_fwd(x1, x2)
+    np.testing.assert_array_equal(i1.cpu().numpy(), ri1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), ri2)
+    np.testing.assert_array_equal(d1.cpu().numpy(), rd1)
+    np.testing.assert_array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_nmdistance_ties_go_to_lowest_index(orc, dev):
+    losses = pkg("losses")
+    x2 = np.repeat(sphere(9, 300, 1), 3, axis=1)          # every target three times
+    x1 = sphere(10, 700, 1)
+    outs = [torch.empty((1, 700), device=dev), torch.empty((1, 900), device=dev),
+            torch.empty((1, 700), dtype=torch.int32, device=dev),
+            torch.empty((1, 900), dtype=torch.int32, device=dev)]
+    losses.nmdistance_forward(_t(x1, dev), _t(x2, dev), *outs)
+    _, ri1, _, ri2 = orc.nmdistance_fwd(x1, x2)
+    np.testing.assert_array_equal(outs[2].cpu().numpy(), ri1)
+    np.testing.assert_array_equal(outs[3].cpu().numpy(), ri2)
+
+
+def test_nmdistance_backward(orc, dev):
+    losses = pkg("losses")
+    rng = np.random.default_rng(2)
+    b, n, m = 4, 624, 500
+    x1, x2 = sphere(1, n, b), sphere(2, m, b)
+    _, i1, _, i2 = orc.nmdistance_fwd(x1, x2)
+    g1 = rng.standard_normal((b, n)).astype(np.float32)
+    g2 = rng.standard_normal((b, m)).astype(np.float32)
+    gx1 = torch.zeros((b, n, 3), device=dev)
+    gx2 = torch.zeros((b, m, 3), device=dev)
+    assert losses.nmdistance_backward(_t(x1, dev), _t(x2, dev), gx1, gx2, _t(g1, dev), _t(g2, dev),
+                                      _t(i1, dev), _t(i2, dev)) == 1
+    r1, r2 = orc.nmdistance_bwd(x1, x2, g1, g2, i1, i2)
+    np.testing.assert_allclose(gx1.cpu().numpy(), r1, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gx2.cpu().numpy(), r2, rtol=1e-5, atol=1e-5)
+
+
+# ---- kNN grouping (a8) -----------------------------------------------------------------------
+def _knn_check(orc, dev, k, q, p, unique, layout=None):
+    ops = pkg("network.operations")
+    idx, dist, grouped = ops.knn_query(k, _t(q, dev), _t(p, dev), unique=unique, layout=layout)
+    ri, rd = orc.knn(k, q, p, unique)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri.astype(np.int64))
+    np.testing.assert_array_equal(dist.cpu().numpy(), rd)
+    bi = np.arange(p.shape[0])[:, None, None]
+    np.testing.assert_array_equal(grouped.cpu().numpy(), p[bi, ri])
+
+
+@pytest.mark.parametrize("k,b,m,n,c,unique", [
+    (312, 1, 48, 5000, 3, True),       # outer patches
+    (2, 2, 624, 624, 3, False),        # outlier test
+    (2, 1, 2496, 2496, 3, False),
+    (312, 2, 10, 624, 3, False),       # inner patches
+    (312, 1, 40, 2496, 3, False),
+    (33, 10, 312, 312, 24, True),      # feature-space graph
+    (17, 3, 312, 312, 24, True),
+    (5, 10, 312, 312, 3, True),        # inter-level skip
+    (5, 4, 312, 3120, 3, True),
+    (5, 2, 312, 6240, 3, True),
+    (64, 2, 100, 400, 7, False),       # odd channel counts / k
+    (100, 2, 50, 300, 40, True),       # c > 32 and k > 64 -> sort kernel, generic dmax
+    (1024, 1, 3, 20000, 3, False),     # chunked sort (n > LDS tile)
+    (1, 1, 5, 9, 3, False),
+    (9, 1, 5, 9, 3, False),            # k == n
+])
+def test_knn_bit_exact(orc, dev, k, b, m, n, c, unique):
+    rng = np.random.default_rng(k * 1000 + n + c)
+    if c == 3:
+        p = sphere(n + c, n, b)
+    else:
+        p = rng.standard_normal((b, n, c)).astype(np.float32)
+    q = p[:, :m].copy() if m <= n else rng.standard_normal((b, m, c)).astype(np.float32)
+    if m <= n and k % 2 == 1:
+        q = q + rng.standard_normal(q.shape).astype(np.float32) * np.float32(0.01)
+    _knn_check(orc, dev, k, q, p, unique)
+
+
+@pytest.mark.parametrize("k,c,n", [(5, 3, 936), (33, 24, 312), (312, 3, 700)])
+def test_knn_unique_with_duplicate_rows(orc, dev, k, c, n):
+    """unique=True semantics (operations.py:192-204): rows that repeat an earlier row get
+    +max(D) (max over the whole batch tensor) -- the load-bearing case is the inter-level skip
+    over merged, overlapping patches."""
+    rng = np.random.default_rng(n)
+    b = 3
+    base = rng.standard_normal((b, (n + 2) // 3, c)).astype(np.float32)
+    p = np.concatenate([base, base, base], axis=1)[:, :n]
+    perm = rng.permutation(n)
+    p = np.ascontiguousarray(p[:, perm])
+    p[1] = rng.standard_normal((n, c)).astype(np.float32)      # one batch element without dups
+    q = p[:, :200] + np.float32(0.05) * rng.standard_normal((b, 200, c)).astype(np.float32)
+    dup = orc.first_occurrence_dup(p)
+    assert dup[0].sum() > 0 and dup[1].sum() == 0
+    _knn_check(orc, dev, k, q, p, True)
+    _knn_check(orc, dev, k, q, p, False)
+
+
+def test_knn_layout_shared_points_groups_and_ragged(orc, dev):
+    """One launch that fuses several reference calls: query sets map onto shared point sets
+    (pts_of), max(D) is kept per group, and point/query counts are ragged."""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(5)
+    bp, n, c, k, m = 3, 700, 3, 5, 312
+    pts = sphere(1, n, bp)
+    pts[0, 350:] = pts[0, :350]                      # point set 0 has duplicates
+    pts[2, 600:] = pts[2, :100]
+    n_arr = np.array([700, 650, 700], np.int32)
+    pts_of = np.array([0, 0, 1, 1, 1, 2], np.int32)
+    grp = pts_of.copy()
+    b = len(pts_of)
+    m_arr = np.array([312, 300, 312, 1, 312, 200], np.int32)
+    q = (sphere(2, m, b) + rng.standard_normal((b, m, 3)).astype(np.float32) * np.float32(0.01))
+    layout = dict(n_arr=_t(n_arr, dev), m_arr=_t(m_arr, dev), pts_of=_t(pts_of, dev),
+                  grp=_t(grp, dev), groups=3)
+    idx, dist, grouped = ops.knn_query(k, _t(q, dev), _t(pts, dev), unique=True, layout=layout)
+    idx, dist, grouped = idx.cpu().numpy(), dist.cpu().numpy(), grouped.cpu().numpy()
+    for g in range(3):                               # one reference call per group
+        members = np.where(grp == g)[0]
+        pn = pts[g:g + 1, :n_arr[g]]
+        # the reference call: all member query sets against the (expanded) shared point set;
+        # ragged queries are emulated by evaluating every member at full m and trimming, which
+        # is only valid when the trimmed queries cannot hold the batch max -> use the full-m
+        # members' maximum by evaluating the live queries only
+        live_q = np.concatenate([q[i, :m_arr[i]] for i in members])[None]
+        ri, rd = orc.knn(k, live_q, pn, True)
+        off = 0
+        for i in members:
+            mi = m_arr[i]
+            np.testing.assert_array_equal(idx[i, :mi], ri[0, off:off + mi])
+            np.testing.assert_array_equal(dist[i, :mi], rd[0, off:off + mi])
+            np.testing.assert_array_equal(grouped[i, :mi], pn[0][ri[0, off:off + mi]])
+            off += mi
+
+
+def test_group_knn_signature_and_views(orc, dev):
+    ops = pkg("network.operations")
+    p = sphere(3, 500, 2).transpose(0, 2, 1).copy()          # (B,3,N)
+    q = p[:, :, :64].copy()
+    nb, idx, dist = ops.group_knn(16, _t(q, dev), _t(p, dev), unique=True, NCHW=True)
+    assert tuple(nb.shape) == (2, 3, 64, 16) and idx.dtype == torch.int64
+    assert nb.stride() == (64 * 16 * 3, 1, 16 * 3, 3)       # permuted view of (B,M,k,C), like the reference
+    rnb, ridx, rdist = orc.group_knn(16, q, p, unique=True, NCHW=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(nb.cpu().numpy(), rnb)
+    np.testing.assert_array_equal(dist.cpu().numpy(), rdist)
+    nb2, idx2, _ = ops.group_knn(16, _t(q.transpose(0, 2, 1).copy(), dev),
+                                 _t(p.transpose(0, 2, 1).copy(), dev), unique=False, NCHW=False)
+    assert tuple(nb2.shape) == (2, 64, 16, 3)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ridx)
+    with pytest.raises(AssertionError, match="greater or equal to k"):
+        ops.group_knn(501, _t(q, dev), _t(p, dev))
+
+
+# ---- normalisation (a7) and FPS call site ----------------------------------------------------
+def test_normalize_point_batch(orc, dev):
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(4)
+    pc = (sphere(8, 312, 40) * np.float32(0.3) + rng.standard_normal((40, 1, 3)).astype(np.float32))
+    pc = np.ascontiguousarray(pc.transpose(0, 2, 1))
+    out, c, r = ops.normalize_point_batch(_t(pc, dev), NCHW=True)
+    ro, rc, rr = orc.normalize_point_batch(pc, NCHW=True)
+    assert tuple(c.shape) == (40, 3, 1) and tuple(r.shape) == (40, 1, 1)
+    # fp32 sums in a different order than numpy/torch: 1e-5 (the north-star tolerance)
+    np.testing.assert_allclose(out.cpu().numpy(), ro, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), rc, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r.cpu().numpy(), rr, rtol=1e-5, atol=1e-6)
+    out2, c2, r2 = ops.normalize_point_batch(_t(pc.transpose(0, 2, 1).copy(), dev), NCHW=False)
+    assert tuple(c2.shape) == (40, 1, 3)
+    np.testing.assert_allclose(out2.cpu().numpy(), ro.transpose(0, 2, 1), rtol=1e-5, atol=1e-5)
+
+
+def test_furthest_point_sample_call_site(orc, dev):
+    ops = pkg("network.operations")
+    xyz = np.ascontiguousarray(sphere(12, 5000, 1).transpose(0, 2, 1))
+    idx, pts = ops.furthest_point_sample(_t(xyz, dev), 48, NCHW=True)
+    ridx, rpts = orc.furthest_point_sample(xyz, 48, NCHW=True)
+    assert idx.dtype == torch.int32 and tuple(pts.shape) == (1, 3, 48)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(pts.cpu().numpy(), rpts)
