@@ -1,0 +1,196 @@
+"""Per-patch feature stacks of 3PU for PyTorch-ROCm -- counterpart of the reference's
+network/layers.py (DenseEdgeConv :6-64, Conv2d :115-158, Conv1d :161-204).
+
+Same classes, constructor arguments, parameter names and shapes (so reference checkpoints load:
+`layerK.mlps.{0,1,2}.{weight,bias}`, `*.conv.{weight,bias}`), different execution:
+
+  * activations are kept channel-last, (B, N, C) / (B, N, k, C): every 1x1 convolution of the
+    reference is then one dense row-major GEMM [B*N(*k), C_in] x [C_in, C_out] that rocBLAS /
+    hipBLASLt maps onto MFMA, instead of an NCHW convolution with 12 output channels;
+  * the k-NN graph comes from the fused HIP kernel (indices + gathered neighbours in one pass,
+    no (B,N,N) distance matrix, no host round trip for unique=True);
+  * the dense concatenations write into one pre-allocated (B,N,k,C_total) buffer slice by slice
+    instead of re-copying the growing tensor at every torch.cat.
+
+The NCHW `forward` keeps the reference's calling convention; `forward_cl` is the channel-last
+entry the Level uses.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import operations
+
+
+def linear_1x1(conv, x):
+    """Apply a kernel-size-1 nn.Conv1d / nn.Conv2d to channel-last activations (..., C_in)."""
+    w = conv.weight
+    return F.linear(x, w.view(w.size(0), w.size(1)), conv.bias)
+
+
+class DenseEdgeConv(nn.Module):
+    """Dense edge convolution block (reference layers.py:6-64): feature-space kNN graph, edge
+    feature [x_i, x_j - x_i], `n` 1x1 convolutions with dense concatenation, max over k."""
+
+    def __init__(self, in_channels, growth_rate, n, k, **kwargs):
+        super(DenseEdgeConv, self).__init__()
+        self.growth_rate = growth_rate
+        self.n = n
+        self.k = k
+        self.in_channels = in_channels
+        self.mlps = torch.nn.ModuleList()
+        self.mlps.append(torch.nn.Conv2d(2 * in_channels, growth_rate, 1, bias=True))
+        for i in range(1, n):
+            in_channels += growth_rate
+            self.mlps.append(torch.nn.Conv2d(in_channels, growth_rate, 1, bias=True))
+
+    def get_local_graph_cl(self, x, k, idx=None, layout=None):
+        """x (B,N,C) -> edge feature (B,N,k,2C) = [x_i, x_j - x_i], idx (B,N,k).
+        The first of the k+1 neighbours is dropped as in the reference (:33-35)."""
+        need_grad = x.requires_grad and torch.is_grad_enabled()
+        if idx is None:
+            with torch.no_grad():
+                idx, _, knn_point = operations.knn_query(
+                    k + 1, x.detach(), x.detach(), unique=True, layout=layout,
+                    want_dist=False, want_grouped=not need_grad)
+            idx = idx[:, :, 1:]
+            if not need_grad:
+                knn_point = knn_point[:, :, 1:, :]
+        else:
+            knn_point = None
+        if knn_point is None or need_grad:
+            b = torch.arange(x.size(0), device=x.device).view(-1, 1, 1)
+            knn_point = x[b, idx]                      # differentiable gather (B,N,k,C)
+        center = x.unsqueeze(2).expand_as(knn_point)
+        return torch.cat([center, knn_point - center], dim=-1), idx
+
+    def forward_cl(self, x, idx=None, layout=None):
+        """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k)."""
+        B, N, C = x.shape
+        g, n, k = self.growth_rate, self.n, self.k
+        edge, idx = self.get_local_graph_cl(x, k, idx, layout)
+        if torch.is_grad_enabled():
+            # training: autograd-friendly concatenations, exactly the reference's dataflow (:53-61)
+            y = torch.cat([F.relu(linear_1x1(self.mlps[0], edge)),
+                           x.unsqueeze(2).expand(-1, -1, k, -1)], dim=-1)
+            for i in range(1, n):
+                h = linear_1x1(self.mlps[i], y)
+                y = torch.cat([h if i == n - 1 else F.relu(h), y], dim=-1)
+        else:
+            # inference: y = [h_{n-1}, ..., h_1, h_0, x_i] along channels, one buffer filled from
+            # the back (no re-copy of the growing tensor per concatenation)
+            total = C + n * g
+            y = x.new_empty((B, N, k, total))
+            y[..., total - C:] = x.unsqueeze(2)
+            lo = total - C - g
+            y[..., lo:lo + g] = F.relu_(linear_1x1(self.mlps[0], edge))    # layer 0: ReLU (:57)
+            for i in range(1, n):
+                h = linear_1x1(self.mlps[i], y[..., lo:])
+                if i != n - 1:
+                    h = F.relu_(h)                                          # last layer: none (:59)
+                lo -= g
+                y[..., lo:lo + g] = h
+        y, _ = torch.max(y, dim=2)
+        return y, idx
+
+    def forward(self, x, idx=None):
+        """x (B,C,N) -> y (B,C',N), idx (B,N,k)   (reference :44-64)."""
+        y, idx = self.forward_cl(x.transpose(2, 1).contiguous(), idx)
+        return y.transpose(2, 1).contiguous(), idx
+
+
+def _make_norm(normalization, out_channels, momentum, dims):
+    if normalization == 'batch':
+        cls = nn.BatchNorm2d if dims == 2 else nn.BatchNorm1d
+    elif normalization == 'instance':
+        cls = nn.InstanceNorm2d if dims == 2 else nn.InstanceNorm1d
+    else:
+        raise ValueError("only \"batch/instance\" normalization permitted.")
+    return cls(out_channels, affine=True, eps=0.001, momentum=momentum)
+
+
+def _make_act(activation):
+    if activation == 'relu':
+        return nn.ReLU()
+    if activation == 'elu':
+        return nn.ELU(alpha=1.0)
+    if activation == 'lrelu':
+        return nn.LeakyReLU(0.1)
+    raise ValueError("only \"relu/elu/lrelu\" allowed")
+
+
+class Conv2d(nn.Module):
+    """2d convolution with custom normalization and activation (reference layers.py:115-158)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True,
+                 activation=None, normalization=None, momentum=0.01):
+        super(Conv2d, self).__init__()
+        self.activation = activation
+        self.normalization = normalization
+        bias = not normalization and bias
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size,
+                              stride=stride, padding=padding, bias=bias)
+        if normalization is not None:
+            self.norm = _make_norm(normalization, out_channels, momentum, 2)
+        if activation is not None:
+            self.act = _make_act(activation)
+
+    def pointwise(self):
+        """True when the layer is a pure per-point linear map (+activation): the only form the
+        hot path uses (every call site passes kernel size 1 and normalization=None)."""
+        c = self.conv
+        return (self.normalization is None and tuple(c.kernel_size) == (1, 1)
+                and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0))
+
+    def forward_cl(self, x):
+        """channel-last (..., C_in) -> (..., C_out)."""
+        assert self.pointwise()
+        x = linear_1x1(self.conv, x)
+        if self.activation is not None:
+            x = self.act(x)
+        return x
+
+    def forward(self, x, epoch=None):
+        x = self.conv(x)
+        if self.normalization is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.act(x)
+        return x
+
+
+class Conv1d(nn.Module):
+    """1d convolution with custom normalization and activation (reference layers.py:161-204)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True,
+                 activation=None, normalization=None, momentum=0.01):
+        super(Conv1d, self).__init__()
+        self.activation = activation
+        self.normalization = normalization
+        bias = not normalization and bias
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size,
+                              stride=stride, padding=padding, bias=bias)
+        if normalization is not None:
+            self.norm = _make_norm(normalization, out_channels, momentum, 1)
+        if activation is not None:
+            self.act = _make_act(activation)
+
+    def pointwise(self):
+        c = self.conv
+        return (self.normalization is None and tuple(c.kernel_size) == (1,)
+                and tuple(c.stride) == (1,) and tuple(c.padding) == (0,))
+
+    def forward_cl(self, x):
+        assert self.pointwise()
+        x = linear_1x1(self.conv, x)
+        if self.activation is not None:
+            x = self.act(x)
+        return x
+
+    def forward(self, x, epoch=None):
+        x = self.conv(x)
+        if self.normalization is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.act(x)
+        return x

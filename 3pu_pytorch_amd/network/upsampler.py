@@ -1,0 +1,341 @@
+"""Progressive patch upsampler of 3PU for PyTorch-ROCm -- counterpart of the reference's
+network/upsampler.py (Net :9-189, Level :192-374; the never-instantiated AdaptiveLevel is out of
+scope).  Same constructor arguments, module names and parameter shapes (reference checkpoints
+load unchanged), same numerical definition of every step; the execution is re-designed:
+
+  * `Net.forward` in eval mode accepts ANY batch of input patches (the reference asserts
+    batch 1, :61) and runs all of them through each level together: the data-dependent sizes
+    the outlier filter creates (:63-80) are kept on the device as per-patch counts next to
+    fixed-size padded tensors, so a whole cloud (48 outer patches x 4 levels) costs a few dozen
+    launches and zero host synchronisations instead of ~200 Level calls and ~400 syncs;
+  * the inter-level skip searches the previous level's merged cloud through an index map
+    (`pts_of`) instead of `expand`-ing it per patch (:319-323), and de-duplicates it once per
+    cloud on the device instead of once per patch on the host;
+  * activations are channel-last (see layers.py).
+"""
+from collections import OrderedDict
+from math import log, sqrt
+
+import torch
+
+from . import layers
+from . import operations
+
+
+def _arange_like(n, t):
+    return torch.arange(n, device=t.device)
+
+
+class Net(torch.nn.Module):
+    """3PU inter-level plus skip connection and dense layers (reference :9-189)."""
+
+    def __init__(self, max_up_ratio=16, step_ratio=2, knn=16, growth_rate=12,
+                 dense_n=3, max_num_point=312, fm_knn=3, **kwargs):
+        super(Net, self).__init__()
+        self.max_up_ratio = max_up_ratio
+        self.step_ratio = step_ratio
+        self.knn = knn
+        self.growth_rate = growth_rate
+        self.dense_n = dense_n
+        self.fm_knn = fm_knn
+        self.num_levels = int(log(max_up_ratio, step_ratio))
+        self.levels = torch.nn.ModuleDict()
+        self.max_num_point = max_num_point
+        for l in range(1, self.num_levels + 1):
+            # NB the reference does not forward fm_knn to Level (:25-26): every level uses 5
+            self.levels['level_%d' % l] = Level(
+                dense_n=dense_n, growth_rate=growth_rate, knn=knn, step_ratio=step_ratio)
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d)):
+                    torch.nn.init.xavier_uniform_(m.weight)
+                    torch.nn.init.zeros_(m.bias)
+                elif isinstance(m, (torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d,
+                                    torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    torch.nn.init.zeros_(m.bias)
+                    torch.nn.init.ones_(m.weight)
+        # number of (outer patch, level) pairs whose filtered cloud was smaller than a patch
+        # (the batched eval path assumes it never is; checked by the pipeline at its one sync)
+        self.small_cloud_events = None
+        # optional list: when set, the eval path appends one dict per level
+        # (patch_xyz (P,3,k) un-normalised inputs, out_norm (P,3,k*r) level output, patch_num)
+        self.trace = None
+
+    # ------------------------------------------------------------------------------------------
+    # training: the reference's flow (:52-58, :83-105), one random kNN patch per batch element
+    # ------------------------------------------------------------------------------------------
+    def extract_xyz_feature_patch(self, batch_xyz, k, gt_xyz=None, gt_k=None):
+        """Training-mode patch extraction: Bx3xN -> Bx3xk (+ ground-truth patch Bx3xgt_k)."""
+        batch_size, _, num_point = batch_xyz.size()
+        seed_idx = torch.randint(low=0, high=num_point, size=[batch_size, 1], dtype=torch.int32,
+                                 layout=torch.strided, device=batch_xyz.device)
+        batch_seed_point = operations.gather_points(batch_xyz, seed_idx)
+        batch_xyz, _, _ = operations.group_knn(k, batch_seed_point, batch_xyz, unique=False, NCHW=True)
+        batch_xyz = torch.cat(torch.unbind(batch_xyz, dim=2), dim=0)
+        if gt_xyz is not None and gt_k is not None:
+            gt_xyz, _, _ = operations.group_knn(gt_k, batch_seed_point, gt_xyz, unique=False)
+            gt_xyz = torch.cat(torch.unbind(gt_xyz, dim=2), dim=0)
+        else:
+            gt_xyz = None
+        return batch_xyz, gt_xyz
+
+    def _forward_train(self, xyz, ratio, gt):
+        batch_size, _, num_point = xyz.size()
+        num_levels = int(log(ratio, self.step_ratio))
+        max_num_point = min(num_point, self.max_num_point)
+        for l in range(1, num_levels + 1):
+            curr_ratio = self.step_ratio ** l
+            if l > 1:
+                if xyz.size(-1) > max_num_point:
+                    gt_k = max_num_point * ratio // curr_ratio * self.step_ratio
+                    patch_xyz, gt = self.extract_xyz_feature_patch(
+                        xyz, max_num_point, gt_k=gt_k, gt_xyz=gt)
+                else:
+                    patch_xyz = xyz
+                patch_xyz_normalized, centroid, radius = operations.normalize_point_batch(
+                    patch_xyz, NCHW=True)
+                xyz, features = self.levels['level_%d' % l](
+                    patch_xyz, patch_xyz_normalized, previous_level4=(old_xyz, old_features))
+                xyz = xyz * radius + centroid
+                old_xyz = patch_xyz
+                old_features = features
+            else:
+                old_xyz = xyz
+                xyz, features = self.levels['level_%d' % l](xyz, xyz, previous_level4=None)
+                old_features = features
+        return xyz, gt
+
+    # ------------------------------------------------------------------------------------------
+    # inference: all patches of the batch advance level by level together
+    # ------------------------------------------------------------------------------------------
+    def _repatch(self, xyz_cl, k):
+        """Eval-mode patch extraction (reference :59-86) for a batch of clouds at once.
+        xyz_cl (B,N,3) -> patches (B,P,k,3) with P = int(N/k*5), live patch count (B,) int32
+        (patches beyond a cloud's count repeat its last live patch and are never merged)."""
+        B, N, _ = xyz_cl.shape
+        dev = xyz_cl.device
+        # distance to the closest neighbour; points far from everything are outliers (:63-73)
+        _, closest_d, _ = operations.knn_query(2, xyz_cl, xyz_cl, unique=False, want_grouped=False)
+        closest_d = closest_d[:, :, 1]
+        mask = closest_d < (5 * torch.mean(closest_d, dim=1, keepdim=True))
+        count = mask.sum(dim=1).to(torch.int32)
+        order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)   # masked_select order
+        xyz_f = torch.gather(xyz_cl, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+        # patch_num = int(num_point / k * 5) per cloud, in double like Python (:76)
+        P = int(N / k * 5)
+        patch_num = torch.floor(count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
+        small = (count < k).sum()
+        self.small_cloud_events = small if self.small_cloud_events is None else self.small_cloud_events + small
+        kk = min(k, N)
+        seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
+        slot = torch.minimum(_arange_like(P, xyz_cl).view(1, P), (patch_num - 1).view(B, 1).long())
+        seed_idx = torch.gather(seed_idx.long(), 1, slot)
+        seeds = torch.gather(xyz_f, 1, seed_idx.unsqueeze(-1).expand(-1, -1, 3))
+        _, _, patches = operations.knn_query(kk, seeds, xyz_f, unique=False,
+                                             layout=dict(n_arr=count), want_dist=False)
+        return patches, patch_num
+
+    def _forward_eval(self, xyz, ratio):
+        B, _, num_point = xyz.size()
+        dev = xyz.device
+        num_levels = int(log(ratio, self.step_ratio))
+        max_num_point = min(num_point, self.max_num_point)
+        self.small_cloud_events = None
+        xyz_cl = xyz.transpose(2, 1).contiguous()                     # (B,N,3)
+        for l in range(1, num_levels + 1):
+            curr_ratio = self.step_ratio ** l
+            level = self.levels['level_%d' % l]
+            if l == 1:
+                # every input patch is its own reference call: its own unique-max group
+                each = torch.arange(B, dtype=torch.int32, device=dev)
+                old_xyz, old_count = xyz_cl, None
+                if self.trace is not None:
+                    self.trace.append(dict(patch_xyz=xyz_cl.transpose(2, 1)))
+                xyz_cl, old_feat = level.forward_cl(xyz_cl, xyz_cl, None, owner=each, groups=B)
+                if self.trace is not None:
+                    self.trace[-1]["out_norm"] = xyz_cl.transpose(2, 1)
+                continue
+            if xyz_cl.size(1) > max_num_point:
+                patches, patch_num = self._repatch(xyz_cl, max_num_point)      # (B,P,k,3)
+            else:
+                patches = xyz_cl.unsqueeze(1)
+                patch_num = torch.ones((B,), dtype=torch.int32, device=dev)
+            P, k = patches.size(1), patches.size(2)
+            patch_cl = patches.reshape(B * P, k, 3)
+            norm, centroid, radius = operations.normalize_point_batch(
+                patch_cl.transpose(2, 1).contiguous(), NCHW=True)
+            norm_cl = norm.transpose(2, 1).contiguous()
+            owner = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), P)
+            up_cl, feat = level.forward_cl(
+                patch_cl, norm_cl, (old_xyz, old_feat, old_count), owner=owner, groups=B)
+            if self.trace is not None:
+                self.trace.append(dict(patch_xyz=patch_cl.transpose(2, 1), out_norm=up_cl.transpose(2, 1),
+                                       patch_num=patch_num))
+            up_cl = up_cl * radius.view(-1, 1, 1) + centroid.view(-1, 1, 3)
+            r = up_cl.size(1) // k
+            # merge the patches of each cloud (reference :149-155): patch-major concatenation
+            merged = up_cl.reshape(B, P * k * r, 3)
+            old_xyz = patch_cl.reshape(B, P * k, 3)
+            old_feat = feat.reshape(B, P * k, feat.size(-1))
+            old_count = (patch_num * k).contiguous()
+            xyz_cl = merged
+            if P > 1:
+                # resample to num_point * curr_ratio points (reference :156-159)
+                num_output_point = num_point * curr_ratio
+                m_count = (patch_num * (k * r)).contiguous()
+                idx = operations.fps(merged, num_output_point, n_arr=m_count, m_arr=None)
+                xyz_cl = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+        return xyz_cl.transpose(2, 1).contiguous()
+
+    def forward(self, xyz, ratio=None, gt=None, **kwargs):
+        """
+        :param
+            xyz     Bx3xN
+            ratio   upscaling factor (integer)
+            gt      Bx3x(max_up_ratio*N)
+        :return
+            xyz     Bx3x(ratio*N)
+            (during training:)
+            gt      Bx3x(ratio*N)
+        """
+        ratio = ratio or self.max_up_ratio
+        if self.training:
+            assert(gt is not None)
+            return self._forward_train(xyz, ratio, gt)
+        return self._forward_eval(xyz, ratio)
+
+
+class Level(torch.nn.Module):
+    """3PU per-level network (reference :192-374)."""
+
+    def __init__(self, dense_n=3, growth_rate=12, knn=16, fm_knn=5, step_ratio=2):
+        super(Level, self).__init__()
+        self.dense_n = dense_n
+        self.fm_knn = fm_knn
+        self.step_ratio = step_ratio
+        # code for feature expansion (:200-206)
+        if step_ratio < 4:
+            self.code = self.gen_1d_grid(step_ratio).unsqueeze(0).detach()
+        else:
+            expansion_ratio = round(sqrt(step_ratio)) ** 2
+            self.code = self.gen_grid(expansion_ratio).unsqueeze(0).detach()
+
+        self.layer0 = layers.Conv2d(3, 24, [1, 1], activation=None)
+        self.layer1 = layers.DenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 84  # 24+(24+growth_rate*dense_n) = 24+(24+36) = 84
+        self.layer2_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer2 = layers.DenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 144  # 84+(24+36) = 144
+        self.layer3_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer3 = layers.DenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 204  # 144+(24+36) = 204
+        self.layer4_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer4 = layers.DenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 264  # 204+(24+36) = 264
+        self.up_layer = torch.nn.Sequential(OrderedDict([
+            ("up_layer1", layers.Conv2d(in_channels + self.code.size(1), 128, 1, activation="relu")),
+            ("up_layer2", layers.Conv2d(128, 128, 1, activation="relu")), ]))
+        self.fc_layer1 = layers.Conv2d(128, 64, 1, activation="relu")
+        self.fc_layer2 = layers.Conv2d(64, 3, 1, activation=None)
+
+    @staticmethod
+    def exponential_distance_cl(points, knn_points):
+        """Bilateral weight of the inter-level skip (reference :232-250), channel-last:
+        points (B,N,C), knn_points (B,N,K,C) -> weight (B,N,K)."""
+        distance = torch.sum((points.unsqueeze(2) - knn_points) ** 2, dim=-1).detach()
+        # mean over points of the distance to the closest of the K neighbours
+        h = torch.mean(torch.min(distance, dim=-1, keepdim=True)[0], dim=-2, keepdim=True)
+        return torch.exp(-distance / (h / 2)).detach()
+
+    def gen_grid(self, grid_size):
+        """output [2, grid_size x grid_size] (reference :252-262)"""
+        x = torch.linspace(-0.2, 0.2, grid_size, dtype=torch.float32)
+        x, y = torch.meshgrid(x, x, indexing="ij")
+        return torch.stack([x, y], dim=0).view([2, grid_size * grid_size])
+
+    def gen_1d_grid(self, num_grid_point):
+        """output [1, num_grid_point] (reference :264-270)"""
+        return torch.linspace(-0.2, 0.2, num_grid_point).view(1, num_grid_point)
+
+    def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1):
+        """Channel-last level:
+            xyz, xyz_normalized  (B,N,3)
+            previous             None or (prev_xyz (Bp,M,3), prev_feat (Bp,M,C), prev_count (Bp,)|None)
+            owner                (B,) int32: which previous cloud / unique-group each patch
+                                 belongs to (None: identity, one group -- the reference's call)
+        -> xyz_up (B, N*r, 3) normalised coordinates, features (B,N,264)."""
+        B, N, _ = xyz_normalized.shape
+        graph_layout = None if owner is None else dict(grp=owner, groups=groups)
+
+        x = self.layer0.forward_cl(xyz_normalized)
+        y, _ = self.layer1.forward_cl(x, layout=graph_layout)
+        x = torch.cat([y, x], dim=-1)
+        y, _ = self.layer2.forward_cl(self.layer2_prep.forward_cl(x), layout=graph_layout)
+        x = torch.cat([y, x], dim=-1)
+        y, _ = self.layer3.forward_cl(self.layer3_prep.forward_cl(x), layout=graph_layout)
+        x = torch.cat([y, x], dim=-1)
+        y, _ = self.layer4.forward_cl(self.layer4_prep.forward_cl(x), layout=graph_layout)
+        x = torch.cat([y, x], dim=-1)
+
+        # interlevel skip connection (:317-347)
+        if previous is not None and self.fm_knn > 0:
+            prev_xyz, prev_feat, prev_count = previous
+            layout = None
+            if owner is not None or prev_count is not None or prev_xyz.size(0) != B:
+                if owner is None:
+                    if prev_xyz.size(0) == B:
+                        owner_ = torch.arange(B, dtype=torch.int32, device=xyz.device)
+                    else:   # the reference's expand of ONE previous cloud over the batch (:319-323)
+                        assert prev_xyz.size(0) == 1
+                        owner_ = torch.zeros(B, dtype=torch.int32, device=xyz.device)
+                    layout = dict(pts_of=owner_, n_arr=prev_count)
+                else:
+                    layout = dict(pts_of=owner, n_arr=prev_count, grp=owner, groups=groups)
+                pts_of = layout["pts_of"].long()
+            else:
+                pts_of = None
+            with torch.no_grad():
+                knn_idx, _, knn_points = operations.knn_query(
+                    self.fm_knn, xyz.detach(), prev_xyz.detach(), unique=True, layout=layout,
+                    want_dist=False)
+            bsel = (torch.arange(B, device=xyz.device) if pts_of is None else pts_of).view(-1, 1, 1)
+            knn_feats = prev_feat[bsel, knn_idx]                              # (B,N,K,C)
+            s_weight = self.exponential_distance_cl(xyz, knn_points)
+            f_weight = self.exponential_distance_cl(x, knn_feats)
+            weight = s_weight * f_weight
+            weight = weight / torch.sum(weight + 1e-5, dim=-1, keepdim=True)
+            x = 0.2 * torch.sum(weight.unsqueeze(-1) * knn_feats, dim=2) + x
+
+        point_features = x
+        # feature expansion: every point r times, followed by its 1-d / 2-d code (:350-361)
+        _, code_length, ratio = self.code.size()
+        code = self.code.to(device=x.device, dtype=x.dtype)                  # (1,L,r)
+        code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)
+        x = torch.cat([x.unsqueeze(2).expand(-1, -1, ratio, -1), code], dim=-1)
+        x = x.reshape(B, N * ratio, x.size(-1))
+        # coordinate regression (:363-369) + residual (:371-372)
+        x = self.up_layer.up_layer1.forward_cl(x)
+        x = self.up_layer.up_layer2.forward_cl(x)
+        x = self.fc_layer1.forward_cl(x)
+        x = self.fc_layer2.forward_cl(x)
+        x = x + xyz_normalized.unsqueeze(2).expand(-1, -1, ratio, -1).reshape(B, N * ratio, 3)
+        return x, point_features
+
+    def forward(self, xyz, xyz_normalized, previous_level4=None, **kwargs):
+        """
+        :param
+            xyz             Bx3xN input xyz, unnormalized
+            xyz_normalized  Bx3xN input xyz, normalized
+            previous_level4 tuple of the xyz and feature of the final feature
+                            in the previous level (Bx3xM, BxCxM)
+        :return
+            xyz             Bx3xNr output xyz, normalized
+            l4_features     BxCxN feature of the input points
+        """
+        previous = None
+        if previous_level4 is not None:
+            pxyz, pfeat = previous_level4
+            previous = (pxyz.transpose(2, 1).contiguous(), pfeat.transpose(2, 1).contiguous(), None)
+        x, feat = self.forward_cl(xyz.transpose(2, 1).contiguous(),
+                                  xyz_normalized.transpose(2, 1).contiguous(), previous)
+        return x.transpose(2, 1).contiguous(), feat.transpose(2, 1).contiguous()

@@ -1,0 +1,133 @@
+"""Batched patch-upsampling pipeline: the inference driver of the reference
+(main.py:214-246 `pc_prediction` + :375-380 concat and final FPS), re-designed for MI355X.
+
+The reference walks the outer patches of ONE cloud in a Python loop at batch 1 (48 x
+`net.forward`, each with ~4 host syncs).  Here every stage is one batched launch over all
+patches of all clouds handed in:
+
+    clouds (C,3,N)
+      -> FPS seeds            (C, P)            P = int(N / num_point * patch_num_ratio)
+      -> kNN patches          (C*P, 3, num_point)   group_knn(unique=True), one group per cloud
+      -> normalise -> Net (all C*P patches advance through the levels together) -> de-normalise
+      -> per-cloud concat in patch order (C, P*num_point*r, 3)
+      -> final FPS            (C, 3, N*r)
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): clouds -- or, for a single
+cloud, its outer patches -- are split across ranks; the only communication is ONE all-gather
+of fp32 xyz at the point where the reference concatenates (`shard="clouds"`: the finished
+clouds; `shard="patches"`: the upsampled patches, after which the final FPS, which does not
+shard, runs replicated).
+"""
+import torch
+import torch.distributed as dist
+
+from .network import operations
+
+
+def num_outer_patches(num_shape_point, num_point, patch_num_ratio=3):
+    """main.py:225."""
+    return int(num_shape_point / num_point * patch_num_ratio)
+
+
+@torch.no_grad()
+def extract_outer_patches(clouds, num_point, patch_num_ratio=3):
+    """main.py:225-235 for a batch of clouds: (C,3,N) -> seeds idx (C,P) int32,
+    patches (C,P,num_point,3) channel-last, patch point indices (C,P,num_point) int64."""
+    C, _, N = clouds.shape
+    P = num_outer_patches(N, num_point, patch_num_ratio)
+    cl = clouds.transpose(2, 1).contiguous()
+    seed_idx = operations.fps(cl, P)
+    seeds = torch.gather(cl, 1, seed_idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    each = torch.arange(C, dtype=torch.int32, device=clouds.device)
+    layout = dict(grp=each, groups=C) if C > 1 else None
+    idx, _, patches = operations.knn_query(num_point, seeds, cl, unique=True, layout=layout,
+                                           want_dist=False)
+    return seed_idx, patches, idx
+
+
+@torch.no_grad()
+def upsample_patches(net, patches_cl, up_ratio):
+    """main.py:237-244 for all patches at once: (Q,num_point,3) channel-last, un-normalised ->
+    (Q, num_point*up_ratio, 3) de-normalised, and the normalised input patches (Q,3,num_point)."""
+    patch = patches_cl.transpose(2, 1).contiguous()
+    patch, centroid, radius = operations.normalize_point_batch(patch, NCHW=True)
+    up = net.forward(patch, ratio=up_ratio)
+    up = up * radius + centroid
+    return up.transpose(2, 1).contiguous(), patch
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _all_gather_cat(t):
+    """all-gather equal-shaped tensors of every rank and concatenate along dim 0 (rank order)."""
+    rank, world = _world()
+    if world == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((world * t.size(0),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t)
+    except (RuntimeError, NotImplementedError):      # backends without the flat form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        out = torch.cat(parts, dim=0)
+    return out
+
+
+def shard_range(total, rank, world):
+    """Contiguous, padded split: every rank gets ceil(total/world) slots; slots past `total`
+    repeat the last item (their results are dropped after the gather)."""
+    per = (total + world - 1) // world
+    ids = [min(rank * per + i, total - 1) for i in range(per)]
+    return ids, per
+
+
+@torch.no_grad()
+def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True):
+    """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
+    the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
+    Every rank passes the same `clouds` and receives the full result."""
+    C, _, N = clouds.shape
+    rank, world = _world()
+    if shard is None or world == 1:
+        _, patches, _ = extract_outer_patches(clouds, num_point, patch_num_ratio)
+        P = patches.size(1)
+        up, _ = upsample_patches(net, patches.reshape(C * P, num_point, 3), up_ratio)
+        merged = up.reshape(C, P * up.size(1), 3)
+    elif shard == "clouds":
+        ids, per = shard_range(C, rank, world)
+        mine = clouds[ids]
+        local = upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps)
+        out = _all_gather_cat(local)                         # (world*per, 3, N*r) in cloud order
+        return out[:C]
+    elif shard == "patches":
+        # seeds + outer kNN are cheap and deterministic: every rank computes them redundantly
+        _, patches, _ = extract_outer_patches(clouds, num_point, patch_num_ratio)
+        P = patches.size(1)
+        flat = patches.reshape(C * P, num_point, 3)
+        ids, per = shard_range(C * P, rank, world)
+        up_local, _ = upsample_patches(net, flat[ids], up_ratio)
+        up = _all_gather_cat(up_local)[:C * P]               # patch order restored by rank order
+        merged = up.reshape(C, P * up.size(1), 3)
+    else:
+        raise ValueError("shard must be None, 'clouds' or 'patches'")
+    if not final_fps:
+        return merged.transpose(2, 1).contiguous()
+    # main.py:379-380: the one big FPS down to N * up_ratio points per cloud
+    idx = operations.fps(merged, N * up_ratio)
+    out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    return out.transpose(2, 1).contiguous()
+
+
+def pc_prediction(net, input_pc, num_point, up_ratio, patch_num_ratio=3):
+    """Drop-in shaped like the reference's pc_prediction (main.py:214-246):
+    input_pc 1x3xN -> (input_list of [1x3xM] normalised patches, up_point_list of [1x3xMr])."""
+    _, patches, _ = extract_outer_patches(input_pc, num_point, patch_num_ratio)
+    P = patches.size(1)
+    up, patch = upsample_patches(net, patches.reshape(P, num_point, 3), up_ratio)
+    up = up.transpose(2, 1).contiguous()
+    return [patch[i:i + 1] for i in range(P)], [up[i:i + 1] for i in range(P)]

@@ -1,0 +1,69 @@
+"""not-gpu: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/tpu3.h declares (no compute calls here: there is no GPU in this container); argument
+validation that happens before any launch is exercised through the ctypes binding."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "tpu3.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tpu3_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_functions_are_exported_and_bound():
+    L = pkg("_lib")
+    pkg("build").build()
+    lib = ctypes.CDLL(L.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), "lib3pu_hip.so does not export %s" % n
+    assert sorted(L.SIGNATURES.keys()) == names            # the Python binding covers the header
+
+
+def test_version_and_strerror():
+    L = pkg("_lib")
+    assert L.lib().tpu3_version().decode().startswith("3pu-hip")
+    assert b"invalid" in L.lib().tpu3_strerror(-1)
+    assert L.lib().tpu3_strerror(0) == b"ok"
+
+
+def test_argument_validation_without_gpu():
+    lib = pkg("_lib").lib()
+    assert lib.tpu3_fps_f32(None, -1, 4, 2, None, None, None) == -1
+    assert lib.tpu3_fps_f32(None, 1, 4, 2, None, None, None) == -1         # NULL pointers
+    assert lib.tpu3_fps_f32(None, 0, 4, 2, None, None, None) == 0          # empty batch: no-op
+    assert lib.tpu3_gather_fwd(None, 1, 1, 4, 2, 3, 8, 8, 8) == -1         # element size 3
+    assert lib.tpu3_knn_f32(None, 1, 4, 8, 3, 9, 8, 8, None, None, None, 8, 8, None, None) == -1  # k > n
+    assert lib.tpu3_knn_f32(None, 1, 4, 8, 3, 2, 8, 8, None, None, None, 8, 2, None, None) == -1  # idx size
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    L = pkg("_lib")
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "no_such_dir", "lib3pu_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    sampling, losses = pkg("sampling"), pkg("losses")
+    ops = pkg("network.operations")
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        sampling.gather_forward(1, 1, 4, 2, torch.zeros(1, 1, 4), torch.zeros(1, 2, dtype=torch.int32),
+                                torch.zeros(1, 1, 2))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        sampling.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 4, 3), 0.1, 2)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        losses.nmdistance_forward(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.zeros(1, 2),
+                                  torch.zeros(1, 2), torch.zeros(1, 2, dtype=torch.int32),
+                                  torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.group_knn(2, torch.zeros(1, 3, 4), torch.zeros(1, 3, 8))

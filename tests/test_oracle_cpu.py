@@ -1,0 +1,223 @@
+"""not-gpu: pins the oracle (oracle/ref_kernels.c + oracle/oracle.py).
+
+The reference has no tests or golden vectors of its own for these kernels,
+so the oracle is pinned three ways: (1) against fixtures the reference's own Python produced
+(tests/golden, see oracle/make_golden.py); (2) against independent brute-force numpy
+definitions; (3) by internal consistency properties (contracted vs un-contracted arithmetic give
+the same indices on generic data, tie rules, the b > 32 grid quirk)."""
+import numpy as np
+import pytest
+
+from conftest import golden, sphere
+
+
+# ---- FPS ---------------------------------------------------------------------------------------
+def _fps_bruteforce(xyz, m, bs):
+    """Definition: start at 0; repeatedly take the point whose distance to the chosen set is
+    largest; ties by (k mod bs, k).  float64 distances of the float32 inputs would not pin the
+    rounding, so this uses float32 ops in the documented association."""
+    n = xyz.shape[0]
+    temp = np.full(n, 1e10, np.float32)
+    idx = [0]
+    for _ in range(1, m):
+        d = xyz - xyz[idx[-1]]
+        dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+        dist = np.float32(dy * dy)
+        dist = (dx.astype(np.float64) * dx + dist).astype(np.float32)      # fma(dx,dx,dy*dy)
+        dist = (dz.astype(np.float64) * dz + dist).astype(np.float32)      # fma(dz,dz,.)
+        temp = np.minimum(temp, dist)
+        best = temp.max()
+        cand = np.where(temp == best)[0]
+        idx.append(int(min(cand, key=lambda k: (k % bs, k))))
+    return np.array(idx, np.int32), temp
+
+
+@pytest.mark.parametrize("n,m", [(40, 40), (312, 50), (700, 64), (1500, 100)])
+def test_fps_matches_definition(orc, n, m):
+    xyz = sphere(n, n)
+    idx, temp = orc.fps(xyz, m)
+    bidx, btemp = _fps_bruteforce(xyz[0], m, orc.opt_n_threads(n))
+    np.testing.assert_array_equal(idx[0], bidx)
+    # the last pick is not folded into temp (the reference stops updating after the last round)
+    last = xyz[0] - xyz[0][bidx[-1]]
+    np.testing.assert_array_equal(np.minimum(temp[0], btemp), btemp)
+
+
+def test_fps_tie_rule_is_block_strided_not_lowest_index(orc):
+    # four copies of the same 3 points: after the first pick all remaining maxima tie
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    n = 1030                      # bs = 512: index 514 (514 % 512 = 2) beats index 3 (3 % 512 = 3)
+    xyz = np.zeros((1, n, 3), np.float32)
+    xyz[0, 3] = base[1]
+    xyz[0, 514] = base[1]
+    idx, _ = orc.fps(xyz, 2)
+    assert orc.opt_n_threads(n) == 512
+    assert idx[0].tolist() == [0, 514]
+
+
+def test_fps_contraction_does_not_change_indices_on_generic_clouds(orc):
+    for n, m in [(5000, 48), (6240, 1248), (12000, 3000)]:
+        xyz = sphere(n + 1, n)
+        a, _ = orc.fps(xyz, m, flags=orc.ORC_FMA)
+        b, _ = orc.fps(xyz, m, flags=0)
+        np.testing.assert_array_equal(a, b)
+
+
+def test_fps_grid32_quirk_only_when_asked(orc):
+    xyz = sphere(3, 600, 40)
+    good, _ = orc.fps(xyz, 20)
+    for i in range(40):
+        np.testing.assert_array_equal(good[i], orc.fps(xyz[i:i + 1], 20)[0][0])
+    quirk, _ = orc.fps(xyz, 20, flags=orc.ORC_FMA | orc.ORC_GRID32_BUG)
+    np.testing.assert_array_equal(quirk[:32], good[:32])       # first 32 rows own their temp
+    assert (quirk[32:] != good[32:]).any()                      # rows 32.. inherit stale distances
+
+
+def test_opt_n_threads(orc):
+    for n, e in [(1, 1), (2, 2), (3, 2), (312, 256), (511, 256), (512, 512), (624, 512), (5000, 512)]:
+        assert orc.opt_n_threads(n) == e
+    for n in range(1, 5000):
+        assert orc.opt_n_threads(n) == min(512, 1 << (n.bit_length() - 1))
+
+
+# ---- gather / ball query / nm-distance -----------------------------------------------------------
+def test_gather_forward_backward(orc):
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((2, 3, 50)).astype(np.float32)
+    idx = rng.integers(0, 50, (2, 80)).astype(np.int32)
+    out = orc.gather_fwd(pts, idx)
+    np.testing.assert_array_equal(out, np.take_along_axis(pts, idx[:, None, :].repeat(3, 1).astype(np.int64), 2))
+    g = rng.standard_normal((2, 3, 80))
+    gp = orc.gather_bwd(g, idx, 50)
+    ref = np.zeros((2, 3, 50))
+    for b in range(2):
+        for c in range(3):
+            np.add.at(ref[b, c], idx[b], g[b, c])
+    np.testing.assert_allclose(gp, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_ball_query_definition(orc):
+    xyz = sphere(5, 800, 2)
+    q = xyz[:, :100].copy()
+    q[:, 0] = 9.0
+    idx = orc.ball_query(q, xyz, 0.2, 16)
+    for b in range(2):
+        for j in range(100):
+            d2 = ((q[b, j].astype(np.float64) - xyz[b].astype(np.float64)) ** 2).sum(1)
+            hits = np.where(d2 < 0.2 * 0.2 - 1e-6)[0]
+            loose = np.where(d2 < 0.2 * 0.2 + 1e-6)[0]
+            got = idx[b, j]
+            if len(loose) == 0:
+                assert (got == 0).all()
+                continue
+            cnt = min(16, len(hits))
+            assert set(hits[:cnt]).issubset(set(got)) and set(got).issubset(set(loose))
+            assert (np.diff(got[:cnt]) > 0).all()                   # index order
+            if cnt < 16 and len(hits) == len(loose):
+                assert (got[cnt:] == got[0]).all()                  # first hit replicated
+
+
+def test_nmdistance_definition_and_ties(orc):
+    a = sphere(1, 300, 2)
+    b = np.repeat(sphere(2, 130, 2), 2, axis=1)                      # every target twice
+    d1, i1, d2, i2 = orc.nmdistance_fwd(a, b)
+    D = ((a[:, :, None, :].astype(np.float64) - b[:, None, :, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(d1, D.min(2), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(d2, D.min(1), rtol=1e-5, atol=1e-7)
+    assert (i1 % 2 == 0).all()                                       # lowest index of each pair
+    # tiles of 512 must not change the answer: 1100 targets span three tiles
+    a2, b2 = sphere(3, 50), sphere(4, 1100)
+    e1, j1, _, _ = orc.nmdistance_fwd(a2, b2)
+    D2 = ((a2[0, :, None, :].astype(np.float64) - b2[0][None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(j1[0], D2.argmin(1))
+
+
+def test_nmdistance_backward_is_the_gradient(orc):
+    import torch
+    a = torch.tensor(sphere(1, 40, 2), dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(sphere(2, 30, 2), dtype=torch.float64, requires_grad=True)
+    D = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    w1 = torch.tensor(np.random.default_rng(0).standard_normal((2, 40)))
+    w2 = torch.tensor(np.random.default_rng(1).standard_normal((2, 30)))
+    ((D.min(2)[0] * w1).sum() + (D.min(1)[0] * w2).sum()).backward()
+    _, i1, _, i2 = orc.nmdistance_fwd(a.detach().numpy(), b.detach().numpy())
+    g1, g2 = orc.nmdistance_bwd(a.detach().numpy(), b.detach().numpy(), w1.numpy(), w2.numpy(), i1, i2)
+    np.testing.assert_allclose(g1, a.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g2, b.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ---- torch-level operators against the reference's outputs ------------------------------------------
+KNN_CASES = ["outer", "outlier", "inner", "feature", "interlevel_dup", "interlevel_dup_nonunique",
+             "feature_dup"]
+
+
+@pytest.mark.parametrize("case", KNN_CASES)
+def test_group_knn_against_reference(orc, case):
+    """Reference = torch matmul + np.unique + torch.topk (operations.py:151-216).  Its summation
+    order and tie order are unspecified, so: identical neighbour SETS except where the k-th and
+    (k+1)-th distances are within float noise, identical ORDER wherever adjacent distances differ
+    by more than that noise, distances within 2e-6 (absolute; values are O(1))."""
+    g = golden("group_knn.npz")
+    k, uniq = int(g[case + "_k"]), bool(g[case + "_unique"])
+    q, p = g[case + "_query"], g[case + "_points"]
+    ridx, rdist = g[case + "_idx"].astype(np.int64), g[case + "_dist"]
+    _, idx, dist = orc.group_knn(k, q, p, unique=uniq, NCHW=True)
+    scale = max(1.0, float(np.abs(rdist).max()))
+    tol = 4e-6 * scale
+    np.testing.assert_allclose(dist, rdist, rtol=0, atol=tol)
+    same_set = (np.sort(idx, -1) == np.sort(ridx, -1)).all(-1)
+    # rows whose index sets differ must either pick a different COPY of a duplicated point (exact
+    # tie: compare the gathered coordinates) or differ at a boundary near-tie
+    pcl = p.transpose(0, 2, 1)
+    exact_tie_rows = 0
+    for b, m in zip(*np.where(~same_set)):
+        mine = pcl[b][idx[b, m]]
+        ref = pcl[b][ridx[b, m]]
+        if (np.sort(mine.view([("", mine.dtype)] * mine.shape[1]), 0)
+                == np.sort(ref.view([("", ref.dtype)] * ref.shape[1]), 0)).all():
+            exact_tie_rows += 1
+            continue
+        sym = set(idx[b, m]) ^ set(ridx[b, m])
+        assert len(sym) <= 4
+        assert abs(dist[b, m, -1] - rdist[b, m, -1]) <= tol
+    assert (same_set.sum() + exact_tie_rows) / same_set.size > 0.99
+    gaps = np.diff(rdist, axis=-1)
+    strict = np.concatenate([gaps > 2 * tol, np.ones(gaps.shape[:-1] + (1,), bool)], -1)
+    strict &= np.concatenate([np.ones(gaps.shape[:-1] + (1,), bool), gaps > 2 * tol], -1)
+    strict &= same_set[..., None]
+    assert (idx[strict] == ridx[strict]).all()
+
+
+def test_unique_semantics(orc):
+    """dup = every occurrence after the first; dup rows get +max(D) over the whole tensor."""
+    g = golden("group_knn.npz")
+    p = np.ascontiguousarray(g["interlevel_dup_points"].transpose(0, 2, 1))
+    dup = orc.first_occurrence_dup(p)
+    for b in range(p.shape[0]):
+        _, first = np.unique(p[b], axis=0, return_index=True)
+        expect = np.ones(p.shape[1], np.uint8)
+        expect[first] = 0
+        np.testing.assert_array_equal(dup[b], expect)
+    assert dup.sum() == 3 * 312
+    # with unique=True no neighbour list may contain a duplicate-flagged point
+    idx_u = g["interlevel_dup_idx"]
+    assert dup[np.arange(3)[:, None, None], idx_u].sum() == 0
+    _, oi, _ = orc.group_knn(5, g["interlevel_dup_query"], g["interlevel_dup_points"], unique=True)
+    assert dup[np.arange(3)[:, None, None], oi].sum() == 0
+
+
+def test_normalize_against_reference(orc):
+    g = golden("normalize.npz")
+    o, c, r = orc.normalize_point_batch(g["pc"], NCHW=True)
+    np.testing.assert_allclose(o, g["out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c, g["centroid"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r, g["radius"], rtol=1e-6, atol=0)
+
+
+def test_chamfer_against_reference(orc):
+    g = golden("chamfer.npz")
+    assert abs(orc.chamfer_loss(g["a"], g["b"]) - float(g["cd"])) < 1e-6
+    assert abs(orc.chamfer_loss(g["a"], g["b"], threshold=2.0) - float(g["cd_thr"])) < 1e-6
+    assert abs(orc.chamfer_loss(g["a"].transpose(0, 2, 1), g["b"], threshold=2.0, forward_weight=50.0)
+               - float(g["cd_thr_w"])) < 1e-5
+    assert float(g["cd_thr"]) < float(g["cd"])                      # the threshold removed outliers

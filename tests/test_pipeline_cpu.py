@@ -1,0 +1,126 @@
+"""not-gpu: the inference driver (pipeline.py) on CPU through the oracle stand-in, against the
+fixture produced by driving the reference's own operations/Net the way main.py does; plus the
+multi-process sharding paths over gloo (world_size 2)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import golden, pkg, sphere, ROOT
+from oracle_backend import OracleBackend
+
+
+def _net(ups):
+    net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+    state = golden("net16_state.npz")
+    net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
+    return net.eval()
+
+
+@pytest.fixture()
+def mods(orc, monkeypatch):
+    ops = pkg("network.operations")
+    monkeypatch.setattr(ops, "BACKEND", OracleBackend())
+    return ops, pkg("network.upsampler"), pkg("pipeline")
+
+
+def test_patch_count_rule(mods):
+    _, _, pipe = mods
+    assert pipe.num_outer_patches(5000, 312, 3) == 48
+    assert pipe.num_outer_patches(80000, 1024, 3) == 234        # config C5
+    assert pipe.num_outer_patches(1000, 312, 3) == 9
+
+
+def test_pipeline_matches_reference_driver(orc, mods):
+    _, ups, pipe = mods
+    g = golden("pc_prediction.npz")
+    net = _net(ups)
+    cloud = torch.from_numpy(g["cloud"])
+    num_point, up_ratio, pnr = int(g["num_point"]), int(g["up_ratio"]), int(g["patch_num_ratio"])
+    seed_idx, patches, pidx = pipe.extract_outer_patches(cloud, num_point, pnr)
+    np.testing.assert_array_equal(seed_idx.numpy(), g["seed_idx"])
+    # torch.topk leaves the order of exact ties open: same neighbour SETS, same order elsewhere
+    ref_pidx = g["patch_idx"].astype(np.int64)
+    assert (np.sort(pidx.numpy(), axis=-1) == np.sort(ref_pidx, axis=-1)).all()
+    assert (pidx.numpy() == ref_pidx).mean() > 0.999
+    # a differently ordered exact tie inside a patch permutes that patch's points, hence the output
+    # POSITIONS; as point sets the results must coincide within 1e-5
+    def set_close(y, ref):
+        d1, _, d2, _ = orc.nmdistance_fwd(np.ascontiguousarray(y.transpose(0, 2, 1)),
+                                          np.ascontiguousarray(ref.transpose(0, 2, 1)))
+        return min((np.sqrt(d1) <= 1e-5).mean(), (np.sqrt(d2) <= 1e-5).mean())
+    merged = pipe.upsample(net, cloud, num_point, up_ratio, pnr, final_fps=False).numpy()
+    assert merged.shape == g["pred_concat"].shape
+    assert (np.abs(merged - g["pred_concat"]).max(axis=1) <= 1e-5).mean() > 0.99
+    assert set_close(merged, g["pred_concat"]) >= 0.999
+    final = pipe.upsample(net, cloud, num_point, up_ratio, pnr).numpy()
+    assert final.shape == (1, 3, 4000)
+    assert set_close(final, g["final"]) >= 0.999
+    inputs, ups_list = pipe.pc_prediction(net, cloud, num_point, up_ratio, pnr)
+    assert len(inputs) == len(ups_list) == 9 and tuple(ups_list[0].shape) == (1, 3, 1248)
+
+
+def test_two_clouds_batched_equal_separately(mods):
+    _, ups, pipe = mods
+    net = _net(ups)
+    clouds = torch.from_numpy(np.ascontiguousarray(sphere(31, 700, 2).transpose(0, 2, 1)))
+    both = pipe.upsample(net, clouds, 312, 2).numpy()
+    one = np.concatenate([pipe.upsample(net, clouds[i:i + 1], 312, 2).numpy() for i in range(2)])
+    np.testing.assert_array_equal(both, one)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from conftest import pkg as _pkg, sphere as _sphere
+    from oracle_backend import OracleBackend as _OB
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops = _pkg("network.operations")
+    ops.BACKEND = _OB()
+    pipe = _pkg("pipeline")
+    net = _net(_pkg("network.upsampler"))
+    clouds = torch.from_numpy(np.ascontiguousarray(_sphere(41, 700, 3).transpose(0, 2, 1)))
+    ref = pipe.upsample(net, clouds, 312, 2, shard=None)
+    by_cloud = pipe.upsample(net, clouds, 312, 2, shard="clouds")          # 3 clouds on 2 ranks: padded
+    by_patch = pipe.upsample(net, clouds[:1], 312, 2, shard="patches")     # 6 patches on 2 ranks
+    ok = bool(torch.equal(by_cloud, ref)) and bool(torch.equal(by_patch, ref[:1]))
+    with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+        f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_over_gloo_world2(tmp_path, orc):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
+
+
+def test_shard_range_covers_everything():
+    pipe = pkg("pipeline")
+    for total in (1, 5, 48, 64):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for r in range(world):
+                ids, per = pipe.shard_range(total, r, world)
+                assert len(ids) == per
+                seen += ids
+            assert sorted(set(seen)) == list(range(total))
+            assert seen[:total] == list(range(total))
