@@ -1,0 +1,141 @@
+"""bench.py -- headline benchmark of the hot path (contract in the task statement).
+
+Metric (BASELINE.json): upsampled points/sec, 16x, 312-point patches, 5000 -> 80000 points per
+cloud, config C2 (1 x MI355X, num_point 312, num_shape_point 5000, up_ratio 16, random-init
+weights, synthetic Poisson-sphere inputs).  A "step" is one pass of the whole pipeline
+(seeds, outer patches, 4 progressive levels incl. every inner FPS / kNN, concat, final FPS) over
+`--clouds` clouds per GPU, inputs resident in HBM.  With --gpus N > 1 (launched by
+torch.distributed.run, one rank per GPU, RCCL) every rank upsamples its own clouds and the
+finished clouds are exchanged by ONE all-gather per step (weak scaling).
+
+One JSON line is printed by rank 0; it also carries `roofline` (dominant kernel: the final
+239 616 -> 80 000 FPS, timed with events on the launch stream) and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pkg(sub=None):
+    return importlib.import_module("3pu_pytorch_amd" + ("." + sub if sub else ""))
+
+
+def poisson_sphere(seed, n, dev, ops):
+    """Blue-noise-like cloud: 8n uniform S^2 candidates thinned to n by FPS."""
+    g = torch.Generator().manual_seed(seed)
+    cand = torch.randn(1, 8 * n, 3, generator=g)
+    cand = (cand / cand.norm(dim=2, keepdim=True)).to(dev)
+    idx = ops.fps(cand, n)
+    return torch.gather(cand, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).transpose(2, 1).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clouds", type=int, default=1, help="clouds per GPU per step")
+    ap.add_argument("--num_shape_point", type=int, default=5000)
+    ap.add_argument("--num_point", type=int, default=312)
+    ap.add_argument("--up_ratio", type=int, default=16)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ops, pipe, ups = pkg("network.operations"), pkg("pipeline"), pkg("network.upsampler")
+    assert ops.BACKEND.name == "hip-gfx950"
+    N, npnt, r, C = args.num_shape_point, args.num_point, args.up_ratio, args.clouds
+    torch.manual_seed(0)
+    net = ups.Net(max_up_ratio=r, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev).eval()
+    clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
+
+    timing = []
+
+    def step():
+        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing)        # (C,3,N*r) on this rank
+        if world > 1:                                                       # reassemble: ONE all-gather
+            out = pipe._all_gather_cat(out)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    del timing[:]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert tuple(out.shape) == (world * C, 3, N * r) and bool(torch.isfinite(out).all())
+    assert int(net.small_cloud_events) == 0
+
+    total_points = world * C * N * r * args.steps
+    fps_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
+
+    if rank == 0:
+        P = pipe.num_outer_patches(N, npnt, 3)
+        n_merged = P * npnt * r
+        m_out = N * r
+        # algorithmic bytes of one final-FPS launch: 20 B per point per round x C clouds
+        alg_bytes = 20.0 * C * n_merged * (m_out - 1)
+        roof = {"kernel": "final FPS %d->%d (fps_stream_kernel / fps_bucket_kernel)" % (n_merged, m_out),
+                "bound": "hbm", "achieved": alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None,
+                "peak": 8000.0, "unit": "GB/s", "traffic": None,
+                "launch_ms": fps_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        line = {
+            "metric": "upsampled points/sec (16x, 312-pt patches, 5000->80000)",
+            "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: %d cloud(s)/GPU x %d pts, num_point=%d, up_ratio=%d (4 levels), "
+                                   "%d outer patches, knn=32, random-init weights, Poisson-sphere input"
+                                   % (C, N, npnt, r, P),
+                       "clouds_per_gpu": C, "parallelism": "clouds sharded, 1 all-gather/step" if world > 1 else "single GPU"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            from oracle import cpu_baseline
+            line["cpu_baseline"] = cpu_baseline.measure(N, npnt, r)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,6 @@
-"""Test-only stand-in for network.operations.HipBackend, served by the CPU oracle.
+"""oracle/backend.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Stand-in for network.operations.HipBackend, served by the CPU oracle.
 
 It lets the `-m "not gpu"` suite run the product's HOST logic (module wiring, batched / ragged
 control flow of Net, the pipeline, the sharding code) on CPU tensors and compare it with the
@@ -7,7 +9,7 @@ reference-generated fixtures.  The product never imports this; tests install it 
 import numpy as np
 import torch
 
-from oracle import oracle as orc
+from . import oracle as orc
 
 
 def _np(t):

@@ -1,12 +1,12 @@
 """not-gpu: the product's HOST logic (module wiring, batched/ragged Net control flow) runs on CPU
-with the kernels served by the oracle stand-in (tests/oracle_backend.py) and is compared with
+with the kernels served by the oracle stand-in (oracle/backend.py) and is compared with
 fixtures the reference's own Python produced (oracle/make_golden.py)."""
 import numpy as np
 import pytest
 import torch
 
 from conftest import golden, pkg
-from oracle_backend import OracleBackend
+from oracle.backend import OracleBackend
 
 
 @pytest.fixture()

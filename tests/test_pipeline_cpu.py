@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 from conftest import golden, pkg, sphere, ROOT
-from oracle_backend import OracleBackend
+from oracle.backend import OracleBackend
 
 
 def _net(ups):
@@ -86,7 +86,7 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from conftest import pkg as _pkg, sphere as _sphere
-    from oracle_backend import OracleBackend as _OB
+    from oracle.backend import OracleBackend as _OB
     torch.set_num_threads(2)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
