@@ -16,7 +16,14 @@
 //     slot order already yields the lane's winner; waves then reduce (distance, tie key).
 #include "tpu3_dev.h"
 
+// fps_bucket.hip: exact work-skipping kernel for point sets beyond the register-resident limit
+size_t tpu3_fps_bucket_workspace_bytes(int b, int n);
+int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
+                           void *workspace, size_t workspace_bytes);
+
 namespace {
+
+constexpr int FPS_RESIDENT_MAX = 25600;
 
 struct FpsArgs {
     int n, m;                 // padded sizes (strides)
@@ -170,17 +177,15 @@ int launch_resident(hipStream_t s, int b, const FpsArgs &a)
 
 extern "C" size_t tpu3_fps_workspace_bytes(int b, int n)
 {
-    (void)b;
-    (void)n;
-    return 0;
+    if (b <= 0 || n <= FPS_RESIDENT_MAX)
+        return 0;
+    return tpu3_fps_bucket_workspace_bytes(b, n);
 }
 
 extern "C" int tpu3_fps_ragged_f32(tpu3_stream_t stream, int b, int n, int m, const int32_t *n_arr,
                                    const int32_t *m_arr, const float *xyz, float *temp,
                                    int32_t *idx, void *workspace, size_t workspace_bytes)
 {
-    (void)workspace;
-    (void)workspace_bytes;
     if (b < 0 || n < 0 || m < 0)
         return TPU3_EINVAL;
     if (b == 0 || n == 0 || m == 0)
@@ -202,7 +207,21 @@ extern "C" int tpu3_fps_ragged_f32(tpu3_stream_t stream, int b, int n, int m, co
     if (n <= 12288) return launch_resident<1024, 12>(s, b, a);
     if (n <= 16384) return launch_resident<1024, 16>(s, b, a);
     if (n <= 20480) return launch_resident<1024, 20>(s, b, a);
-    if (n <= 25600) return launch_resident<1024, 25>(s, b, a);
+    if (n <= FPS_RESIDENT_MAX) return launch_resident<1024, 25>(s, b, a);
+    if (!n_arr && !m_arr) {
+        // large dense sets: Morton buckets + exact pruning (fps_bucket.hip)
+        const size_t need = tpu3_fps_bucket_workspace_bytes(b, n);
+        if (need) {
+            if (workspace && workspace_bytes >= need)
+                return tpu3_fps_bucket_launch(s, b, n, m, xyz, temp, idx, workspace, workspace_bytes);
+            void *ws = nullptr;                 // caller gave no scratch: stream-ordered allocation
+            hipError_t e = hipMallocAsync(&ws, need, s);
+            if (e != hipSuccess) return (int)e;
+            const int r = tpu3_fps_bucket_launch(s, b, n, m, xyz, temp, idx, ws, need);
+            e = hipFreeAsync(ws, s);
+            return r ? r : (int)e;
+        }
+    }
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, s, a);
     return tpu3_launch_status();
 }

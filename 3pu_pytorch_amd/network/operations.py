@@ -81,7 +81,9 @@ class HipBackend(object):
         b, n, _ = xyz.shape
         idx = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
         temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
-        if n_arr is None and m_arr is None:
+        lib = L.lib() if xyz.is_cuda else None
+        need = lib.tpu3_fps_workspace_bytes(b, n) if lib is not None else 0
+        if n_arr is None and m_arr is None and need == 0:
             sampling.furthest_sampling(b, n, npoint, xyz, temp, idx)
             return idx
         L.require_device(xyz, "xyz")
@@ -91,9 +93,11 @@ class HipBackend(object):
                 L.require_device(t, nm)
                 L.require_dtype(t, torch.int32, nm)
         idx.zero_()
+        # large point sets: scratch for the bucketed kernel comes from torch's caching allocator
+        ws = torch.empty((need,), dtype=torch.uint8, device=xyz.device) if need else None
         with torch.cuda.device(xyz.device):
             L.check(L.lib().tpu3_fps_ragged_f32(L.stream_of(xyz), b, n, npoint, L.ptr(n_arr), L.ptr(m_arr),
-                                                L.ptr(xyz), L.ptr(temp), L.ptr(idx), None, 0),
+                                                L.ptr(xyz), L.ptr(temp), L.ptr(idx), L.ptr(ws), need),
                     "tpu3_fps_ragged_f32")
         return idx
 

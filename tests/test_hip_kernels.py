@@ -32,16 +32,56 @@ def test_fps_bit_exact(orc, dev, b, n, m):
     np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
 
 
-def test_fps_streaming_kernel_large_n(orc, dev):
-    sampling = pkg("sampling")
-    n, m = 30000, 300
-    xyz = sphere(7, n, 1)
+@pytest.mark.parametrize("b,n,m,dups", [(1, 30000, 3000, False), (2, 70000, 1500, False),
+                                          (1, 239616, 2500, False), (1, 40000, 4000, True),
+                                          (1, 26000, 26000, False), (3, 25601, 300, False)])
+def test_fps_bucketed_kernel_bit_exact(orc, dev, b, n, m, dups):
+    """Point sets beyond the register-resident limit take the Morton-bucket kernel with exact
+    pruning; indices AND the final temp must equal the plain algorithm's, ties included."""
+    sampling, ops = pkg("sampling"), pkg("network.operations")
+    if dups:
+        rng = np.random.default_rng(n)
+        base = sphere(n, n // 4, 1)[0]
+        xyz = base[rng.integers(0, base.shape[0], size=n)][None]
+    else:
+        xyz = sphere(2000 + n, n, b)
     ref_idx, ref_temp = orc.fps(xyz, m)
-    temp = torch.full((1, n), 1e10, dtype=torch.float32, device=dev)
-    idx = torch.empty((1, m), dtype=torch.int32, device=dev)
-    sampling.furthest_sampling(1, n, m, _t(xyz, dev), temp, idx)
+    x = _t(xyz, dev)
+    # (a) drop-in entry point: no scratch passed, the library allocates stream-ordered
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.empty((b, m), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(b, n, m, x, temp, idx)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
     np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+    # (b) operator entry point: scratch from torch's allocator
+    np.testing.assert_array_equal(ops.fps(x, m).cpu().numpy(), ref_idx)
+
+
+def test_fps_bucketed_continues_from_given_temp(orc, dev):
+    """temp is in/out: a second call that starts from the first call's distances must behave like
+    the plain algorithm started from them (the bucket table is built from the caller's temp)."""
+    sampling = pkg("sampling")
+    n = 50000
+    xyz = sphere(77, n, 1)
+    i1, t1 = orc.fps(xyz, 200)
+    i2, t2 = orc.fps(xyz, 300, temp=t1)
+    temp = _t(t1, dev)
+    idx = torch.empty((1, 300), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(1, n, 300, _t(xyz, dev), temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), i2)
+    np.testing.assert_array_equal(temp.cpu().numpy(), t2)
+
+
+def test_fps_streaming_kernel_large_ragged(orc, dev):
+    """Ragged batches beyond the resident limit fall back to the streaming kernel."""
+    ops = pkg("network.operations")
+    n, m = 30000, 300
+    xyz = sphere(7, n, 2)
+    n_arr = np.array([30000, 27000], np.int32)
+    idx = ops.fps(_t(xyz, dev), m, _t(n_arr, dev), None).cpu().numpy()
+    for i in range(2):
+        ref_idx, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], m)
+        np.testing.assert_array_equal(idx[i], ref_idx[0])
 
 
 @pytest.mark.parametrize("n", [300, 700, 3000])
