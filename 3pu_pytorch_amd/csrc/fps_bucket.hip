@@ -36,8 +36,9 @@ struct FbArgs {
     const float *xyz;     // (n,3) original order
     float *temp;          // (n)
     int32_t *idx;         // (m)
-    float *sx, *sy, *sz, *st;   // (npad) Morton order
+    float4 *sp;           // (npad) Morton order: x, y, z, running distance
     uint32_t *skey;       // (npad) tie key of the original index (0xFFFFFFFF = padding)
+    unsigned long long *prof;   // PROF builds only: 16 waves x 8 cycle counters
 };
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void fb_morton_kernel(int n, const float *__re
     vals[i] = (uint32_t)i;
 }
 
-// Morton-ordered structure-of-arrays; slots past n repeat the last live point with temp = -1
+// Morton-ordered float4 (x,y,z,temp) + tie keys; slots past n repeat the last live point with temp = -1
 __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a, const uint32_t *__restrict__ order, int lb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,10 +105,8 @@ __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a, const uint32_
         return;
     const bool live = i < a.n;
     const uint32_t o = order[live ? i : a.n - 1];
-    a.sx[i] = a.xyz[(size_t)o * 3 + 0];
-    a.sy[i] = a.xyz[(size_t)o * 3 + 1];
-    a.sz[i] = a.xyz[(size_t)o * 3 + 2];
-    a.st[i] = live ? a.temp[o] : -1.0f;
+    a.sp[i] = make_float4(a.xyz[(size_t)o * 3 + 0], a.xyz[(size_t)o * 3 + 1], a.xyz[(size_t)o * 3 + 2],
+                          live ? a.temp[o] : -1.0f);
     a.skey[i] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
 }
 
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a, int lb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n)
-        a.temp[tpu3_fps_tiekey_to_index(a.skey[i], lb)] = a.st[i];
+        a.temp[tpu3_fps_tiekey_to_index(a.skey[i], lb)] = a.sp[i].w;
 }
 
 struct FbSlots {
@@ -132,73 +131,62 @@ __host__ __device__ inline FbArgs fb_elem(const FbArgs &a0, size_t per_elem, int
     a.xyz = a0.xyz + (size_t)i * a0.n * 3;
     a.temp = a0.temp + (size_t)i * a0.n;
     a.idx = a0.idx + (size_t)i * a0.m;
-    a.sx = (float *)((char *)a0.sx + (size_t)i * per_elem);
-    a.sy = (float *)((char *)a0.sy + (size_t)i * per_elem);
-    a.sz = (float *)((char *)a0.sz + (size_t)i * per_elem);
-    a.st = (float *)((char *)a0.st + (size_t)i * per_elem);
+    a.sp = (float4 *)((char *)a0.sp + (size_t)i * per_elem);
     a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * per_elem);
     return a;
 }
 
-template <int NBPT, int PPL>
+template <int NBPT, int PPL, bool PROF = false>
 __global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_elem, int lb)
 {
     constexpr int BS = 64 * PPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FbArgs a = fb_elem(a0, per_elem, blockIdx.x);
     const int nb = a.nb;
-    int *t_max = (int *)smem;                       // bucket table
-    uint32_t *t_key = (uint32_t *)(t_max + nb);
-    float *t_x = (float *)(t_key + nb);
-    float *t_y = t_x + nb;
-    float *t_z = t_y + nb;
-    FbSlots &sl = *(FbSlots *)(t_z + nb);
+    constexpr int TB = NBPT * FB_W;                 // table entries (owner order, see publish)
+    int *t_max = (int *)smem;
+    uint32_t *t_key = (uint32_t *)(t_max + TB);
+    float *t_x = (float *)(t_key + TB);
+    float *t_y = t_x + TB;
+    float *t_z = t_y + TB;
+    FbSlots &sl = *(FbSlots *)(t_z + TB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *__restrict__ sx = a.sx, *__restrict__ sy = a.sy, *__restrict__ sz = a.sz;
-    float *__restrict__ st = a.st;
+    float4 *__restrict__ sp = a.sp;
     const uint32_t *__restrict__ skey = a.skey;
 
-    // re-scan one bucket against sample (qx,qy,qz); `first` = setup pass (no distance update,
-    // also returns the bucket AABB)
-    auto scan = [&](int beta, float qx, float qy, float qz, bool first, float (&lo)[3], float (&hi)[3]) {
-        float best = -2.0f, bxv = 0.f, byv = 0.f, bzv = 0.f;
-        uint32_t bkey = 0xFFFFFFFFu;
-        float llo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-        float lhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    // lane-local best of one bucket after folding sample q into its points
+    struct Cand { float t, x, y, z; uint32_t key; };
+    auto fold = [&](int beta, float qx, float qy, float qz, bool update) {
+        Cand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
 #pragma unroll
         for (int p = 0; p < PPL; ++p) {
             const int i = beta * BS + p * 64 + lane;
-            const float x = sx[i], y = sy[i], z = sz[i];
-            float t = st[i];
+            const float4 v = sp[i];
             const uint32_t key = skey[i];
-            if (!first) {
-                const float d = tpu3_sqdist3(x - qx, y - qy, z - qz);
+            float t = v.w;
+            if (update) {
+                const float d = tpu3_sqdist3(v.x - qx, v.y - qy, v.z - qz);
                 const float d2 = fminf(d, t);
                 if (d2 != t)
-                    st[i] = d2;
+                    ((float *)(sp + i))[3] = d2;
                 t = d2;
-            } else {
-                llo[0] = fminf(llo[0], x); lhi[0] = fmaxf(lhi[0], x);
-                llo[1] = fminf(llo[1], y); lhi[1] = fmaxf(lhi[1], y);
-                llo[2] = fminf(llo[2], z); lhi[2] = fmaxf(lhi[2], z);
             }
-            if (t > best || (t == best && key < bkey)) {
-                best = t; bkey = key; bxv = x; byv = y; bzv = z;
+            if (t > c.t || (t == c.t && key < c.key)) {
+                c.t = t; c.key = key; c.x = v.x; c.y = v.y; c.z = v.z;
             }
         }
-        const int bits = __float_as_int(best);
-        const int wmax = tpu3_wave_max_i32(bits);
-        const uint32_t wkey = tpu3_wave_min_u32(bits == wmax ? bkey : 0xFFFFFFFFu);
-        if (bits == wmax && bkey == wkey && (wkey != 0xFFFFFFFFu || lane == 0)) {
-            t_max[beta] = wmax; t_key[beta] = wkey;
-            t_x[beta] = bxv; t_y[beta] = byv; t_z[beta] = bzv;
+        return c;
+    };
+    // The table is stored in OWNER order: the entry of bucket (j, l, wave) sits at j*1024 + wave*64 + l,
+    // i.e. at j*1024 + tid of its owner, so the per-round table read of a wave is 64 consecutive
+    // words (bucket-id order would put the 64 lanes 16 words apart: a 16-way LDS bank conflict
+    // on every read of every wave, measured at ~4000 LDS cycles per round).
+    auto publish = [&](int e, const Cand &c, int wmax, int win_lane) {
+        if (lane == win_lane) {
+            t_max[e] = wmax; t_key[e] = c.key;
+            t_x[e] = c.x; t_y[e] = c.y; t_z[e] = c.z;
         }
-        if (first)
-            for (int c = 0; c < 3; ++c) {
-                lo[c] = -tpu3_wave_max_f32(-llo[c]);
-                hi[c] = tpu3_wave_max_f32(lhi[c]);
-            }
     };
 
     // ---- setup: every wave scans the buckets its lanes own; the owner lane keeps the AABB --------
@@ -213,13 +201,26 @@ __global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_ele
             const int beta = j * FB_W + l * FB_NW + wave;
             if (beta >= nb)
                 break;
-            float lo[3], hi[3];
-            scan(beta, 0.f, 0.f, 0.f, true, lo, hi);
-            if (lane == l)
-                for (int c = 0; c < 3; ++c) {
-                    blo[j][c] = lo[c];
-                    bhi[j][c] = hi[c];
+            const Cand c = fold(beta, 0.f, 0.f, 0.f, false);
+            int wl;
+            const int wmax = tpu3_wave_argmax(__float_as_int(c.t), c.key, wl);
+            publish(j * FB_W + wave * 64 + l, c, wmax, wl);
+            float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+            float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                const float4 v = sp[beta * BS + p * 64 + lane];
+                lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+                lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+                lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+            }
+            for (int c3 = 0; c3 < 3; ++c3) {
+                const float l3 = -tpu3_wave_max_f32(-lo[c3]), h3 = tpu3_wave_max_f32(hi[c3]);
+                if (lane == l) {
+                    blo[j][c3] = l3;
+                    bhi[j][c3] = h3;
                 }
+            }
         }
     }
 
@@ -231,25 +232,58 @@ __global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_ele
 #pragma unroll
     for (int j = 0; j < NBPT; ++j) {
         const int beta = j * FB_W + lane * FB_NW + wave;
-        cmax[j] = beta < nb ? t_max[beta] : (int)0x80000000;
+        cmax[j] = beta < nb ? t_max[j * FB_W + tid] : (int)0x80000000;
     }
 
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 1; r < a.m; ++r) {
-        // ---- prune test + re-scan of the touched buckets (each by its owning wave) -----------------
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+        if (PROF) tk0 = __builtin_amdgcn_s_memtime();
+        // ---- prune test: which of this wave's buckets can the new sample change? ------------------
+        unsigned long long touched[NBPT];
 #pragma unroll
         for (int j = 0; j < NBPT; ++j) {
             const float dx = fmaxf(fmaxf(blo[j][0] - qx, qx - bhi[j][0]), 0.f);
             const float dy = fmaxf(fmaxf(blo[j][1] - qy, qy - bhi[j][1]), 0.f);
             const float dz = fmaxf(fmaxf(blo[j][2] - qz, qz - bhi[j][2]), 0.f);
-            const float dbox = tpu3_sqdist3(dx, dy, dz);
-            unsigned long long mask = __ballot(dbox < __int_as_float(cmax[j]));
+            touched[j] = __ballot(tpu3_sqdist3(dx, dy, dz) < __int_as_float(cmax[j]));
+        }
+        if (PROF) tk1 = __builtin_amdgcn_s_memtime();
+        // ---- re-scan them two at a time: both buckets' loads are in flight together and the two
+        //      reduction chains interleave; an odd one out is simply scanned twice (idempotent) -----
+#pragma unroll
+        for (int j = 0; j < NBPT; ++j) {
+            unsigned long long mask = touched[j];
             while (mask) {
-                const int l = __builtin_ctzll(mask);
+                const int l0 = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                float lo[3], hi[3];
-                scan(j * FB_W + l * FB_NW + wave, qx, qy, qz, false, lo, hi);
+                int l1 = l0;
+                if (mask) {
+                    l1 = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                }
+                const int b0 = j * FB_W + l0 * FB_NW + wave, b1 = j * FB_W + l1 * FB_NW + wave;
+                const Cand c0 = fold(b0, qx, qy, qz, true);
+                const Cand c1 = fold(b1, qx, qy, qz, true);
+                int m0 = __float_as_int(c0.t), m1 = __float_as_int(c1.t);
+                tpu3_wave_max_i32_fast_x2(m0, m1);
+                unsigned long long t0 = __ballot(__float_as_int(c0.t) == m0);
+                unsigned long long t1 = __ballot(__float_as_int(c1.t) == m1);
+                if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
+                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c0.t) == m0 ? c0.key : 0xFFFFFFFFu);
+                    t0 = __ballot(__float_as_int(c0.t) == m0 && c0.key == k);
+                }
+                if (__builtin_popcountll(t1) != 1) {
+                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c1.t) == m1 ? c1.key : 0xFFFFFFFFu);
+                    t1 = __ballot(__float_as_int(c1.t) == m1 && c1.key == k);
+                }
+                publish(j * FB_W + wave * 64 + l0, c0, m0, __builtin_ctzll(t0));
+                publish(j * FB_W + wave * 64 + l1, c1, m1, __builtin_ctzll(t1));
+                if (PROF) pc[5] += 1 + (b1 != b0);
+                if (PROF) pc[6] += 1;
             }
         }
+        if (PROF) tk2 = __builtin_amdgcn_s_memtime();
         // ---- arg-max over the bucket table --------------------------------------------------------
         int best = (int)0x80000000, bj = 0;
         uint32_t bkey = 0xFFFFFFFFu;
@@ -257,8 +291,8 @@ __global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_ele
         for (int j = 0; j < NBPT; ++j) {
             const int beta = j * FB_W + lane * FB_NW + wave;
             if (beta < nb) {
-                const int v = t_max[beta];
-                const uint32_t k = t_key[beta];
+                const int v = t_max[j * FB_W + tid];
+                const uint32_t k = t_key[j * FB_W + tid];
                 cmax[j] = v;
                 if (v > best || (v == best && k < bkey)) {
                     best = v; bkey = k; bj = j;
@@ -266,33 +300,44 @@ __global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_ele
             }
         }
         const int par = r & 1;
-        const int wmax = tpu3_wave_max_i32(best);
-        const uint32_t wkey = tpu3_wave_min_u32(best == wmax ? bkey : 0xFFFFFFFFu);
-        if (best == wmax && bkey == wkey && (wkey != 0xFFFFFFFFu || lane == 0)) {
-            const int beta = bj * FB_W + lane * FB_NW + wave;
+        int wl;
+        const int wmax = tpu3_wave_argmax(best, bkey, wl);
+        if (lane == wl) {
+            const int beta = bj * FB_W + lane * FB_NW + wave, e = bj * FB_W + tid;
             sl.d[par][wave] = wmax;
-            sl.key[par][wave] = wkey;
+            sl.key[par][wave] = bkey;
             const bool ok = beta < nb;
-            sl.x[par][wave] = ok ? t_x[beta] : 0.f;
-            sl.y[par][wave] = ok ? t_y[beta] : 0.f;
-            sl.z[par][wave] = ok ? t_z[beta] : 0.f;
+            sl.x[par][wave] = ok ? t_x[e] : 0.f;
+            sl.y[par][wave] = ok ? t_y[e] : 0.f;
+            sl.z[par][wave] = ok ? t_z[e] : 0.f;
         }
+        if (PROF) tk3 = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        if (PROF) tk4 = __builtin_amdgcn_s_memtime();
         const int sd = lane < FB_NW ? sl.d[par][lane] : (int)0x80000000;
         const uint32_t sk = lane < FB_NW ? sl.key[par][lane] : 0xFFFFFFFFu;
-        const int rmax = tpu3_row_max_i32(sd);
-        const uint32_t rk = tpu3_row_min_u32(sd == rmax ? sk : 0xFFFFFFFFu);
-        const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
-        const int gmax = __builtin_amdgcn_readlane(rmax, 0);
-        const unsigned long long who = __ballot(lane < FB_NW && sd == gmax && sk == win);
-        const int ww = __builtin_ctzll(who | (1ull << 63));
-        qx = sl.x[par][ww & 15];
-        qy = sl.y[par][ww & 15];
-        qz = sl.z[par][ww & 15];
-        old = tpu3_fps_tiekey_to_index(win, lb);
+        const int gmax = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+        unsigned long long who = __ballot(lane < FB_NW && sd == gmax);
+        if (__builtin_popcountll(who) != 1) {
+            const uint32_t rk = tpu3_row_min_u32(lane < FB_NW && sd == gmax ? sk : 0xFFFFFFFFu);
+            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
+            who = __ballot(lane < FB_NW && sd == gmax && sk == win);
+        }
+        const int ww = __builtin_ctzll(who | (1ull << 63)) & 15;
+        qx = sl.x[par][ww];
+        qy = sl.y[par][ww];
+        qz = sl.z[par][ww];
+        old = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
         if (tid == 0)
             a.idx[r] = old;
+        if (PROF) {
+            const unsigned long long tk5 = __builtin_amdgcn_s_memtime();
+            pc[0] += tk1 - tk0; pc[1] += tk2 - tk1; pc[2] += tk3 - tk2; pc[3] += tk4 - tk3; pc[4] += tk5 - tk4;
+        }
     }
+    if (PROF && lane == 0 && a.prof)
+        for (int i = 0; i < 8; ++i)
+            a.prof[wave * 8 + i] = pc[i];
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -337,7 +382,7 @@ bool fb_plan(int b, int n, FbPlan &p)
 template <int NBPT, int PPL>
 int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, size_t per_elem, int nb, int lb)
 {
-    const size_t lds = (size_t)nb * 20 + sizeof(FbSlots) + 16;
+    const size_t lds = (size_t)NBPT * FB_W * 20 + sizeof(FbSlots) + 16;
     auto kern = fb_main_kernel<NBPT, PPL>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
@@ -380,9 +425,9 @@ int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz,
     const size_t ks = align256(sizeof(uint32_t) * (size_t)n), ps = align256(sizeof(float) * (size_t)p.npad);
     FbArgs a0;
     a0.n = n; a0.m = m; a0.nb = p.nb; a0.npad = p.npad;
-    a0.xyz = xyz; a0.temp = temp; a0.idx = idx;
+    a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = nullptr;
     char *q0 = base + 4 * ks;
-    a0.sx = (float *)q0; a0.sy = (float *)(q0 + ps); a0.sz = (float *)(q0 + 2 * ps); a0.st = (float *)(q0 + 3 * ps);
+    a0.sp = (float4 *)q0;
     a0.skey = (uint32_t *)(q0 + 4 * ps);
     for (int i = 0; i < b; ++i) {
         char *e = base + (size_t)i * p.per_elem;
@@ -410,5 +455,42 @@ int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz,
         return r;
     for (int i = 0; i < b; ++i)
         hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fb_elem(a0, p.per_elem, i), lb);
+    return tpu3_launch_status();
+}
+
+// Development probe (not part of include/tpu3.h): runs the <4,1> kernel with per-phase cycle
+// counters; prof = 16 x 8 u64: [prune, rescan, argmax, barrier wait, broadcast, buckets, pairs, -].
+extern "C" int tpu3_debug_fps_bucket_profile(void *stream, int n, int m, const float *xyz, float *temp,
+                                             int32_t *idx, void *workspace, size_t workspace_bytes,
+                                             unsigned long long *prof)
+{
+    hipStream_t s = (hipStream_t)stream;
+    FbPlan p;
+    if (!fb_plan(1, n, p) || p.ppl != 1 || p.nbpt != 4 || workspace_bytes < p.total)
+        return TPU3_EINVAL;
+    char *base = (char *)workspace;
+    char *sort_tmp = base + p.per_elem;
+    const int lb = tpu3_fps_log2_bs(n);
+    const size_t ks = align256(sizeof(uint32_t) * (size_t)n), ps = align256(sizeof(float) * (size_t)p.npad);
+    FbArgs a0;
+    a0.n = n; a0.m = m; a0.nb = p.nb; a0.npad = p.npad;
+    a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = prof;
+    char *q0 = base + 4 * ks;
+    a0.sp = (float4 *)q0;
+    a0.skey = (uint32_t *)(q0 + 4 * ps);
+    uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + ks);
+    uint32_t *v_in = (uint32_t *)(base + 2 * ks), *v_out = (uint32_t *)(base + 3 * ks);
+    float *bbox = (float *)(base + 4 * ks + 5 * ps);
+    hipLaunchKernelGGL(fb_bbox_kernel, dim3(1), dim3(1024), 0, s, n, xyz, bbox);
+    hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, xyz, bbox, k_in, v_in);
+    size_t tb = p.sort_temp;
+    hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 30, s);
+    if (se != hipSuccess) return (int)se;
+    hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256), dim3(256), 0, s, a0, v_out, lb);
+    const size_t lds = (size_t)4 * FB_W * 20 + sizeof(FbSlots) + 16;
+    auto kern = fb_main_kernel<4, 1, true>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(FB_W), lds, s, a0, p.per_elem, lb);
     return tpu3_launch_status();
 }

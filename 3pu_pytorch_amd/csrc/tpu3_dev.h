@@ -104,6 +104,70 @@ __device__ __forceinline__ float tpu3_wave_sum_f32(float v)
     return v;
 }
 
+// ---- latency-tuned reductions for the FPS round loops ----------------------------------------------
+// hipcc lowers the update_dpp + max pairs above to v_mov_dpp / v_max / v_mov / s_nop (4 issue slots
+// per step).  The FPS kernels are one long dependent chain per round, so here the DPP modifier is
+// fused into the max itself (one instruction + the 2 wait states a DPP read of a freshly written
+// VGPR needs), and a two-value form interleaves two independent chains so each fills the other's
+// wait states.
+#define TPU3_DPP_MAX_I32(reg, ctrl) "v_max_i32_dpp " reg ", " reg ", " reg " " ctrl "\n\t"
+__device__ __forceinline__ int tpu3_wave_max_i32_fast(int v)
+{
+    asm volatile("s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_half_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n\t"
+                 : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void tpu3_wave_max_i32_fast_x2(int &a, int &b)
+{
+    asm volatile("s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_half_mirror row_mask:0xf bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "row_half_mirror row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_mirror row_mask:0xf bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "row_mirror row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 TPU3_DPP_MAX_I32("%1", "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n\t"
+                 : "+v"(a), "+v"(b));
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+}
+// max over the 16 lanes of row 0 only (cross-wave slots); result valid in every lane of row 0
+__device__ __forceinline__ int tpu3_row_max_i32_fast(int v)
+{
+    asm volatile("s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_half_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 TPU3_DPP_MAX_I32("%0", "row_mirror row_mask:0xf bank_mask:0xf") "s_nop 1\n\t"
+                 : "+v"(v));
+    return v;
+}
+
+// Wave arg-max with the FPS tie rule: value = signed-int order of the distance bits, ties (rare:
+// duplicated points) to the smallest key.  Returns the maximum; `lane` = the one winning lane.
+__device__ __forceinline__ int tpu3_wave_argmax(int bits, uint32_t key, int &lane)
+{
+    const int wmax = tpu3_wave_max_i32_fast(bits);
+    unsigned long long tie = __ballot(bits == wmax);
+    if (__builtin_popcountll(tie) != 1) {
+        const uint32_t wkey = tpu3_wave_min_u32(bits == wmax ? key : 0xFFFFFFFFu);
+        tie = __ballot(bits == wmax && key == wkey);
+    }
+    lane = __builtin_ctzll(tie);
+    return wmax;
+}
+
 // FPS tie key (see tpu3.h): lexicographic (k mod bs, k div bs) packed so that unsigned order
 // is the reference's winner order among equal distances; bs = 1 << lb <= 512.
 __device__ __forceinline__ uint32_t tpu3_fps_tiekey(int k, int lb)
