@@ -7,38 +7,45 @@
 // (and identical final `temp`) while touching only that ball:
 //
 //   setup   points are sorted along a 30-bit Morton curve (rocPRIM radix sort) and cut into
-//           buckets of 64*PPL consecutive points; a bucket knows its tight AABB, and the table in
-//           LDS holds for every bucket its current (max distance, tie key, xyz of that point).
-//   round   every lane tests the buckets it owns:  dbox(sample, AABB) >= bucket max  ==> no
-//           point of the bucket can change (dbox is computed with the same fp32 association as the
-//           point distance, and fp32 rounding is monotone, so dbox <= d(p) for every p inside:
-//           min(d(p), temp[p]) == temp[p] exactly) -- skip it.  Touched buckets are re-scanned by
-//           the wave that owns them (64 lanes = 64 points, one coalesced read of x,y,z,temp,key).
-//           Then the arg-max over the bucket table (DPP wave reduction + one LDS hand-off, ONE
-//           s_barrier per round) picks the next sample with the reference's tie rule.
+//           BUCKETS of 64*PPL consecutive points; 16 consecutive buckets form a GROUP (one DPP row).
+//           Every bucket / group knows an AABB and its current (max distance, tie key, xyz of that
+//           point).  Bucket table + fp16 (outward-rounded) bucket boxes live in LDS, group boxes in
+//           the owner lane's registers, the group table in LDS.
+//   round   1. every lane tests the groups it owns:  dbox(sample, AABB) >= max  ==> nothing inside
+//              can change (dbox uses the fp32 association of the point distance and fp32 rounding is
+//              monotone, so dbox <= d(p) for every p inside: min(d(p), temp[p]) == temp[p] exactly);
+//           2. the 16 children of each touched group are tested the same way by one DPP row (up to 4
+//              groups per wave instruction);
+//           3. touched buckets are re-scanned two at a time (64 lanes = 64 points; both buckets'
+//              loads in flight together, the two reduction chains interleaved);
+//           4. the touched groups' entries are rebuilt by a 16-lane row arg-max;
+//           5. arg-max over the group table (fused-DPP wave reduction, one LDS hand-off across the
+//              waves, ONE s_barrier per round) picks the next sample with the reference's tie rule.
 //
-// One workgroup (1024 lanes) per batch element; bucket b is owned by wave b%16, lane (b/16)%64,
-// so spatially adjacent (Morton-consecutive) buckets are re-scanned by different waves.  Every
-// table entry is written and read by the same wave, hence no second barrier.
+// One workgroup of NW waves (one per SIMD: the per-round work is a dependent chain, extra waves only
+// add issue pressure -- a 16-wave version of this kernel was issue-bound at 4400 cycles per round)
+// per batch element.  Group g belongs to wave g % NW, so spatially adjacent groups are handled by
+// different waves; every table entry is written and read by the same wave, hence no second barrier.
 #include "tpu3_dev.h"
+
+#include <hip/hip_fp16.h>
 
 #include <cstring>
 #include <rocprim/rocprim.hpp>
-#include <vector>
 
 namespace {
 
-constexpr int FB_W = 1024;
-constexpr int FB_NW = FB_W / 64;
+constexpr int FB_GS = 16;        // buckets per group = lanes per DPP row
 
 struct FbArgs {
-    int n, m, nb, npad;
+    int n, m, nb, nbpad, npad, ng;
     const float *xyz;     // (n,3) original order
     float *temp;          // (n)
     int32_t *idx;         // (m)
     float4 *sp;           // (npad) Morton order: x, y, z, running distance
     uint32_t *skey;       // (npad) tie key of the original index (0xFFFFFFFF = padding)
-    unsigned long long *prof;   // PROF builds only: 16 waves x 8 cycle counters
+    uint32_t *ib;         // (8, nbpad) initial bucket table: max, key, x, y, z, box0, box1, box2
+    unsigned long long *prof;   // PROF builds only
 };
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
@@ -117,10 +124,126 @@ __global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a, int lb)
         a.temp[tpu3_fps_tiekey_to_index(a.skey[i], lb)] = a.sp[i].w;
 }
 
-struct FbSlots {
-    int d[2][FB_NW];
-    uint32_t key[2][FB_NW];
-    float x[2][FB_NW], y[2][FB_NW], z[2][FB_NW];
+// lane-local best of one bucket (64*PPL points), optionally after folding sample q into it
+struct FbCand {
+    float t, x, y, z;
+    uint32_t key;
+};
+
+// The re-scan of a bucket is split into load / apply / store so that a caller can put the loads of
+// two buckets in flight together and issue the stores LAST: on gfx950 loads and stores share vmcnt
+// but complete out of order with each other, so a value loaded before a store can only be waited
+// for with vmcnt(0) once the store is in the queue -- a store between a load and its first use
+// costs a full store round trip (measured: 2000 instead of 600 cycles per bucket pair).
+template <int PPL>
+struct FbBucket {
+    float4 v[PPL];
+    uint32_t key[PPL];
+    float nt[PPL];          // updated running distances
+};
+
+template <int PPL>
+__device__ __forceinline__ void fb_load(FbBucket<PPL> &b, const float4 *__restrict__ sp,
+                                        const uint32_t *__restrict__ skey, int beta, int lane)
+{
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        const int i = beta * (64 * PPL) + p * 64 + lane;
+        b.v[p] = sp[i];
+        b.key[p] = skey[i];
+    }
+}
+
+template <int PPL>
+__device__ __forceinline__ FbCand fb_apply(FbBucket<PPL> &b, float qx, float qy, float qz, bool update)
+{
+    FbCand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        float t = b.v[p].w;
+        if (update)
+            t = fminf(tpu3_sqdist3(b.v[p].x - qx, b.v[p].y - qy, b.v[p].z - qz), t);
+        b.nt[p] = t;
+        if (t > c.t || (t == c.t && b.key[p] < c.key)) {
+            c.t = t; c.key = b.key[p]; c.x = b.v[p].x; c.y = b.v[p].y; c.z = b.v[p].z;
+        }
+    }
+    return c;
+}
+
+template <int PPL>
+__device__ __forceinline__ void fb_store(const FbBucket<PPL> &b, float4 *__restrict__ sp, int beta, int lane)
+{
+#pragma unroll
+    for (int p = 0; p < PPL; ++p)
+        if (b.nt[p] != b.v[p].w)
+            ((float *)(sp + beta * (64 * PPL) + p * 64 + lane))[3] = b.nt[p];
+}
+
+// initial bucket table (one wave per bucket, whole GPU): max / key / xyz and the fp16 box, rounded
+// outward so that it still contains every point
+template <int PPL>
+__global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int beta = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (beta >= a.nbpad)
+        return;
+    uint32_t *ib = a.ib;
+    const int S = a.nbpad;
+    if (beta >= a.nb) {     // padding bucket: never wins, infinitely far away
+        if (lane == 0) {
+            const uint32_t pinf = 0x7C00u | (0x7C00u << 16);
+            ib[0 * S + beta] = 0x80000000u; ib[1 * S + beta] = 0xFFFFFFFFu;
+            ib[2 * S + beta] = 0; ib[3 * S + beta] = 0; ib[4 * S + beta] = 0;
+            ib[5 * S + beta] = pinf; ib[6 * S + beta] = pinf; ib[7 * S + beta] = pinf;
+        }
+        return;
+    }
+    FbBucket<PPL> bk;
+    fb_load<PPL>(bk, a.sp, a.skey, beta, lane);
+    const FbCand c = fb_apply<PPL>(bk, 0.f, 0.f, 0.f, false);
+    int wl;
+    const int wmax = tpu3_wave_argmax(__float_as_int(c.t), c.key, wl);
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        const float4 v = bk.v[p];
+        lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+        lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+        lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+    }
+    uint32_t h[6];
+    for (int c3 = 0; c3 < 3; ++c3) {
+        h[c3] = __half_as_ushort(__float2half_rd(-tpu3_wave_max_f32(-lo[c3])));
+        h[3 + c3] = __half_as_ushort(__float2half_ru(tpu3_wave_max_f32(hi[c3])));
+    }
+    if (lane == wl) {
+        ib[0 * S + beta] = (uint32_t)wmax; ib[1 * S + beta] = c.key;
+        ib[2 * S + beta] = __float_as_uint(c.x); ib[3 * S + beta] = __float_as_uint(c.y);
+        ib[4 * S + beta] = __float_as_uint(c.z);
+        ib[5 * S + beta] = h[0] | (h[1] << 16); ib[6 * S + beta] = h[2] | (h[3] << 16);
+        ib[7 * S + beta] = h[4] | (h[5] << 16);
+    }
+}
+
+__device__ __forceinline__ float fb_half_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); }
+__device__ __forceinline__ float fb_half_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
+
+__device__ __forceinline__ float fb_dbox(float qx, float qy, float qz, float lx, float ly, float lz, float hx,
+                                         float hy, float hz)
+{
+    const float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
+    const float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
+    const float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
+    return tpu3_sqdist3(dx, dy, dz);
+}
+
+struct FbSlots {        // cross-wave hand-off, up to 8 waves
+    int d[2][8];
+    uint32_t key[2][8];
+    float x[2][8], y[2][8], z[2][8];
 };
 
 // arguments of batch element i from those of element 0: user arrays are dense (b, n, ...) slabs,
@@ -133,273 +256,367 @@ __host__ __device__ inline FbArgs fb_elem(const FbArgs &a0, size_t per_elem, int
     a.idx = a0.idx + (size_t)i * a0.m;
     a.sp = (float4 *)((char *)a0.sp + (size_t)i * per_elem);
     a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * per_elem);
+    a.ib = (uint32_t *)((char *)a0.ib + (size_t)i * per_elem);
     return a;
 }
 
-template <int NBPT, int PPL, bool PROF = false>
-__global__ __launch_bounds__(FB_W) void fb_main_kernel(FbArgs a0, size_t per_elem, int lb)
+// LDS bytes of the main kernel: 8 words per bucket, 11 per group-table entry, the slots
+constexpr size_t fb_lds_bytes(int nbpad, int nw, int ngpt)
 {
-    constexpr int BS = 64 * PPL;
+    return (size_t)nbpad * 32 + (size_t)ngpt * nw * 64 * 11 * 4 + sizeof(FbSlots) + 64;
+}
+
+template <int NW, int NGPT, int PPL, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0, size_t per_elem, int lb)
+{
+    constexpr int W = NW * 64;
+    constexpr int GT = NGPT * W;                    // group-table entries (owner order)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FbArgs a = fb_elem(a0, per_elem, blockIdx.x);
-    const int nb = a.nb;
-    constexpr int TB = NBPT * FB_W;                 // table entries (owner order, see publish)
+    const int nbpad = a.nbpad, ng = a.ng;
+    // bucket table, indexed by bucket id (a DPP row reads 16 consecutive children)
     int *t_max = (int *)smem;
-    uint32_t *t_key = (uint32_t *)(t_max + TB);
-    float *t_x = (float *)(t_key + TB);
-    float *t_y = t_x + TB;
-    float *t_z = t_y + TB;
-    FbSlots &sl = *(FbSlots *)(t_z + TB);
+    uint32_t *t_key = (uint32_t *)(t_max + nbpad);
+    float *t_x = (float *)(t_key + nbpad);
+    float *t_y = t_x + nbpad;
+    float *t_z = t_y + nbpad;
+    uint32_t *t_b0 = (uint32_t *)(t_z + nbpad);     // fp16 boxes: lo.x|lo.y, lo.z|hi.x, hi.y|hi.z
+    uint32_t *t_b1 = t_b0 + nbpad;
+    uint32_t *t_b2 = t_b1 + nbpad;
+    // group table in OWNER order (entry of the group owned by lane `l`, slot `j` at j*W + tid):
+    // the per-round read of a wave is 64 consecutive words, no bank conflicts
+    int *g_max = (int *)(t_b2 + nbpad);
+    uint32_t *g_key = (uint32_t *)(g_max + GT);
+    float *g_x = (float *)(g_key + GT);
+    float *g_y = g_x + GT;
+    float *g_z = g_y + GT;
+    float *g_box = g_z + GT;                        // 6 x GT, setup only
+    FbSlots &sl = *(FbSlots *)(g_box + 6 * GT);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane >> 4, col = lane & 15;
     float4 *__restrict__ sp = a.sp;
     const uint32_t *__restrict__ skey = a.skey;
 
-    // lane-local best of one bucket after folding sample q into its points
-    struct Cand { float t, x, y, z; uint32_t key; };
-    auto fold = [&](int beta, float qx, float qy, float qz, bool update) {
-        Cand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) {
-            const int i = beta * BS + p * 64 + lane;
-            const float4 v = sp[i];
-            const uint32_t key = skey[i];
-            float t = v.w;
-            if (update) {
-                const float d = tpu3_sqdist3(v.x - qx, v.y - qy, v.z - qz);
-                const float d2 = fminf(d, t);
-                if (d2 != t)
-                    ((float *)(sp + i))[3] = d2;
-                t = d2;
-            }
-            if (t > c.t || (t == c.t && key < c.key)) {
-                c.t = t; c.key = key; c.x = v.x; c.y = v.y; c.z = v.z;
-            }
+    // group g  <->  wave g % NW, owner slot g / NW (lane slot % 64, register slot / 64)
+    auto group_entry = [&](int slot) { return (slot >> 6) * W + wave * 64 + (slot & 63); };
+
+    // Rebuild the entries of up to four groups at once: DPP row r handles the group in owner slot
+    // `slot` (per lane; < 0 = row idle).  Row arg-max over the 16 children with the FPS tie rule.
+    auto refresh_groups = [&](int slot, bool with_box) {
+        const bool valid = slot >= 0 && slot * NW + wave < ng;
+        const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+        const int bits = valid ? t_max[beta] : (int)0x80000000;
+        const uint32_t key = valid ? t_key[beta] : 0xFFFFFFFFu;
+        const int rmax = tpu3_row_max_i32_fast(bits);
+        unsigned long long tie = __ballot(valid && bits == rmax);
+        const unsigned long long rows = __ballot(valid && col == 0);
+        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
+            const uint32_t k = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
+            tie = __ballot(valid && bits == rmax && key == k);
         }
-        return c;
-    };
-    // The table is stored in OWNER order: the entry of bucket (j, l, wave) sits at j*1024 + wave*64 + l,
-    // i.e. at j*1024 + tid of its owner, so the per-round table read of a wave is 64 consecutive
-    // words (bucket-id order would put the 64 lanes 16 words apart: a 16-way LDS bank conflict
-    // on every read of every wave, measured at ~4000 LDS cycles per round).
-    auto publish = [&](int e, const Cand &c, int wmax, int win_lane) {
-        if (lane == win_lane) {
-            t_max[e] = wmax; t_key[e] = c.key;
-            t_x[e] = c.x; t_y[e] = c.y; t_z[e] = c.z;
+        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
+        if (valid && ((tie >> lane) & 1ull) && (tie & below) == 0) {
+            const int e = group_entry(slot);
+            g_max[e] = rmax; g_key[e] = key;
+            g_x[e] = t_x[beta]; g_y[e] = t_y[beta]; g_z[e] = t_z[beta];
+        }
+        if (with_box) {     // setup: group AABB = union of the children's (outward-rounded) boxes
+            const uint32_t w0 = valid ? t_b0[beta] : 0, w1 = valid ? t_b1[beta] : 0, w2 = valid ? t_b2[beta] : 0;
+            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
+                          fb_half_hi(w2)};
+            for (int c3 = 0; c3 < 6; ++c3) {
+                if (!valid)
+                    v[c3] = -__builtin_inff();
+                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
+                if (valid && col == 0)
+                    g_box[c3 * GT + group_entry(slot)] = c3 < 3 ? -m : m;
+            }
         }
     };
 
-    // ---- setup: every wave scans the buckets its lanes own; the owner lane keeps the AABB --------
-    float blo[NBPT][3], bhi[NBPT][3];
+    // ---- setup: bucket table from the init kernel's arrays, then every group's entry + AABB --------
+    for (int i = tid; i < nbpad; i += W) {
+        t_max[i] = (int)a.ib[0 * nbpad + i];
+        t_key[i] = a.ib[1 * nbpad + i];
+        t_x[i] = __uint_as_float(a.ib[2 * nbpad + i]);
+        t_y[i] = __uint_as_float(a.ib[3 * nbpad + i]);
+        t_z[i] = __uint_as_float(a.ib[4 * nbpad + i]);
+        t_b0[i] = a.ib[5 * nbpad + i];
+        t_b1[i] = a.ib[6 * nbpad + i];
+        t_b2[i] = a.ib[7 * nbpad + i];
+    }
+    for (int i = tid; i < GT; i += W) {
+        g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu;
+        g_x[i] = g_y[i] = g_z[i] = 0.f;
+        for (int c3 = 0; c3 < 6; ++c3)
+            g_box[c3 * GT + i] = __builtin_inff();          // lo = hi = +inf: infinitely far away
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < NGPT * 64; s0 += 4)
+        if ((s0 * NW + wave) < ng)
+            refresh_groups(s0 + row, true);
+    __syncthreads();
+    float gbox[NGPT][6];
+    int gmax[NGPT];
 #pragma unroll
-    for (int j = 0; j < NBPT; ++j) {
-        for (int c = 0; c < 3; ++c) {           // an unowned slot is infinitely far away
-            blo[j][c] = __builtin_inff();
-            bhi[j][c] = __builtin_inff();
-        }
-        for (int l = 0; l < 64; ++l) {
-            const int beta = j * FB_W + l * FB_NW + wave;
-            if (beta >= nb)
-                break;
-            const Cand c = fold(beta, 0.f, 0.f, 0.f, false);
-            int wl;
-            const int wmax = tpu3_wave_argmax(__float_as_int(c.t), c.key, wl);
-            publish(j * FB_W + wave * 64 + l, c, wmax, wl);
-            float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-            float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-#pragma unroll
-            for (int p = 0; p < PPL; ++p) {
-                const float4 v = sp[beta * BS + p * 64 + lane];
-                lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-                lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-                lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-            }
-            for (int c3 = 0; c3 < 3; ++c3) {
-                const float l3 = -tpu3_wave_max_f32(-lo[c3]), h3 = tpu3_wave_max_f32(hi[c3]);
-                if (lane == l) {
-                    blo[j][c3] = l3;
-                    bhi[j][c3] = h3;
-                }
-            }
-        }
+    for (int j = 0; j < NGPT; ++j) {
+        for (int c3 = 0; c3 < 6; ++c3)
+            gbox[j][c3] = g_box[c3 * GT + j * W + tid];
+        gmax[j] = g_max[j * W + tid];
     }
 
-    int old = 0;
     if (tid == 0)
         a.idx[0] = 0;
     float qx = a.xyz[0], qy = a.xyz[1], qz = a.xyz[2];
-    int cmax[NBPT];                 // this lane's buckets: current max bits (for the prune test)
-#pragma unroll
-    for (int j = 0; j < NBPT; ++j) {
-        const int beta = j * FB_W + lane * FB_NW + wave;
-        cmax[j] = beta < nb ? t_max[j * FB_W + tid] : (int)0x80000000;
-    }
 
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 1; r < a.m; ++r) {
-        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
         if (PROF) tk0 = __builtin_amdgcn_s_memtime();
-        // ---- prune test: which of this wave's buckets can the new sample change? ------------------
-        unsigned long long touched[NBPT];
+        // ---- 1. group prune --------------------------------------------------------------------------
+        unsigned long long gm[NGPT];
 #pragma unroll
-        for (int j = 0; j < NBPT; ++j) {
-            const float dx = fmaxf(fmaxf(blo[j][0] - qx, qx - bhi[j][0]), 0.f);
-            const float dy = fmaxf(fmaxf(blo[j][1] - qy, qy - bhi[j][1]), 0.f);
-            const float dz = fmaxf(fmaxf(blo[j][2] - qz, qz - bhi[j][2]), 0.f);
-            touched[j] = __ballot(tpu3_sqdist3(dx, dy, dz) < __int_as_float(cmax[j]));
-        }
-        if (PROF) tk1 = __builtin_amdgcn_s_memtime();
-        // ---- re-scan them two at a time: both buckets' loads are in flight together and the two
-        //      reduction chains interleave; an odd one out is simply scanned twice (idempotent) -----
+        for (int j = 0; j < NGPT; ++j)
+            gm[j] = __ballot(fb_dbox(qx, qy, qz, gbox[j][0], gbox[j][1], gbox[j][2], gbox[j][3], gbox[j][4],
+                                     gbox[j][5]) < __int_as_float(gmax[j]));
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (PROF) { ta = __builtin_amdgcn_s_memtime(); pc[8] += ta - tk0; }
 #pragma unroll
-        for (int j = 0; j < NBPT; ++j) {
-            unsigned long long mask = touched[j];
+        for (int j = 0; j < NGPT; ++j) {
+            unsigned long long mask = gm[j];
             while (mask) {
-                const int l0 = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                int l1 = l0;
-                if (mask) {
-                    l1 = __builtin_ctzll(mask);
-                    mask &= mask - 1;
+                // up to four touched groups, one per DPP row
+                int slot = -1;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (mask) {
+                        const int l = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        if (row == rr)
+                            slot = j * 64 + l;
+                    }
+                // ---- 2. children test ------------------------------------------------------------------
+                const bool valid = slot >= 0;
+                const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+                const uint32_t w0 = t_b0[beta], w1 = t_b1[beta], w2 = t_b2[beta];
+                const float db = fb_dbox(qx, qy, qz, fb_half_lo(w0), fb_half_hi(w0), fb_half_lo(w1), fb_half_hi(w1),
+                                         fb_half_lo(w2), fb_half_hi(w2));
+                unsigned long long bt = __ballot(valid && db < __int_as_float(t_max[beta]));
+                if (PROF) { tb = __builtin_amdgcn_s_memtime(); pc[9] += tb - ta; }
+                // ---- 3. re-scan the touched buckets two at a time (an odd one out twice: idempotent) ---
+                while (bt) {
+                    const int p0 = __builtin_ctzll(bt);
+                    bt &= bt - 1;
+                    int p1 = p0;
+                    if (bt) {
+                        p1 = __builtin_ctzll(bt);
+                        bt &= bt - 1;
+                    }
+                    const int b0 = __builtin_amdgcn_readlane(beta, p0), b1 = __builtin_amdgcn_readlane(beta, p1);
+                    FbBucket<PPL> k0, k1;
+                    fb_load<PPL>(k0, sp, skey, b0, lane);
+                    fb_load<PPL>(k1, sp, skey, b1, lane);
+                    const FbCand c0 = fb_apply<PPL>(k0, qx, qy, qz, true);
+                    const FbCand c1 = fb_apply<PPL>(k1, qx, qy, qz, true);
+                    int m0 = __float_as_int(c0.t), m1 = __float_as_int(c1.t);
+                    if (PROF) { asm volatile("" :: "v"(m0), "v"(m1)); tc = __builtin_amdgcn_s_memtime(); pc[10] += tc - tb; }
+                    tpu3_wave_max_i32_fast_x2(m0, m1);
+                    unsigned long long t0 = __ballot(__float_as_int(c0.t) == m0);
+                    unsigned long long t1 = __ballot(__float_as_int(c1.t) == m1);
+                    if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
+                        const uint32_t k = tpu3_wave_min_u32(__float_as_int(c0.t) == m0 ? c0.key : 0xFFFFFFFFu);
+                        t0 = __ballot(__float_as_int(c0.t) == m0 && c0.key == k);
+                    }
+                    if (__builtin_popcountll(t1) != 1) {
+                        const uint32_t k = tpu3_wave_min_u32(__float_as_int(c1.t) == m1 ? c1.key : 0xFFFFFFFFu);
+                        t1 = __ballot(__float_as_int(c1.t) == m1 && c1.key == k);
+                    }
+                    if (lane == (int)__builtin_ctzll(t0)) {
+                        t_max[b0] = m0; t_key[b0] = c0.key; t_x[b0] = c0.x; t_y[b0] = c0.y; t_z[b0] = c0.z;
+                    }
+                    if (lane == (int)__builtin_ctzll(t1)) {
+                        t_max[b1] = m1; t_key[b1] = c1.key; t_x[b1] = c1.x; t_y[b1] = c1.y; t_z[b1] = c1.z;
+                    }
+                    fb_store<PPL>(k0, sp, b0, lane);        // stores last, off the dependent chain
+                    if (b1 != b0)
+                        fb_store<PPL>(k1, sp, b1, lane);
+                    if (PROF) pc[5] += 1 + (b1 != b0);
+                    if (PROF) { tb = __builtin_amdgcn_s_memtime(); pc[11] += tb - tc; }
                 }
-                const int b0 = j * FB_W + l0 * FB_NW + wave, b1 = j * FB_W + l1 * FB_NW + wave;
-                const Cand c0 = fold(b0, qx, qy, qz, true);
-                const Cand c1 = fold(b1, qx, qy, qz, true);
-                int m0 = __float_as_int(c0.t), m1 = __float_as_int(c1.t);
-                tpu3_wave_max_i32_fast_x2(m0, m1);
-                unsigned long long t0 = __ballot(__float_as_int(c0.t) == m0);
-                unsigned long long t1 = __ballot(__float_as_int(c1.t) == m1);
-                if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
-                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c0.t) == m0 ? c0.key : 0xFFFFFFFFu);
-                    t0 = __ballot(__float_as_int(c0.t) == m0 && c0.key == k);
-                }
-                if (__builtin_popcountll(t1) != 1) {
-                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c1.t) == m1 ? c1.key : 0xFFFFFFFFu);
-                    t1 = __ballot(__float_as_int(c1.t) == m1 && c1.key == k);
-                }
-                publish(j * FB_W + wave * 64 + l0, c0, m0, __builtin_ctzll(t0));
-                publish(j * FB_W + wave * 64 + l1, c1, m1, __builtin_ctzll(t1));
-                if (PROF) pc[5] += 1 + (b1 != b0);
+                // ---- 4. rebuild the touched groups' entries ------------------------------------------------
+                if (PROF) td = __builtin_amdgcn_s_memtime();
+                refresh_groups(slot, false);
+                if (PROF) { ta = __builtin_amdgcn_s_memtime(); pc[12] += ta - td; }
                 if (PROF) pc[6] += 1;
             }
         }
-        if (PROF) tk2 = __builtin_amdgcn_s_memtime();
-        // ---- arg-max over the bucket table --------------------------------------------------------
+        if (PROF) tk1 = __builtin_amdgcn_s_memtime();
+        // ---- 5. arg-max over the group table ----------------------------------------------------------
         int best = (int)0x80000000, bj = 0;
         uint32_t bkey = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < NBPT; ++j) {
-            const int beta = j * FB_W + lane * FB_NW + wave;
-            if (beta < nb) {
-                const int v = t_max[j * FB_W + tid];
-                const uint32_t k = t_key[j * FB_W + tid];
-                cmax[j] = v;
-                if (v > best || (v == best && k < bkey)) {
-                    best = v; bkey = k; bj = j;
-                }
+        for (int j = 0; j < NGPT; ++j) {
+            const int v = g_max[j * W + tid];
+            const uint32_t k = g_key[j * W + tid];
+            gmax[j] = v;
+            if (v > best || (v == best && k < bkey)) {
+                best = v; bkey = k; bj = j;
             }
         }
         const int par = r & 1;
         int wl;
         const int wmax = tpu3_wave_argmax(best, bkey, wl);
         if (lane == wl) {
-            const int beta = bj * FB_W + lane * FB_NW + wave, e = bj * FB_W + tid;
+            const int e = bj * W + tid;
             sl.d[par][wave] = wmax;
             sl.key[par][wave] = bkey;
-            const bool ok = beta < nb;
-            sl.x[par][wave] = ok ? t_x[e] : 0.f;
-            sl.y[par][wave] = ok ? t_y[e] : 0.f;
-            sl.z[par][wave] = ok ? t_z[e] : 0.f;
+            sl.x[par][wave] = g_x[e];
+            sl.y[par][wave] = g_y[e];
+            sl.z[par][wave] = g_z[e];
         }
-        if (PROF) tk3 = __builtin_amdgcn_s_memtime();
+        if (PROF) tk2 = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        if (PROF) tk4 = __builtin_amdgcn_s_memtime();
-        const int sd = lane < FB_NW ? sl.d[par][lane] : (int)0x80000000;
-        const uint32_t sk = lane < FB_NW ? sl.key[par][lane] : 0xFFFFFFFFu;
-        const int gmax = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-        unsigned long long who = __ballot(lane < FB_NW && sd == gmax);
+        if (PROF) tk3 = __builtin_amdgcn_s_memtime();
+        const int sd = lane < NW ? sl.d[par][lane] : (int)0x80000000;
+        const uint32_t sk = lane < NW ? sl.key[par][lane] : 0xFFFFFFFFu;
+        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+        unsigned long long who = __ballot(lane < NW && sd == gbest);
         if (__builtin_popcountll(who) != 1) {
-            const uint32_t rk = tpu3_row_min_u32(lane < FB_NW && sd == gmax ? sk : 0xFFFFFFFFu);
+            const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
             const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
-            who = __ballot(lane < FB_NW && sd == gmax && sk == win);
+            who = __ballot(lane < NW && sd == gbest && sk == win);
         }
-        const int ww = __builtin_ctzll(who | (1ull << 63)) & 15;
+        const int ww = __builtin_ctzll(who | (1ull << 63)) & 7;
         qx = sl.x[par][ww];
         qy = sl.y[par][ww];
         qz = sl.z[par][ww];
-        old = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
         if (tid == 0)
-            a.idx[r] = old;
+            a.idx[r] = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
         if (PROF) {
-            const unsigned long long tk5 = __builtin_amdgcn_s_memtime();
-            pc[0] += tk1 - tk0; pc[1] += tk2 - tk1; pc[2] += tk3 - tk2; pc[3] += tk4 - tk3; pc[4] += tk5 - tk4;
+            const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
+            pc[0] += tk1 - tk0; pc[1] += tk2 - tk1; pc[2] += tk3 - tk2; pc[3] += tk4 - tk3;
         }
     }
     if (PROF && lane == 0 && a.prof)
-        for (int i = 0; i < 8; ++i)
-            a.prof[wave * 8 + i] = pc[i];
+        for (int i = 0; i < 16; ++i)
+            a.prof[wave * 16 + i] = pc[i];
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FbPlan {
-    int ppl, nbpt, nb, npad;
+    int ppl, nw, ngpt, nb, nbpad, npad, ng;
+    size_t ks, ps, bs;    // byte sizes: key array, per-point float array, bucket word array
     size_t per_elem;      // bytes of one batch element's arrays
     size_t sort_temp;     // rocPRIM temporary storage
     size_t total;
 };
 
+constexpr int FB_NW = 4;            // waves per workgroup (one per SIMD)
+constexpr int FB_NB_MAX = 4096;     // buckets: 32 B of LDS each
+
 bool fb_plan(int b, int n, FbPlan &p)
 {
-    // smallest bucket (64*PPL points) that keeps the table within LDS and 6 buckets per lane
-    const int cap = 6 * FB_W;       // 6144 buckets: 5 words each = 120 KiB of LDS
     p.ppl = 0;
     for (int ppl : {1, 2, 4, 8, 16})
-        if ((long)cap * 64 * ppl >= n) {
+        if ((long)FB_NB_MAX * 64 * ppl >= n) {
             p.ppl = ppl;
             break;
         }
     if (!p.ppl)
         return false;
-    const int bs = 64 * p.ppl;
-    p.nb = (n + bs - 1) / bs;
-    p.npad = p.nb * bs;
-    const int need = (p.nb + FB_W - 1) / FB_W;
-    p.nbpt = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 6));
-    size_t e = 0;
-    e += 4 * align256(sizeof(uint32_t) * (size_t)n);          // keys in/out, vals in/out
-    e += 5 * align256(sizeof(float) * (size_t)p.npad);        // sx sy sz st skey
-    e += align256(8 * sizeof(float));                         // bbox
-    p.per_elem = e;
+    const int bsz = 64 * p.ppl;
+    p.nb = (n + bsz - 1) / bsz;
+    p.nbpad = (p.nb + FB_GS - 1) / FB_GS * FB_GS;
+    p.ng = p.nbpad / FB_GS;
+    p.npad = p.nb * bsz;
+    p.nw = FB_NW;
+    p.ngpt = (p.ng + p.nw * 64 - 1) / (p.nw * 64);          // 1 for ng <= 256
+    p.ks = align256(sizeof(uint32_t) * (size_t)n);
+    p.ps = align256(sizeof(float) * (size_t)p.npad);
+    p.bs = align256(sizeof(uint32_t) * (size_t)p.nbpad);
+    p.per_elem = 4 * p.ks + 5 * p.ps + 8 * p.bs + align256(8 * sizeof(float));
     size_t tb = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                              (uint32_t *)nullptr, (size_t)n, 0, 30, (hipStream_t)0);
+                                    (uint32_t *)nullptr, (size_t)n, 0, 30, (hipStream_t)0);
     p.sort_temp = align256(tb);
     p.total = (size_t)b * p.per_elem + p.sort_temp;
     return true;
 }
 
-template <int NBPT, int PPL>
-int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, size_t per_elem, int nb, int lb)
+template <int PPL, bool PROF>
+int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p, int lb)
 {
-    const size_t lds = (size_t)NBPT * FB_W * 20 + sizeof(FbSlots) + 16;
-    auto kern = fb_main_kernel<NBPT, PPL>;
+    if (p.ngpt != 1)
+        return TPU3_ELIMIT;
+    const size_t lds = fb_lds_bytes(p.nbpad, FB_NW, 1);
+    auto kern = fb_main_kernel<FB_NW, 1, PPL, PROF>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(FB_W), lds, s, a0, per_elem, lb);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(FB_NW * 64), lds, s, a0, p.per_elem, lb);
     return tpu3_launch_status();
 }
 
-template <int PPL>
-int fb_dispatch_nbpt(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p, int lb)
+int fb_run(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx, void *workspace,
+           size_t workspace_bytes, unsigned long long *prof)
 {
-    switch (p.nbpt) {
-    case 1: return fb_launch_main<1, PPL>(s, b, a0, p.per_elem, p.nb, lb);
-    case 2: return fb_launch_main<2, PPL>(s, b, a0, p.per_elem, p.nb, lb);
-    case 4: return fb_launch_main<4, PPL>(s, b, a0, p.per_elem, p.nb, lb);
-    default: return fb_launch_main<6, PPL>(s, b, a0, p.per_elem, p.nb, lb);
+    FbPlan p;
+    if (!fb_plan(b, n, p))
+        return TPU3_ELIMIT;
+    if (!workspace || workspace_bytes < p.total)
+        return TPU3_EINVAL;
+    char *base = (char *)workspace;
+    char *sort_tmp = base + (size_t)b * p.per_elem;
+    const int lb = tpu3_fps_log2_bs(n);
+    FbArgs a0;
+    a0.n = n; a0.m = m; a0.nb = p.nb; a0.nbpad = p.nbpad; a0.npad = p.npad; a0.ng = p.ng;
+    a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = prof;
+    char *q0 = base + 4 * p.ks;
+    a0.sp = (float4 *)q0;
+    a0.skey = (uint32_t *)(q0 + 4 * p.ps);
+    a0.ib = (uint32_t *)(q0 + 5 * p.ps);
+    for (int i = 0; i < b; ++i) {
+        char *e = base + (size_t)i * p.per_elem;
+        uint32_t *k_in = (uint32_t *)e, *k_out = (uint32_t *)(e + p.ks);
+        uint32_t *v_in = (uint32_t *)(e + 2 * p.ks), *v_out = (uint32_t *)(e + 3 * p.ks);
+        float *bbox = (float *)(e + 4 * p.ks + 5 * p.ps + 8 * p.bs);
+        const FbArgs a = fb_elem(a0, p.per_elem, i);
+        hipLaunchKernelGGL(fb_bbox_kernel, dim3(1), dim3(1024), 0, s, n, a.xyz, bbox);
+        hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a.xyz, bbox, k_in, v_in);
+        size_t tb = p.sort_temp;
+        hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 30, s);
+        if (se != hipSuccess)
+            return (int)se;
+        hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256), dim3(256), 0, s, a, v_out, lb);
+        const dim3 gi((p.nbpad + 3) / 4);
+        switch (p.ppl) {
+        case 1: hipLaunchKernelGGL(fb_bucket_init_kernel<1>, gi, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(fb_bucket_init_kernel<2>, gi, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(fb_bucket_init_kernel<4>, gi, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(fb_bucket_init_kernel<8>, gi, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(fb_bucket_init_kernel<16>, gi, dim3(256), 0, s, a); break;
+        }
     }
+    int r;
+    if (prof) {
+        if (p.ppl != 1) return TPU3_EINVAL;
+        r = fb_launch_main<1, true>(s, b, a0, p, lb);
+    } else {
+        switch (p.ppl) {
+        case 1: r = fb_launch_main<1, false>(s, b, a0, p, lb); break;
+        case 2: r = fb_launch_main<2, false>(s, b, a0, p, lb); break;
+        case 4: r = fb_launch_main<4, false>(s, b, a0, p, lb); break;
+        case 8: r = fb_launch_main<8, false>(s, b, a0, p, lb); break;
+        default: r = fb_launch_main<16, false>(s, b, a0, p, lb); break;
+        }
+    }
+    if (r)
+        return r;
+    for (int i = 0; i < b; ++i)
+        hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fb_elem(a0, p.per_elem, i), lb);
+    return tpu3_launch_status();
 }
 
 } // namespace
@@ -414,83 +631,14 @@ size_t tpu3_fps_bucket_workspace_bytes(int b, int n)
 int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
                            void *workspace, size_t workspace_bytes)
 {
-    FbPlan p;
-    if (!fb_plan(b, n, p))
-        return TPU3_ELIMIT;
-    if (!workspace || workspace_bytes < p.total)
-        return TPU3_EINVAL;
-    char *base = (char *)workspace;
-    char *sort_tmp = base + (size_t)b * p.per_elem;
-    const int lb = tpu3_fps_log2_bs(n);
-    const size_t ks = align256(sizeof(uint32_t) * (size_t)n), ps = align256(sizeof(float) * (size_t)p.npad);
-    FbArgs a0;
-    a0.n = n; a0.m = m; a0.nb = p.nb; a0.npad = p.npad;
-    a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = nullptr;
-    char *q0 = base + 4 * ks;
-    a0.sp = (float4 *)q0;
-    a0.skey = (uint32_t *)(q0 + 4 * ps);
-    for (int i = 0; i < b; ++i) {
-        char *e = base + (size_t)i * p.per_elem;
-        uint32_t *k_in = (uint32_t *)e, *k_out = (uint32_t *)(e + ks);
-        uint32_t *v_in = (uint32_t *)(e + 2 * ks), *v_out = (uint32_t *)(e + 3 * ks);
-        float *bbox = (float *)(e + 4 * ks + 5 * ps);
-        const FbArgs a = fb_elem(a0, p.per_elem, i);
-        hipLaunchKernelGGL(fb_bbox_kernel, dim3(1), dim3(1024), 0, s, n, a.xyz, bbox);
-        hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a.xyz, bbox, k_in, v_in);
-        size_t tb = p.sort_temp;
-        hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 30, s);
-        if (se != hipSuccess)
-            return (int)se;
-        hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256), dim3(256), 0, s, a, v_out, lb);
-    }
-    int r;
-    switch (p.ppl) {
-    case 1: r = fb_dispatch_nbpt<1>(s, b, a0, p, lb); break;
-    case 2: r = fb_dispatch_nbpt<2>(s, b, a0, p, lb); break;
-    case 4: r = fb_dispatch_nbpt<4>(s, b, a0, p, lb); break;
-    case 8: r = fb_dispatch_nbpt<8>(s, b, a0, p, lb); break;
-    default: r = fb_dispatch_nbpt<16>(s, b, a0, p, lb); break;
-    }
-    if (r)
-        return r;
-    for (int i = 0; i < b; ++i)
-        hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fb_elem(a0, p.per_elem, i), lb);
-    return tpu3_launch_status();
+    return fb_run(s, b, n, m, xyz, temp, idx, workspace, workspace_bytes, nullptr);
 }
 
-// Development probe (not part of include/tpu3.h): runs the <4,1> kernel with per-phase cycle
-// counters; prof = 16 x 8 u64: [prune, rescan, argmax, barrier wait, broadcast, buckets, pairs, -].
+// Development probe (not part of include/tpu3.h): the same kernel with per-phase cycle counters;
+// prof = NW x 8 u64: [prune+rescan+refresh, argmax, barrier wait, broadcast, -, buckets, group batches, -].
 extern "C" int tpu3_debug_fps_bucket_profile(void *stream, int n, int m, const float *xyz, float *temp,
                                              int32_t *idx, void *workspace, size_t workspace_bytes,
                                              unsigned long long *prof)
 {
-    hipStream_t s = (hipStream_t)stream;
-    FbPlan p;
-    if (!fb_plan(1, n, p) || p.ppl != 1 || p.nbpt != 4 || workspace_bytes < p.total)
-        return TPU3_EINVAL;
-    char *base = (char *)workspace;
-    char *sort_tmp = base + p.per_elem;
-    const int lb = tpu3_fps_log2_bs(n);
-    const size_t ks = align256(sizeof(uint32_t) * (size_t)n), ps = align256(sizeof(float) * (size_t)p.npad);
-    FbArgs a0;
-    a0.n = n; a0.m = m; a0.nb = p.nb; a0.npad = p.npad;
-    a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = prof;
-    char *q0 = base + 4 * ks;
-    a0.sp = (float4 *)q0;
-    a0.skey = (uint32_t *)(q0 + 4 * ps);
-    uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + ks);
-    uint32_t *v_in = (uint32_t *)(base + 2 * ks), *v_out = (uint32_t *)(base + 3 * ks);
-    float *bbox = (float *)(base + 4 * ks + 5 * ps);
-    hipLaunchKernelGGL(fb_bbox_kernel, dim3(1), dim3(1024), 0, s, n, xyz, bbox);
-    hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, xyz, bbox, k_in, v_in);
-    size_t tb = p.sort_temp;
-    hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 30, s);
-    if (se != hipSuccess) return (int)se;
-    hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256), dim3(256), 0, s, a0, v_out, lb);
-    const size_t lds = (size_t)4 * FB_W * 20 + sizeof(FbSlots) + 16;
-    auto kern = fb_main_kernel<4, 1, true>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(FB_W), lds, s, a0, p.per_elem, lb);
-    return tpu3_launch_status();
+    return fb_run((hipStream_t)stream, 1, n, m, xyz, temp, idx, workspace, workspace_bytes, prof);
 }
