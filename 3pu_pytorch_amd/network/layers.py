@@ -64,10 +64,27 @@ class DenseEdgeConv(nn.Module):
         center = x.unsqueeze(2).expand_as(knn_point)
         return torch.cat([center, knn_point - center], dim=-1), idx
 
-    def forward_cl(self, x, idx=None, layout=None):
-        """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k)."""
+    def fused_ok(self, x):
+        """The hand-written MFMA kernel covers the configuration every Level uses."""
+        return (hasattr(operations.BACKEND, "dense_edge_conv") and not torch.is_grad_enabled()
+                and x.is_cuda and x.dtype == torch.float32 and self.in_channels == 24
+                and self.growth_rate == 12 and self.n == 3 and self.k % 16 == 0 and self.k <= 64)
+
+    def forward_cl(self, x, idx=None, layout=None, out=None):
+        """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k).
+        `out`: optional (B,N,C + n*growth_rate) view (unit channel stride) that receives y -- the
+        Level passes a slice of its concatenated feature buffer so that no copy is needed."""
         B, N, C = x.shape
         g, n, k = self.growth_rate, self.n, self.k
+        if idx is None and self.fused_ok(x):
+            # kNN graph + gather + 3 dense layers + max in two launches, no (B,N,k,C) tensors
+            x = x.contiguous()
+            full_idx, _, _ = operations.knn_query(k + 1, x, x, unique=True, layout=layout,
+                                                  want_dist=False, want_grouped=False)
+            if out is None:
+                out = x.new_empty((B, N, C + n * g))
+            operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out)
+            return out, full_idx[:, :, 1:]
         edge, idx = self.get_local_graph_cl(x, k, idx, layout)
         if torch.is_grad_enabled():
             # training: autograd-friendly concatenations, exactly the reference's dataflow (:53-61)
@@ -91,6 +108,9 @@ class DenseEdgeConv(nn.Module):
                 lo -= g
                 y[..., lo:lo + g] = h
         y, _ = torch.max(y, dim=2)
+        if out is not None:
+            out.copy_(y)
+            y = out
         return y, idx
 
     def forward(self, x, idx=None):

@@ -112,6 +112,27 @@ class HipBackend(object):
         grad = torch.zeros((b, c, n), dtype=grad_out.dtype, device=grad_out.device)
         return sampling.gather_backward(b, c, n, npoint, grad_out, idx, grad)
 
+    def dense_edge_conv(self, x, idx, idx_off, k, mlps, out):
+        """Fused DenseEdgeConv (inference): x (P,N,24) contiguous, idx (P,N,idx_stride) int64/int32,
+        the k neighbours start at column idx_off; mlps = the block's three nn.Conv2d; `out` is a
+        (P,N,>=60) view with unit channel stride whose channels [0,60) receive y."""
+        L.require_device(x, "x")
+        L.require_dtype(x, torch.float32, "x")
+        L.require_device(idx, "idx")
+        P, N, _ = x.shape
+        if out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
+            raise RuntimeError("dense_edge_conv: out must be a channel-slice of a contiguous (P,N,C) tensor")
+        w = []
+        for conv in mlps:
+            w.append(conv.weight.detach().reshape(conv.weight.size(0), -1).contiguous())
+            w.append(conv.bias.detach().contiguous())
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_dense_edge_conv_f32(
+                L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
+                L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
+                L.ptr(out), out.stride(1)), "tpu3_dense_edge_conv_f32")
+        return out
+
     def normalize(self, pc, n_arr=None):
         """pc (B,3,N) f32 contiguous -> (out (B,3,N), centroid (B,3,1), radius (B,1,1))."""
         L.require_device(pc, "pc")

@@ -267,15 +267,28 @@ class Level(torch.nn.Module):
         B, N, _ = xyz_normalized.shape
         graph_layout = None if owner is None else dict(grp=owner, groups=groups)
 
-        x = self.layer0.forward_cl(xyz_normalized)
-        y, _ = self.layer1.forward_cl(x, layout=graph_layout)
-        x = torch.cat([y, x], dim=-1)
-        y, _ = self.layer2.forward_cl(self.layer2_prep.forward_cl(x), layout=graph_layout)
-        x = torch.cat([y, x], dim=-1)
-        y, _ = self.layer3.forward_cl(self.layer3_prep.forward_cl(x), layout=graph_layout)
-        x = torch.cat([y, x], dim=-1)
-        y, _ = self.layer4.forward_cl(self.layer4_prep.forward_cl(x), layout=graph_layout)
-        x = torch.cat([y, x], dim=-1)
+        # One (B,N,264) buffer holds the level's dense concatenation [y4 | y3 | y2 | y1 | x0]
+        # (reference: four torch.cat, :293-311); every block writes its slice in place and the next
+        # prep convolution reads the tail slice, so nothing is copied.
+        blocks = ((self.layer1, None), (self.layer2, self.layer2_prep), (self.layer3, self.layer3_prep),
+                  (self.layer4, self.layer4_prep))
+        x0 = self.layer0.forward_cl(xyz_normalized)
+        widths = [blk.in_channels + blk.n * blk.growth_rate for blk, _ in blocks]
+        total = x0.size(-1) + sum(widths)
+        if torch.is_grad_enabled():
+            x = x0
+            for blk, prep in blocks:
+                y, _ = blk.forward_cl(x if prep is None else prep.forward_cl(x), layout=graph_layout)
+                x = torch.cat([y, x], dim=-1)
+        else:
+            feat = x0.new_empty((B, N, total))
+            lo = total - x0.size(-1)
+            feat[..., lo:] = x0
+            for (blk, prep), wdt in zip(blocks, widths):
+                inp = x0 if prep is None else prep.forward_cl(feat[..., lo:])
+                blk.forward_cl(inp, layout=graph_layout, out=feat[..., lo - wdt:lo])
+                lo -= wdt
+            x = feat
 
         # interlevel skip connection (:317-347)
         if previous is not None and self.fm_knn > 0:

@@ -147,6 +147,21 @@ int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c
                                 const float *query, const float *points,
                                 const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws);
 
+/* Fused DenseEdgeConv block, inference (network/layers.py:44-64 for in_channels 24, growth 12,
+ * 3 dense layers -- the configuration of every Level, network/upsampler.py:210-223):
+ *   y_i = max_j [h2, h1, h0, x_i],  h0 = relu(W0 [x_i, x_j - x_i] + b0),  h1 = relu(W1 [h0, x_i] + b1),
+ *   h2 = W2 [h1, h0, x_i] + b2,  j over the k neighbours idx[p, i, idx_off .. idx_off + k).
+ *   x   (patches, n, 24) f32 channel-last;  idx (patches, n, idx_stride) i32 / i64, entries in [0, n)
+ *   w0 (12,48) b0 (12)  w1 (12,36) b1 (12)  w2 (12,48) b2 (12): the nn.Conv2d weights, row-major
+ *   out (patches, n, out_stride) f32: channels [0,60) of every row are written (out_stride >= 60,
+ *       multiple of 4, base 16-byte aligned) -- lets the caller place y inside the level's
+ *       concatenated feature buffer without a copy.  k must be a multiple of 16, at most 64.
+ * fp32 MFMA (exact fp32 fma chains); the summation order differs from a BLAS GEMM. */
+int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                             const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                             const float *w0, const float *b0, const float *w1, const float *b1,
+                             const float *w2, const float *b2, float *out, int out_stride);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
