@@ -23,6 +23,7 @@ namespace {
 
 struct KnnArgs {
     int m, n, c, k;
+    int b, nblk_x;           // batch elements; query blocks per batch element (strided kernels)
     const float *query;      // (b,m,c)
     const float *points;     // (b,n,c)
     const int32_t *n_arr;    // (bp) live points per point set, or null
@@ -30,7 +31,9 @@ struct KnnArgs {
     const int32_t *pts_of;   // (b) point set of each query set, or null (identity)
     const int32_t *grp;      // (b) unique-max group, or null (one group)
     const uint8_t *dup;      // (bp,n) or null
-    const uint32_t *uws;     // [0] any-dup, [4+g] mono(max D) of group g
+    uint32_t *uws;           // [0] any-dup, [1] optimistic pass failed, [4+g] mono(max D) of group g
+    int mode;                // 0: D += max(D)*dup (reference arithmetic); 1: optimistic (see below)
+    int gate;                // run only if uws[gate] != 0 (0 = always)
     void *idx;               // (b,m,k) i32 / i64
     int idx64;
     float *dist;             // (b,m,k) or null
@@ -109,26 +112,44 @@ __device__ __forceinline__ void load_query(float (&q)[C], float &rq, const float
         rq = __builtin_fmaf(q[i], q[i], rq);
 }
 
-constexpr int tile_rows(int C) { return C == 3 ? 1024 : (C <= 8 ? 512 : (C <= 32 ? 256 : 128)); }
+// C = 24: 320 rows so that a whole 312-point patch is one tile (36 KiB of LDS)
+constexpr int tile_rows(int C) { return C == 3 ? 1024 : (C <= 8 ? 512 : (C == 24 ? 320 : (C <= 32 ? 256 : 128))); }
 
 // ---------------------------------------------------------------------------------------------
 // small k: lane-per-query register insertion
 // ---------------------------------------------------------------------------------------------
 template <int C, int KMAX>
-__global__ __launch_bounds__(512) void knn_insert_kernel(KnnArgs a)
+__global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(KnnArgs a)
 {
     constexpr int TILE = tile_rows(C);
     constexpr int F4 = Row<C>::F4;
     __shared__ float4 tile[TILE * F4];
     __shared__ float addend[C == 3 ? TILE : 1];
-    const int b = blockIdx.y;
+    if (a.gate && a.uws[a.gate < 0 ? 0 : a.gate] == 0)
+        return;
+    // work item = (batch element, block of queries); gated launches use a small grid and stride over
+    // the items so that the (usual) early exit does not pay for dispatching tens of thousands of
+    // workgroups (measured: 0.8 ms per empty 15 360-block launch)
+    const int total = a.nblk_x * a.b;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int b = w / a.nblk_x;
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int n = a.n_arr ? a.n_arr[pb] : a.n;
     const int m = a.m_arr ? a.m_arr[b] : a.m;
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = (w - b * a.nblk_x) * blockDim.x + threadIdx.x;
     const bool live = qi < m;
     const bool use_dup = a.dup != nullptr && a.uws[0] != 0;
-    const float dmax = use_dup ? tpu3_unmono(a.uws[4 + (a.grp ? a.grp[b] : 0)]) : 0.f;
+    // Optimistic mode: duplicate-flagged candidates are skipped instead of penalised.  With the
+    // reference's D' = D + max(D)*dup every duplicate ranks behind every first occurrence unless
+    // fewer than k first occurrences exist (or rounding puts a duplicate in front of the largest
+    // distances); each query VERIFIES that its k-th distance is below a lower bound of every
+    // duplicate's D' (fl(min dup D + max D seen) <= fl(D + true max), fp32 addition is monotone).
+    // If any query cannot, uws[1] is raised and the caller's gated launches redo the call with the
+    // reference arithmetic -- results are exact either way, the max(D) pass is skipped when it
+    // cannot matter (it is a full extra distance pass over up to 12 480 candidates per query).
+    const bool optimistic = use_dup && a.mode == 1;
+    const float dmax = (use_dup && !optimistic) ? tpu3_unmono(a.uws[4 + (a.grp ? a.grp[b] : 0)]) : 0.f;
+    float dupmin = __builtin_inff(), dqmax = -__builtin_inff();
 
     float q[C], rq;
     load_query<C>(q, rq, a.query + ((size_t)b * a.m + (live ? qi : 0)) * a.c, a.c, live);
@@ -147,7 +168,8 @@ __global__ __launch_bounds__(512) void knn_insert_kernel(KnnArgs a)
         const int len = min(TILE, n - j0);
         __syncthreads();
         for (int i = threadIdx.x; i < len; i += blockDim.x) {
-            const float add = use_dup ? dmax * (float)DUP[j0 + i] : 0.f;
+            // optimistic: the slot carries the dup flag itself; otherwise the addend max(D)*dup
+            const float add = use_dup ? (optimistic ? (float)DUP[j0 + i] : dmax * (float)DUP[j0 + i]) : 0.f;
             stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, add);
             if (C == 3)
                 addend[i] = add;
@@ -156,8 +178,18 @@ __global__ __launch_bounds__(512) void knn_insert_kernel(KnnArgs a)
         if (live) {
             for (int j = 0; j < len; ++j) {
                 float d = row_dist<C>(tile + j * F4, q, rq);
-                if (use_dup)
-                    d = d + (C == 3 ? addend[j] : tile[j * F4 + C / 4].y);
+                if (use_dup) {
+                    const float ad = C == 3 ? addend[j] : tile[j * F4 + C / 4].y;
+                    if (optimistic) {
+                        dqmax = fmaxf(dqmax, d);
+                        if (ad != 0.f) {
+                            dupmin = fminf(dupmin, d);
+                            continue;
+                        }
+                    } else {
+                        d = d + ad;
+                    }
+                }
                 if (d < bd[KMAX - 1]) {
                     // sorted insertion; an equal distance goes behind the (lower-index) holder
                     const int id = j0 + j;
@@ -178,12 +210,106 @@ __global__ __launch_bounds__(512) void knn_insert_kernel(KnnArgs a)
     }
     if (live) {
         const size_t o = ((size_t)b * a.m + qi) * a.k;
+        float tk = __builtin_inff();
 #pragma unroll
         for (int i = 0; i < KMAX; ++i)
             if (i < a.k) {
                 store_idx(a, o + i, bi[i]);
                 if (a.dist)
                     a.dist[o + i] = bd[i];
+                if (i == a.k - 1)
+                    tk = bd[i];
+            }
+        if (optimistic && dupmin < __builtin_inff() && !(tk < dupmin + dqmax))
+            a.uws[1] = 1u;      // cannot prove the duplicates stay out of the top k: redo exactly
+    }
+    __syncthreads();
+    }   // work items
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN *graph* for the fused DenseEdgeConv: the k nearest as a SET, nearest first
+// ---------------------------------------------------------------------------------------------
+// DenseEdgeConv drops the nearest neighbour (itself) and max-pools over the rest
+// (network/layers.py:33-35,63), so the order of the other k-1 is irrelevant.  That allows a much
+// cheaper exact selection than a sorted insertion with indices (~190 VALU ops per candidate):
+//   pass 1  keeps only the k smallest DISTANCES, sorted, with one v_med3_f32 per slot
+//           (new[i] = med3(old[i-1], d, old[i]); all slots independent);
+//   pass 2  recomputes the distances (bit-identical) and collects the indices with
+//           d < T_k, plus the first q candidates (lowest indices) with d == T_k, where q is how often
+//           T_k occurs in the sorted list -- exactly the top-k under (distance, index) order.
+// Slot 0 receives the nearest (lowest index among the minima), slots 1..k-1 the others in index
+// order.  Runs only when the point sets hold no duplicated rows (uws[0] == 0); otherwise the exact
+// sorted kernels above run instead (gated the other way).
+template <int C, int K>
+__global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
+{
+    constexpr int TILE = tile_rows(C);
+    constexpr int F4 = Row<C>::F4;
+    __shared__ float4 tile[TILE * F4];
+    if (a.uws && a.uws[0] != 0)
+        return;
+    const int b = blockIdx.y;
+    const int pb = a.pts_of ? a.pts_of[b] : b;
+    const int n = a.n_arr ? a.n_arr[pb] : a.n;
+    const int m = a.m_arr ? a.m_arr[b] : a.m;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = qi < m;
+    float q[C], rq;
+    load_query<C>(q, rq, a.query + ((size_t)b * a.m + (live ? qi : 0)) * a.c, a.c, live);
+    const float *P = a.points + (size_t)pb * a.n * a.c;
+
+    float ds[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        ds[i] = __builtin_inff();
+    // ---- pass 1: the k smallest distances ---------------------------------------------------------
+    for (int j0 = 0; j0 < n; j0 += TILE) {
+        const int len = min(TILE, n - j0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += blockDim.x)
+            stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
+        __syncthreads();
+        if (live)
+            for (int j = 0; j < len; ++j) {
+                const float d = row_dist<C>(tile + j * F4, q, rq);
+#pragma unroll
+                for (int i = K - 1; i > 0; --i)
+                    ds[i] = __builtin_amdgcn_fmed3f(ds[i - 1], d, ds[i]);
+                ds[0] = fminf(ds[0], d);
+            }
+    }
+    const float t1 = ds[0], tk = ds[K - 1];
+    int quota = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        quota += ds[i] == tk ? 1 : 0;
+    // ---- pass 2: the indices ---------------------------------------------------------------------------
+    int32_t *out = (int32_t *)a.idx + ((size_t)b * a.m + (live ? qi : 0)) * K;
+    int cnt = 1, used = 0;
+    bool found = false;
+    for (int j0 = 0; j0 < n; j0 += TILE) {
+        const int len = min(TILE, n - j0);
+        if (n > TILE) {         // the tile still holds the whole set when it fits (the 312-point case)
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += blockDim.x)
+                stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
+            __syncthreads();
+        }
+        if (live)
+            for (int j = 0; j < len; ++j) {
+                const float d = row_dist<C>(tile + j * F4, q, rq);
+                const bool at = d == tk;
+                const bool sel = d < tk || (at && used < quota);
+                if (sel) {
+                    used += at ? 1 : 0;
+                    if (!found && d == t1) {
+                        out[0] = j0 + j;
+                        found = true;
+                    } else if (cnt < K) {
+                        out[cnt++] = j0 + j;
+                    }
+                }
             }
     }
 }
@@ -319,17 +445,19 @@ __global__ __launch_bounds__(256) void knn_dup_kernel(int n_pad, int c, const fl
 template <int C>
 __global__ __launch_bounds__(512) void knn_dmax_kernel(KnnArgs a, uint32_t *uws)
 {
-    if (uws[0] == 0)
+    if (uws[a.gate] == 0)
         return;
     constexpr int TILE = tile_rows(C);
     constexpr int F4 = Row<C>::F4;
     __shared__ float4 tile[TILE * F4];
     __shared__ uint32_t red[16];
-    const int b = blockIdx.y;
+    const int total = a.nblk_x * a.b;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int b = w / a.nblk_x;
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int n = a.n_arr ? a.n_arr[pb] : a.n;
     const int m = a.m_arr ? a.m_arr[b] : a.m;
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = (w - b * a.nblk_x) * blockDim.x + threadIdx.x;
     const bool live = qi < m;
     float q[C], rq;
     load_query<C>(q, rq, a.query + ((size_t)b * a.m + (live ? qi : 0)) * a.c, a.c, live);
@@ -355,12 +483,14 @@ __global__ __launch_bounds__(512) void knn_dmax_kernel(KnnArgs a, uint32_t *uws)
             r = max(r, red[w]);
         atomicMax(uws + 4 + (a.grp ? a.grp[b] : 0), r);
     }
+    __syncthreads();
+    }   // work items
 }
 
 __global__ __launch_bounds__(256) void knn_dmax_generic_kernel(KnnArgs a, uint32_t *uws)
 {
     // any channel count: one lane per query, points read straight from global memory (L2)
-    if (uws[0] == 0)
+    if (uws[a.gate] == 0)
         return;
     __shared__ uint32_t red[4];
     const int b = blockIdx.y;
@@ -393,6 +523,89 @@ __global__ __launch_bounds__(256) void knn_dmax_generic_kernel(KnnArgs a, uint32
         atomicMax(uws + 4 + (a.grp ? a.grp[b] : 0), max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
+// ---- first-occurrence mask in O(n): open-addressing table of equivalence-class representatives -----
+// Phase 1: every row probes from hash(row); an empty slot is claimed with atomicCAS, a slot whose
+// representative equals the row is lowered to the smaller index with atomicMin.  Rows of one class
+// share their hash, hence their probe sequence, hence their slot.  Phase 2 (next launch): the class
+// slot holds the lowest index of the class; every other member is a duplicate.  Deterministic.
+__device__ __forceinline__ bool knn_rows_equal(const float *__restrict__ a, const float *__restrict__ b, int c)
+{
+    for (int ch = 0; ch < c; ++ch)
+        if (!(a[ch] == b[ch]))
+            return false;
+    return true;
+}
+__device__ __forceinline__ uint32_t knn_row_hash(const float *__restrict__ r, int c)
+{
+    uint32_t h = 0x9E3779B9u;
+    for (int ch = 0; ch < c; ++ch) {
+        uint32_t u = __float_as_uint(r[ch] + 0.0f);       // -0.0 == +0.0 must hash alike
+        h ^= u + 0x9E3779B9u + (h << 6) + (h >> 2);
+        h *= 0x85EBCA6Bu;
+    }
+    return h ^ (h >> 15);
+}
+__global__ __launch_bounds__(256) void knn_dup_hash_insert_kernel(int n_pad, int c, int tsize,
+                                                                  const float *__restrict__ points,
+                                                                  const int32_t *__restrict__ n_arr,
+                                                                  uint32_t *__restrict__ table)
+{
+    const int b = blockIdx.y;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *P = points + (size_t)b * n_pad * c;
+    uint32_t *T = table + (size_t)b * tsize;
+    const float *row = P + (size_t)i * c;
+    uint32_t s = knn_row_hash(row, c) & (uint32_t)(tsize - 1);
+    for (int probes = 0; probes < tsize; ++probes) {
+        uint32_t o = __hip_atomic_load(T + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o == 0xFFFFFFFFu) {
+            o = atomicCAS(T + s, 0xFFFFFFFFu, (uint32_t)i);
+            if (o == 0xFFFFFFFFu)
+                return;
+        }
+        if (knn_rows_equal(P + (size_t)o * c, row, c)) {
+            atomicMin(T + s, (uint32_t)i);
+            return;
+        }
+        s = (s + 1) & (uint32_t)(tsize - 1);
+    }
+}
+__global__ __launch_bounds__(256) void knn_dup_hash_lookup_kernel(int n_pad, int c, int tsize,
+                                                                  const float *__restrict__ points,
+                                                                  const int32_t *__restrict__ n_arr,
+                                                                  const uint32_t *__restrict__ table,
+                                                                  uint8_t *__restrict__ dup, uint32_t *__restrict__ uws)
+{
+    const int b = blockIdx.y;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *P = points + (size_t)b * n_pad * c;
+    const uint32_t *T = table + (size_t)b * tsize;
+    const float *row = P + (size_t)i * c;
+    uint32_t s = knn_row_hash(row, c) & (uint32_t)(tsize - 1);
+    uint8_t d = 0;
+    for (int probes = 0; probes < tsize; ++probes) {
+        const uint32_t o = T[s];
+        if (o == 0xFFFFFFFFu)
+            break;                                  // rows with a NaN never match anything, incl. themselves
+        if (o == (uint32_t)i)
+            break;
+        if (knn_rows_equal(P + (size_t)o * c, row, c)) {
+            d = 1;
+            break;
+        }
+        s = (s + 1) & (uint32_t)(tsize - 1);
+    }
+    dup[(size_t)b * n_pad + i] = d;
+    if (d)
+        uws[0] = 1u;
+}
+
 // grouped[b,q,t,:] = points[b, idx[b,q,t], :]
 __global__ __launch_bounds__(256) void knn_group_kernel(KnnArgs a, float *__restrict__ grouped, long total)
 {
@@ -409,14 +622,21 @@ __global__ __launch_bounds__(256) void knn_group_kernel(KnnArgs a, float *__rest
     }
 }
 
+constexpr int KNN_GATED_GRID = 1024;
+
 template <int C, int KMAX>
-int launch_insert(hipStream_t s, int b, const KnnArgs &a)
+int launch_insert(hipStream_t s, int b, const KnnArgs &a0)
 {
+    KnnArgs a = a0;
     int threads = ((a.m + 63) / 64) * 64;
     if (threads > 512)
         threads = 256;
-    const dim3 g((a.m + threads - 1) / threads, b);
-    hipLaunchKernelGGL((knn_insert_kernel<C, KMAX>), g, dim3(threads), 0, s, a);
+    a.b = b;
+    a.nblk_x = (a.m + threads - 1) / threads;
+    long grid = (long)a.nblk_x * b;
+    if (a.gate && grid > KNN_GATED_GRID)
+        grid = KNN_GATED_GRID;
+    hipLaunchKernelGGL((knn_insert_kernel<C, KMAX>), dim3((unsigned)grid), dim3(threads), 0, s, a);
     return tpu3_launch_status();
 }
 
@@ -470,11 +690,55 @@ bool bad_dims(int b, int m, int n, int c, int k)
     return b < 0 || m < 0 || n < 0 || c <= 0 || k < 0;
 }
 
+constexpr int KNN_DUP_HASH_MIN_N = 1024;    // below this the quadratic kernel is faster and needs no table
+
+int knn_dup_table_size(int n)
+{
+    int t = 64;
+    while (t < 2 * n)
+        t <<= 1;
+    return t;
+}
+
+int launch_dmax(hipStream_t s, int b, const KnnArgs &a0, uint32_t *uws)
+{
+    KnnArgs a = a0;
+    int threads = ((a.m + 63) / 64) * 64;
+    if (threads > 512) threads = 256;
+    a.b = b;
+    a.nblk_x = (a.m + threads - 1) / threads;
+    long grid = (long)a.nblk_x * b;
+    if (grid > KNN_GATED_GRID)
+        grid = KNN_GATED_GRID;
+    const dim3 g((unsigned)grid);
+    const int c = a.c;
+    if (c == 3)
+        hipLaunchKernelGGL(knn_dmax_kernel<3>, g, dim3(threads), 0, s, a, uws);
+    else if (c <= 8)
+        hipLaunchKernelGGL(knn_dmax_kernel<8>, g, dim3(threads), 0, s, a, uws);
+    else if (c <= 16)
+        hipLaunchKernelGGL(knn_dmax_kernel<16>, g, dim3(threads), 0, s, a, uws);
+    else if (c <= 24)
+        hipLaunchKernelGGL(knn_dmax_kernel<24>, g, dim3(threads), 0, s, a, uws);
+    else if (c <= 32)
+        hipLaunchKernelGGL(knn_dmax_kernel<32>, g, dim3(threads), 0, s, a, uws);
+    else
+        hipLaunchKernelGGL(knn_dmax_generic_kernel, dim3((a.m + 255) / 256, b), dim3(256), 0, s, a, uws);
+    return tpu3_launch_status();
+}
+
 } // namespace
+
+extern "C" size_t tpu3_knn_unique_workspace_bytes(int bp, int n)
+{
+    if (bp <= 0 || n < KNN_DUP_HASH_MIN_N)
+        return 0;
+    return (size_t)bp * (size_t)knn_dup_table_size(n) * sizeof(uint32_t);
+}
 
 extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k,
                             const float *query, const float *points, const tpu3_knn_layout *layout,
-                            const uint8_t *dup, const uint32_t *uws, void *idx, int idx_elem_size,
+                            const uint8_t *dup, uint32_t *uws, void *idx, int idx_elem_size,
                             float *dist, float *grouped)
 {
     if (bad_dims(b, m, n, c, k)) return TPU3_EINVAL;
@@ -486,13 +750,34 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
     if (b > 65535) return TPU3_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
     const tpu3_knn_layout L = layout ? *layout : tpu3_knn_layout{nullptr, nullptr, nullptr, nullptr, b, 1};
-    KnnArgs a{m, n, c, k, query, points, L.n_arr, L.m_arr, L.pts_of, L.grp, dup, uws, idx,
+    KnnArgs a{m, n, c, k, b, 1, query, points, L.n_arr, L.m_arr, L.pts_of, L.grp, dup, uws, 0, 0, idx,
               idx_elem_size == 8, dist};
     int r = -100;
-    if (k <= 64)
-        r = dispatch_insert(s, b, a);
-    if (r == -100)
+    if (k <= 64 && c <= 32) {
+        if (dup) {
+            // optimistic pass (duplicates skipped + verified), then -- only if some query could not
+            // verify -- max(D) and the reference arithmetic; both follow-ups early-exit on uws[1] == 0
+            a.mode = 1;
+            r = dispatch_insert(s, b, a);
+            if (r) return r;
+            KnnArgs d = a;
+            d.mode = 0; d.gate = 1; d.dup = nullptr;
+            r = launch_dmax(s, b, d, uws);
+            if (r) return r;
+            a.mode = 0; a.gate = 1;
+            r = dispatch_insert(s, b, a);
+        } else {
+            r = dispatch_insert(s, b, a);
+        }
+    } else {
+        if (dup) {      // selection by sorting: max(D) whenever anything is duplicated
+            KnnArgs d = a;
+            d.gate = 0; d.dup = nullptr;
+            r = launch_dmax(s, b, d, uws);      // gate word 0 = the any-dup flag itself
+            if (r) return r;
+        }
         r = dispatch_sort(s, b, a);
+    }
     if (r) return r;
     if (grouped) {
         const long total = (long)b * m * k * c;
@@ -504,10 +789,55 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
     return r;
 }
 
+// kNN graph for the fused DenseEdgeConv (see knn_graph_kernel): idx (b,m,k) i32, slot 0 = nearest,
+// slots 1..k-1 = the other members of the exact top-k set in index order.  unique=True semantics:
+// dup/uws from tpu3_knn_unique_prepare_f32; when any row is duplicated the exact sorted kernels run
+// instead (device-side gate, no host synchronisation).  Supported: c <= 32, k in {17, 33}; other
+// sizes return TPU3_ELIMIT (callers then use tpu3_knn_f32).
+extern "C" int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
+                                  const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
+                                  uint32_t *uws, int32_t *idx)
+{
+    if (bad_dims(b, m, n, c, k)) return TPU3_EINVAL;
+    if ((dup == nullptr) != (uws == nullptr)) return TPU3_EINVAL;
+    if (c > 32 || (k != 17 && k != 33)) return TPU3_ELIMIT;
+    if (b == 0 || m == 0) return TPU3_OK;
+    if (k > n) return TPU3_EINVAL;
+    if (!query || !points || !idx) return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    const tpu3_knn_layout L = layout ? *layout : tpu3_knn_layout{nullptr, nullptr, nullptr, nullptr, b, 1};
+    KnnArgs a{m, n, c, k, b, 1, query, points, L.n_arr, L.m_arr, L.pts_of, L.grp, dup, uws, 0, 0, idx, 0, nullptr};
+    int threads = ((m + 63) / 64) * 64;
+    if (threads > 512) threads = 256;
+    const dim3 g((m + threads - 1) / threads, b);
+#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+    if (k == 33) {
+        if (c == 3) KG(3, 33); else if (c <= 8) KG(8, 33); else if (c <= 16) KG(16, 33);
+        else if (c <= 24) KG(24, 33); else KG(32, 33);
+    } else {
+        if (c == 3) KG(3, 17); else if (c <= 8) KG(8, 17); else if (c <= 16) KG(16, 17);
+        else if (c <= 24) KG(24, 17); else KG(32, 17);
+    }
+#undef KG
+    int r = tpu3_launch_status();
+    if (r || !dup) return r;
+    // duplicated rows present (uws[0] != 0): exact path, everything gated on the any-dup flag
+    KnnArgs d = a;
+    d.gate = 0; d.dup = nullptr;
+    r = launch_dmax(s, b, d, uws);                  // runs only if uws[0] != 0
+    if (r) return r;
+    a.mode = 0; a.gate = -1;                        // gate -1: run only if uws[0] != 0
+    a.idx64 = 0;
+    return dispatch_insert(s, b, a);
+}
+
 extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c,
                                            const float *query, const float *points,
-                                           const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws)
+                                           const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws,
+                                           void *workspace, size_t workspace_bytes)
 {
+    (void)query;
     if (bad_dims(b, m, n, c, 0)) return TPU3_EINVAL;
     if (!dup || !uws) return TPU3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -520,27 +850,29 @@ extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, i
     if (b == 0 || bp == 0 || n == 0) return TPU3_OK;
     if (!points) return TPU3_EINVAL;
     if (b > 65535 || bp > 65535) return TPU3_ELIMIT;
-    hipLaunchKernelGGL(knn_dup_kernel, dim3((n + 255) / 256, bp), dim3(256), 0, s, n, c, points, L.n_arr,
-                       dup, uws);
+    const size_t need = tpu3_knn_unique_workspace_bytes(bp, n);
+    if (need == 0) {
+        hipLaunchKernelGGL(knn_dup_kernel, dim3((n + 255) / 256, bp), dim3(256), 0, s, n, c, points, L.n_arr,
+                           dup, uws);
+        return tpu3_launch_status();
+    }
+    void *ws = workspace;
+    const bool own = !(workspace && workspace_bytes >= need);
+    if (own) {
+        e = hipMallocAsync(&ws, need, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int tsize = knn_dup_table_size(n);
+    e = hipMemsetAsync(ws, 0xFF, need, s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 g((n + 255) / 256, bp);
+    hipLaunchKernelGGL(knn_dup_hash_insert_kernel, g, dim3(256), 0, s, n, c, tsize, points, L.n_arr, (uint32_t *)ws);
+    hipLaunchKernelGGL(knn_dup_hash_lookup_kernel, g, dim3(256), 0, s, n, c, tsize, points, L.n_arr,
+                       (const uint32_t *)ws, dup, uws);
     int r = tpu3_launch_status();
-    if (r || m == 0) return r;
-    if (!query) return TPU3_EINVAL;
-    KnnArgs a{m, n, c, 0, query, points, L.n_arr, L.m_arr, L.pts_of, L.grp, nullptr, nullptr, nullptr,
-              0, nullptr};
-    int threads = ((m + 63) / 64) * 64;
-    if (threads > 512) threads = 256;
-    const dim3 g((m + threads - 1) / threads, b);
-    if (c == 3)
-        hipLaunchKernelGGL(knn_dmax_kernel<3>, g, dim3(threads), 0, s, a, uws);
-    else if (c <= 8)
-        hipLaunchKernelGGL(knn_dmax_kernel<8>, g, dim3(threads), 0, s, a, uws);
-    else if (c <= 16)
-        hipLaunchKernelGGL(knn_dmax_kernel<16>, g, dim3(threads), 0, s, a, uws);
-    else if (c <= 24)
-        hipLaunchKernelGGL(knn_dmax_kernel<24>, g, dim3(threads), 0, s, a, uws);
-    else if (c <= 32)
-        hipLaunchKernelGGL(knn_dmax_kernel<32>, g, dim3(threads), 0, s, a, uws);
-    else
-        hipLaunchKernelGGL(knn_dmax_generic_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, a, uws);
-    return tpu3_launch_status();
+    if (own) {
+        e = hipFreeAsync(ws, s);
+        if (!r && e != hipSuccess) r = (int)e;
+    }
+    return r;
 }

@@ -79,8 +79,11 @@ class DenseEdgeConv(nn.Module):
         if idx is None and self.fused_ok(x):
             # kNN graph + gather + 3 dense layers + max in two launches, no (B,N,k,C) tensors
             x = x.contiguous()
-            full_idx, _, _ = operations.knn_query(k + 1, x, x, unique=True, layout=layout,
-                                                  want_dist=False, want_grouped=False)
+            full_idx = operations.BACKEND.knn_graph(k + 1, x, layout) \
+                if hasattr(operations.BACKEND, "knn_graph") else None
+            if full_idx is None:
+                full_idx, _, _ = operations.knn_query(k + 1, x, x, unique=True, layout=layout,
+                                                      want_dist=False, want_grouped=False)
             if out is None:
                 out = x.new_empty((B, N, C + n * g))
             operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out)

@@ -19,6 +19,10 @@ from .. import _lib as L
 from .. import sampling
 
 
+import os
+_DEBUG_UWS = bool(os.environ.get("TPU3_DEBUG_UWS"))
+
+
 class HipBackend(object):
     """The kernels, behind the small interface the operators below use.  Tests swap this object
     to exercise the host-side wiring without a GPU; the product never does."""
@@ -67,13 +71,58 @@ class HipBackend(object):
             if unique:
                 dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
                 uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
+                need = lib.tpu3_knn_unique_workspace_bytes(bp, n)
+                ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
                 L.check(lib.tpu3_knn_unique_prepare_f32(s, b, m, n, c, L.ptr(query), L.ptr(points),
-                                                        lay_ref, L.ptr(dup), L.ptr(uws)),
+                                                        lay_ref, L.ptr(dup), L.ptr(uws), L.ptr(ws), need),
                         "tpu3_knn_unique_prepare_f32")
             L.check(lib.tpu3_knn_f32(s, b, m, n, c, k, L.ptr(query), L.ptr(points), lay_ref, L.ptr(dup),
                                      L.ptr(uws), L.ptr(idx), 8, L.ptr(dist), L.ptr(grouped)),
                     "tpu3_knn_f32")
+        if unique and _DEBUG_UWS:
+            torch.cuda.synchronize()
+            print("[uws] b=%d m=%d n=%d c=%d k=%d any_dup=%d redo=%d" % (b, m, n, c, k, int(uws[0]), int(uws[1])))
         return idx, dist, grouped
+
+    def _layout(self, layout, b, bp):
+        if layout is None:
+            return None, 1, []
+        lay = L.KnnLayout()
+        keep = []
+        for name in ("n_arr", "m_arr", "pts_of", "grp"):
+            t = layout.get(name)
+            if t is not None:
+                L.require_device(t, name)
+                L.require_dtype(t, torch.int32, name)
+                keep.append(t)
+            setattr(lay, name, L.ptr(t))
+        groups = int(layout.get("groups", 1)) if layout.get("grp") is not None else 1
+        lay.bp, lay.groups = bp, groups
+        return lay, groups, keep
+
+    def knn_graph(self, k, x, layout=None):
+        """Self kNN graph for the fused DenseEdgeConv: x (B,N,C) f32 -> idx int32 (B,N,k) holding the
+        exact top-k set (unique=True semantics), nearest in slot 0, the rest in index order.
+        Returns None when the size is not covered by the two-pass kernel."""
+        b, n, c = x.shape
+        if c > 32 or k not in (17, 33) or n < k:
+            return None
+        lay, groups, keep = self._layout(layout, b, b)
+        lay_ref = ctypes.byref(lay) if lay is not None else None
+        dev = x.device
+        idx = torch.empty((b, n, k), dtype=torch.int32, device=dev)
+        dup = torch.empty((b, n), dtype=torch.uint8, device=dev)
+        uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
+        lib = L.lib()
+        with torch.cuda.device(dev):
+            s = L.stream_of(x)
+            need = lib.tpu3_knn_unique_workspace_bytes(b, n)
+            ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
+            L.check(lib.tpu3_knn_unique_prepare_f32(s, b, n, n, c, L.ptr(x), L.ptr(x), lay_ref, L.ptr(dup),
+                                                    L.ptr(uws), L.ptr(ws), need), "tpu3_knn_unique_prepare_f32")
+            L.check(lib.tpu3_knn_graph_f32(s, b, n, n, c, k, L.ptr(x), L.ptr(x), lay_ref, L.ptr(dup), L.ptr(uws),
+                                           L.ptr(idx)), "tpu3_knn_graph_f32")
+        return idx
 
     def fps(self, xyz, npoint, n_arr=None, m_arr=None):
         """xyz (B,N,3) f32 contiguous -> idx int32 (B,npoint).  Dense calls go through the

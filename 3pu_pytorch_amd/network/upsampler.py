@@ -257,7 +257,35 @@ class Level(torch.nn.Module):
         """output [1, num_grid_point] (reference :264-270)"""
         return torch.linspace(-0.2, 0.2, num_grid_point).view(1, num_grid_point)
 
+    # patches per launch group of forward_cl: bounds the (B,N,K,264) / (B,N*r,265) temporaries of the
+    # skip connection and the regressor (25 GB / 10 GB for the 15 360 level-4 patches of 8 clouds)
+    max_patches = 4096
+
     def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1):
+        """Channel-last level; large batches are processed in chunks of whole owner groups (every
+        patch is independent apart from the per-group unique-max, so chunks are exact)."""
+        B = xyz_normalized.size(0)
+        if B <= self.max_patches or torch.is_grad_enabled():
+            return self._forward_cl(xyz, xyz_normalized, previous, owner, groups)
+        if owner is None:
+            bounds = list(range(0, B, self.max_patches)) + [B]
+        else:
+            # owner ids are non-decreasing (patches of one cloud are contiguous): cut between owners
+            per = B // groups if groups > 0 and B % groups == 0 else None
+            if per is None or per > self.max_patches:
+                bounds = list(range(0, B, self.max_patches)) + [B]
+            else:
+                step = (self.max_patches // per) * per
+                bounds = list(range(0, B, step)) + [B]
+        outs, feats = [], []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            own = None if owner is None else owner[lo:hi].contiguous()
+            o, f = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups)
+            outs.append(o)
+            feats.append(f)
+        return torch.cat(outs, dim=0), torch.cat(feats, dim=0)
+
+    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1):
         """Channel-last level:
             xyz, xyz_normalized  (B,N,3)
             previous             None or (prev_xyz (Bp,M,3), prev_feat (Bp,M,C), prev_count (Bp,)|None)

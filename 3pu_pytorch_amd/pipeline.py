@@ -88,12 +88,16 @@ def shard_range(total, rank, world):
 
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-             timing=None):
+             timing=None, fps_stream=None):
     """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
     the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
     Every rank passes the same `clouds` and receives the full result.
     `timing`: optional list; a (start, end) pair of torch.cuda.Event bracketing the final-FPS
-    launch on the current stream is appended per call (bench.py's roofline measurement)."""
+    launch on its stream is appended per call (bench.py's roofline measurement).
+    `fps_stream`: optional side stream for the final FPS.  That kernel is one long dependent chain
+    on ONE compute unit per cloud; on its own stream it overlaps with the network stages of the
+    next call, which use the other 255 CUs.  The result is then only valid after that stream has
+    been synchronised (the caller's job)."""
     C, _, N = clouds.shape
     rank, world = _world()
     if shard is None or world == 1:
@@ -105,7 +109,9 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
         ids, per = shard_range(C, rank, world)
         mine = clouds[ids]
         local = upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
-                         timing=timing)
+                         timing=timing, fps_stream=fps_stream)
+        if fps_stream is not None:
+            torch.cuda.current_stream().wait_stream(fps_stream)
         out = _all_gather_cat(local)                         # (world*per, 3, N*r) in cloud order
         return out[:C]
     elif shard == "patches":
@@ -122,15 +128,23 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     if not final_fps:
         return merged.transpose(2, 1).contiguous()
     # main.py:379-380: the one big FPS down to N * up_ratio points per cloud
-    if timing is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
-    idx = operations.fps(merged, N * up_ratio)
-    if timing is not None:
-        ev[1].record()
-        timing.append(ev)
-    out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
-    return out.transpose(2, 1).contiguous()
+    def final(merged):
+        if timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        idx = operations.fps(merged, N * up_ratio)
+        if timing is not None:
+            ev[1].record()
+            timing.append(ev)
+        out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+        return out.transpose(2, 1).contiguous()
+
+    if fps_stream is None:
+        return final(merged)
+    fps_stream.wait_stream(torch.cuda.current_stream())
+    merged.record_stream(fps_stream)
+    with torch.cuda.stream(fps_stream):
+        return final(merged)
 
 
 def pc_prediction(net, input_pc, num_point, up_ratio, patch_num_ratio=3):

@@ -133,19 +133,39 @@ typedef struct {
  *   grouped  (b,m,k,c) f32 gathered neighbours, may be NULL (the reference returns this as a
  *            (b,c,m,k) permuted view of exactly this layout, :209-214)
  *   dup/uws  unique=True support (:192-204): NULL/NULL for unique=False, else the outputs of
- *            tpu3_knn_unique_prepare_f32 for the same query/points/layout. */
+ *            tpu3_knn_unique_prepare_f32 for the same query/points/layout.  D += max(D)*dup puts
+ *            every duplicate behind every first occurrence unless fewer than k first occurrences
+ *            exist; for k <= 64 the call first skips duplicates and lets every query verify that
+ *            this is exact for it, and only otherwise (uws[1]) computes max(D) and applies the
+ *            reference arithmetic.  Results are identical either way. */
 int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
                  const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
-                 const uint32_t *uws, void *idx, int idx_elem_size, float *dist, float *grouped);
+                 uint32_t *uws, void *idx, int idx_elem_size, float *dist, float *grouped);
+
+/* kNN graph for the fused DenseEdgeConv block: the exact top-k SET per query with the nearest
+ * neighbour in slot 0 and the other k-1 members in ascending index order (DenseEdgeConv drops the
+ * nearest and max-pools over the rest, network/layers.py:33-35,63, so their order is immaterial).
+ * Two passes -- the k smallest distances by a v_med3 chain, then the indices by threshold -- instead
+ * of a sorted insertion with indices.  idx (b,m,k) i32.  dup/uws as for tpu3_knn_f32; with
+ * duplicated rows present the exact sorted kernels produce the (then ordered) result instead.
+ * Supported: c <= 32 and k in {17, 33}, else TPU3_ELIMIT. */
+int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
+                       const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
+                       uint32_t *uws, int32_t *idx);
 
 /* unique=True pre-pass: dup (bp,n) u8 = 1 iff an identical row exists at a smaller index of
- * the same point set (complement of np.unique(axis=0, return_index=True), operations.py:194-200)
- * and, only if any row anywhere is a duplicate, max(D) per group (operations.py:204).
- * uws = TPU3_KNN_UWS_WORDS(groups) device words: [0] any-dup flag, [1..3] reserved,
- * [4+g] max(D) of group g as order-preserving bits. */
+ * the same point set (complement of np.unique(axis=0, return_index=True), operations.py:194-200).
+ * O(n) per point set (open-addressing table of class representatives) above 1024 points,
+ * a quadratic scan below.  uws = TPU3_KNN_UWS_WORDS(groups) device words, zeroed here:
+ * [0] any-dup flag, [1] set by tpu3_knn_f32 when its optimistic pass had to be redone,
+ * [2..3] reserved, [4+g] max(D) of group g as order-preserving bits (operations.py:204; filled by
+ * tpu3_knn_f32 only when the result can depend on it).  `workspace`: NULL (stream-ordered
+ * allocation inside) or tpu3_knn_unique_workspace_bytes(bp, n) device bytes. */
 int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c,
                                 const float *query, const float *points,
-                                const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws);
+                                const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws,
+                                void *workspace, size_t workspace_bytes);
+size_t tpu3_knn_unique_workspace_bytes(int bp, int n);
 
 /* Fused DenseEdgeConv block, inference (network/layers.py:44-64 for in_channels 24, growth 12,
  * 3 dense layers -- the configuration of every Level, network/upsampler.py:210-223):

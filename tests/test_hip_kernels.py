@@ -261,6 +261,36 @@ def test_knn_bit_exact(orc, dev, k, b, m, n, c, unique):
     _knn_check(orc, dev, k, q, p, unique)
 
 
+@pytest.mark.parametrize("k,c,n,uniq_rows", [(5, 3, 40, 3), (33, 24, 100, 20), (5, 3, 3000, 4), (8, 3, 64, 8)])
+def test_knn_unique_fewer_first_occurrences_than_k(orc, dev, k, c, n, uniq_rows):
+    """When fewer than k distinct rows exist the neighbour list must contain penalised duplicates,
+    exactly as D += max(D)*dup ranks them: the optimistic pass cannot verify and the gated exact
+    passes (max(D) + reference arithmetic) must produce the oracle's result."""
+    rng = np.random.default_rng(k * n)
+    base = rng.standard_normal((2, uniq_rows, c)).astype(np.float32)
+    p = base[:, rng.integers(0, uniq_rows, size=n)]
+    q = rng.standard_normal((2, 50, c)).astype(np.float32)
+    _knn_check(orc, dev, k, q, np.ascontiguousarray(p), True)
+
+
+@pytest.mark.parametrize("n,c", [(1024, 3), (5000, 3), (12480, 3), (2000, 24)])
+def test_knn_unique_hash_dedup_large_sets(orc, dev, n, c):
+    """Point sets of >= 1024 rows take the O(n) hash de-duplication; results must match the oracle's
+    quadratic first-occurrence definition (every row repeated ~4 times, plus -0.0 / +0.0 twins)."""
+    rng = np.random.default_rng(n + c)
+    base = rng.standard_normal((2, n // 4, c)).astype(np.float32)
+    base[:, 0, 0] = 0.0
+    p = base[:, rng.integers(0, n // 4, size=n)]
+    p[:, 5] = base[:, 0]
+    p[:, 9] = base[:, 0]
+    p[:, 9, 0] = -0.0                                  # equal to row 5 under float ==
+    p = np.ascontiguousarray(p)
+    q = p[:, :200] + np.float32(0.01) * rng.standard_normal((2, 200, c)).astype(np.float32)
+    dup = orc.first_occurrence_dup(p)
+    assert dup[:, 9].all()
+    _knn_check(orc, dev, 5, q, p, True)
+
+
 @pytest.mark.parametrize("k,c,n", [(5, 3, 936), (33, 24, 312), (312, 3, 700)])
 def test_knn_unique_with_duplicate_rows(orc, dev, k, c, n):
     """unique=True semantics (operations.py:192-204): rows that repeat an earlier row get
@@ -278,6 +308,29 @@ def test_knn_unique_with_duplicate_rows(orc, dev, k, c, n):
     assert dup[0].sum() > 0 and dup[1].sum() == 0
     _knn_check(orc, dev, k, q, p, True)
     _knn_check(orc, dev, k, q, p, False)
+
+
+@pytest.mark.parametrize("b,n,c,k,dups", [(6, 312, 24, 33, False), (3, 312, 24, 17, False), (2, 700, 3, 33, False),
+                                          (4, 312, 24, 33, True), (2, 40, 24, 33, False)])
+def test_knn_graph_is_the_exact_topk_set(orc, dev, b, n, c, k, dups):
+    """tpu3_knn_graph_f32: slot 0 = the oracle's nearest neighbour, slots 1.. = the oracle's other
+    k-1 neighbours as a set (ascending index order).  With duplicated rows the gated exact kernels
+    must take over (unique=True penalty)."""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(n * k + c)
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    if dups:
+        x[:, n // 2:] = x[:, :n - n // 2]
+        x[1] = rng.standard_normal((n, c)).astype(np.float32)
+    # exact ties without duplicate rows: points on a lattice line
+    if not dups and c == 3:
+        x[0, :50] = np.stack([np.arange(50), np.zeros(50), np.zeros(50)], 1).astype(np.float32)
+    idx = ops.BACKEND.knn_graph(k, _t(x, dev)).cpu().numpy()
+    ri, _ = orc.knn(k, x, x, True)
+    np.testing.assert_array_equal(idx[:, :, 0], ri[:, :, 0])
+    np.testing.assert_array_equal(np.sort(idx[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
+    if not dups:
+        assert (np.diff(idx[:, :, 1:], axis=-1) > 0).all()
 
 
 def test_knn_layout_shared_points_groups_and_ragged(orc, dev):
