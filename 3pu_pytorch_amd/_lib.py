@@ -37,6 +37,7 @@ SIGNATURES = {
     "tpu3_knn_unique_prepare_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout),
                                          _vp, _vp, _vp, _sz]),
     "tpu3_knn_unique_workspace_bytes": (_sz, [_i, _i]),
+    "tpu3_interlevel_skip_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f]),
     "tpu3_knn_graph_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp]),
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -182,6 +182,22 @@ class HipBackend(object):
                 L.ptr(out), out.stride(1)), "tpu3_dense_edge_conv_f32")
         return out
 
+    def interlevel_skip(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2):
+        """Fused skip connection (inference): feat (B,N,C) is updated in place
+        (x_i += scale * sum_k w_k f_k with the reference's bilateral weights)."""
+        for t, nm in ((xyz, "xyz"), (feat, "feat"), (prev_xyz, "prev_xyz"), (prev_feat, "prev_feat")):
+            L.require_device(t, nm)
+            L.require_dtype(t, torch.float32, nm)
+        L.require_device(idx, "idx")
+        B, N, C = feat.shape
+        K = idx.size(2)
+        with torch.cuda.device(feat.device):
+            L.check(L.lib().tpu3_interlevel_skip_f32(
+                L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
+                L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale)),
+                "tpu3_interlevel_skip_f32")
+        return feat
+
     def normalize(self, pc, n_arr=None):
         """pc (B,3,N) f32 contiguous -> (out (B,3,N), centroid (B,3,1), radius (B,1,1))."""
         L.require_device(pc, "pc")

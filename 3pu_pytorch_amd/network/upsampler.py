@@ -335,10 +335,17 @@ class Level(torch.nn.Module):
                 pts_of = layout["pts_of"].long()
             else:
                 pts_of = None
+            fused = (not torch.is_grad_enabled() and hasattr(operations.BACKEND, "interlevel_skip")
+                     and x.is_cuda and x.is_contiguous() and self.fm_knn <= 8 and x.size(-1) <= 320)
             with torch.no_grad():
                 knn_idx, _, knn_points = operations.knn_query(
                     self.fm_knn, xyz.detach(), prev_xyz.detach(), unique=True, layout=layout,
-                    want_dist=False)
+                    want_dist=False, want_grouped=not fused)
+            if fused:
+                operations.BACKEND.interlevel_skip(
+                    xyz.contiguous(), x, prev_xyz.contiguous(), prev_feat.contiguous(),
+                    None if pts_of is None else layout["pts_of"], knn_idx)
+                return self._regress(x, xyz_normalized, B, N)
             bsel = (torch.arange(B, device=xyz.device) if pts_of is None else pts_of).view(-1, 1, 1)
             knn_feats = prev_feat[bsel, knn_idx]                              # (B,N,K,C)
             s_weight = self.exponential_distance_cl(xyz, knn_points)
@@ -347,6 +354,9 @@ class Level(torch.nn.Module):
             weight = weight / torch.sum(weight + 1e-5, dim=-1, keepdim=True)
             x = 0.2 * torch.sum(weight.unsqueeze(-1) * knn_feats, dim=2) + x
 
+        return self._regress(x, xyz_normalized, B, N)
+
+    def _regress(self, x, xyz_normalized, B, N):
         point_features = x
         # feature expansion: every point r times, followed by its 1-d / 2-d code (:350-361)
         _, code_length, ratio = self.code.size()

@@ -182,6 +182,18 @@ int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, co
                              const float *w0, const float *b0, const float *w1, const float *b1,
                              const float *w2, const float *b2, float *out, int out_stride);
 
+/* Fused inter-level skip connection of a Level, inference (network/upsampler.py:317-347):
+ *   w_k = exp(-|p_i - q_k|^2 / (h_s/2)) * exp(-|x_i - f_k|^2 / (h_f/2)),  h = mean_i min_k (dist),
+ *   w_k /= sum_k (w_k + 1e-5),  x_i += scale * sum_k w_k f_k          (scale = 0.2 in the reference)
+ * xyz (b,n,3) patch coordinates; feat (b,n,feat_stride) in/out, the first c channels are x_i;
+ * prev_xyz (bp,m,3), prev_feat (bp,m,c) previous level's merged cloud; pts_of (b) i32 maps a patch
+ * to its previous cloud (NULL = identity); idx (b,n,k) i32/i64 neighbour rows (from tpu3_knn_f32,
+ * k <= 8, c <= 320).  Nothing of size (b,n,k,c) is materialised. */
+int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
+                             float *feat, int feat_stride, const float *prev_xyz,
+                             const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+                             int idx_elem_size, float scale);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,

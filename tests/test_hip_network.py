@@ -229,3 +229,32 @@ def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
     assert torch.equal(idx_f.long().sort(-1)[0], idx_u.sort(-1)[0])
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
     assert torch.equal(y_f[..., 36:], x)                      # the x_i pass-through channels
+
+
+def test_interlevel_skip_fused_matches_unfused(dev, monkeypatch):
+    """Level with a previous cloud shared by several patches (pts_of), ragged previous counts and
+    duplicated previous points: the fused skip kernel against the plain torch formulation of
+    network/upsampler.py:317-347 on the device.  1e-5 on the regressed coordinates, 1e-4 on the
+    264-channel features (O(1..10) values)."""
+    ops, ups = pkg("network.operations"), pkg("network.upsampler")
+    net = _net(dev)
+    lvl = net.levels["level_3"]
+    torch.manual_seed(3)
+    B, Bp, M = 12, 3, 936
+    prev_xyz = torch.randn(Bp, M, 3, device=dev)
+    prev_xyz = prev_xyz / prev_xyz.norm(dim=2, keepdim=True)
+    prev_xyz[:, 624:] = prev_xyz[:, :312]                        # overlapping merged patches
+    prev_feat = torch.randn(Bp, M, 264, device=dev)
+    prev_feat[:, 624:] = prev_feat[:, :312]
+    prev_count = torch.tensor([936, 900, 936], dtype=torch.int32, device=dev)
+    owner = torch.arange(Bp, dtype=torch.int32, device=dev).repeat_interleave(B // Bp)
+    xyz = torch.randn(B, 312, 3, device=dev)
+    xyz = 0.3 * xyz / xyz.norm(dim=2, keepdim=True) + prev_xyz[owner.long(), :1]
+    norm, _, _ = ops.normalize_point_batch(xyz.transpose(2, 1).contiguous())
+    norm = norm.transpose(2, 1).contiguous()
+    with torch.no_grad():
+        y_f, f_f = lvl._forward_cl(xyz, norm, (prev_xyz, prev_feat, prev_count), owner, Bp)
+        monkeypatch.delattr(ops.HipBackend, "interlevel_skip")
+        y_u, f_u = lvl._forward_cl(xyz, norm, (prev_xyz, prev_feat, prev_count), owner, Bp)
+    np.testing.assert_allclose(f_f.cpu().numpy(), f_u.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
