@@ -690,7 +690,7 @@ bool bad_dims(int b, int m, int n, int c, int k)
     return b < 0 || m < 0 || n < 0 || c <= 0 || k < 0;
 }
 
-constexpr int KNN_DUP_HASH_MIN_N = 1024;    // below this the quadratic kernel is faster and needs no table
+constexpr int KNN_DUP_HASH_MIN_N = 128;     // below this the quadratic kernel needs no table and is as fast
 
 int knn_dup_table_size(int n)
 {

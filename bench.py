@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clouds", type=int, default=8,
                     help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs)")
+    ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
     ap.add_argument("--no_overlap", action="store_true",
                     help="run the final FPS on the main stream instead of a side stream")
     ap.add_argument("--num_shape_point", type=int, default=5000)
@@ -75,13 +76,13 @@ def main():
     clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
 
     timing = []
-    # two side streams, used alternately: the final FPS launches of consecutive steps occupy
-    # different CUs and may overlap each other as well as the next steps' network stages
-    sides = None if args.no_overlap else [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    # side streams, used round-robin: the final FPS launches of consecutive steps occupy different
+    # CUs (one per cloud) and overlap each other as well as the following steps' network stages
+    sides = None if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(args.fps_streams)]
     counter = [0]
 
     def step():
-        side = None if sides is None else sides[counter[0] % 2]
+        side = None if sides is None else sides[counter[0] % len(sides)]
         counter[0] += 1
         # the final FPS of this step (one CU per cloud, a pure latency chain) runs on a side stream
         # and overlaps with the network stages of the NEXT step; everything is inside the timed region
@@ -130,6 +131,15 @@ def main():
                 "peak": 8000.0, "unit": "GB/s", "traffic": None,
                 "launch_ms": fps_ms, "algorithmic_bytes_per_launch": alg_bytes}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        # HBM traffic of that launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
+        # gfx950 correction + WRITE_SIZE, KiB -> bytes); only valid for the profiled configuration
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_fb_main.json")) as f:
+                tr = json.load(f)
+            if tr.get("clouds_per_launch") == C and (N, npnt, r) == (5000, 312, 16):
+                roof["traffic"] = tr["traffic_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "upsampled points/sec (16x, 312-pt patches, 5000->80000)",
             "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,

@@ -34,16 +34,25 @@ class OracleBackend(object):
         # one reference call per group: all its query sets against their point sets
         for g in np.unique(grp):
             members = np.where(grp == g)[0]
-            # the oracle call wants one shared batch: evaluate member by member but with the
-            # group's max(D) -> build the batch explicitly
-            sub_q, sub_p, spans = [], [], []
+            spans = []
             for i in members:
                 pb = int(pts_of[i])
                 nn = n if n_arr is None else int(n_arr[pb])
                 mm = m if m_arr is None else int(m_arr[i])
                 spans.append((i, pb, nn, mm))
+            if len({(nn, mm) for (_, _, nn, mm) in spans}) == 1:
+                # uniform sizes: this IS one reference call (batch = the group's query sets, point sets
+                # expanded like previous_xyz.expand) -- the C oracle applies max(D) over the whole call
+                _, _, nn, mm = spans[0]
+                qq = np.ascontiguousarray(q[members][:, :mm])
+                pp = np.ascontiguousarray(p[[pb for (_, pb, _, _) in spans]][:, :nn])
+                ii, dd = orc.knn(k, qq, pp, unique)
+                for t, (i, pb, _, _) in enumerate(spans):
+                    idx[i, :mm], dist[i, :mm] = ii[t], dd[t]
+                    grouped[i, :mm] = p[pb][ii[t]]
+                continue
             if unique:
-                # emulate `D += max(D) * dup` over the whole group with a two-pass evaluation
+                # ragged group: emulate `D += max(D) * dup` over the whole group in two passes
                 dmax, any_dup = None, False
                 dups = {}
                 for (i, pb, nn, mm) in spans:
@@ -58,7 +67,6 @@ class OracleBackend(object):
                 for (i, pb, nn, mm) in spans:
                     if any_dup:
                         ii, dd = orc.knn(nn, q[i:i + 1, :mm], p[pb:pb + 1, :nn], False)
-                        # re-rank with the addend (distances were sorted ascending by (d, idx))
                         d_by_idx = np.empty((mm, nn), np.float32)
                         np.put_along_axis(d_by_idx, ii[0].astype(np.int64), dd[0], axis=1)
                         d_by_idx = d_by_idx + np.float32(dmax) * dups[pb].astype(np.float32)[None, :]
