@@ -9,17 +9,7 @@ from math import log
 import torch
 
 from .network.model_loss import ChamferLoss
-
-
-def load_network(net, path):
-    """pytorch_utils.py:18-51: load the parameters whose names exist in `net`, return the step."""
-    loaded_state = torch.load(path, map_location="cpu")
-    own = set(net.state_dict().keys())
-    extra = set(loaded_state["states"].keys()) - own
-    for k in extra:
-        del loaded_state["states"][k]
-    net.load_state_dict(loaded_state["states"])
-    return int(loaded_state.get("step", 0)) if "step" in loaded_state else 0
+from .utils.pytorch_utils import load_network, save_network  # noqa: F401
 
 
 class Model(object):
@@ -32,7 +22,7 @@ class Model(object):
             self.old_lr = opt.lr_init
             self.lr = opt.lr_init
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=opt.lr_init, betas=(0.9, 0.999))
-        if getattr(opt, "ckpt", None) is not None:
+        if getattr(opt, "ckpt", None) not in (None, "random"):
             self.step = load_network(self.net, opt.ckpt)
         else:
             self.step = 0

@@ -1,6 +1,8 @@
 """-m gpu: the network, Chamfer loss and the pipeline on the MI355X through the HIP kernels,
 against the reference-generated fixtures and the oracle; and, at BASELINE.json's full sizes,
 through size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -258,3 +260,27 @@ def test_interlevel_skip_fused_matches_unfused(dev, monkeypatch):
         y_u, f_u = lvl._forward_cl(xyz, norm, (prev_xyz, prev_feat, prev_count), owner, Bp)
     np.testing.assert_allclose(f_f.cpu().numpy(), f_u.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
+
+
+def test_cli_test_and_train_phases(dev, tmp_path, monkeypatch):
+    """The drop-in CLI on the device: --phase test on .xyz files (checkpoint in the reference's
+    format) writes <name>.ply with N*up_ratio points; --phase train runs optimiser steps."""
+    main, pu, ups, pcu = pkg("main"), pkg("utils.pytorch_utils"), pkg("network.upsampler"), pkg("utils.pc_utils")
+    torch.manual_seed(0)
+    net = ups.Net(max_up_ratio=4, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+    ckpt = pu.save_network(net, str(tmp_path), "model", epoch_label="0", step="0")
+    os.makedirs(os.path.join(str(tmp_path), "data"))
+    for i in range(2):
+        np.savetxt(os.path.join(str(tmp_path), "data", "cloud%d.xyz" % i), sphere(i, 900)[0] * 2.0 + 0.5)
+    out = os.path.join(str(tmp_path), "out")
+    main.main(["--phase", "test", "--ckpt", ckpt, "--num_point", "312", "--num_shape_point", "1000",
+               "--up_ratio", "4", "--test_data", os.path.join(str(tmp_path), "data", "*.xyz"),
+               "--result_dir", out])
+    for i in range(2):
+        up = pcu.load(os.path.join(out, "data", "cloud%d.ply" % i))
+        src = pcu.load(os.path.join(out, "data", "cloud%d_input.ply" % i))
+        assert up.shape == (4000, 3) and src.shape == (1000, 3) and np.isfinite(up).all()
+        assert abs(up.mean(0) - src.mean(0)).max() < 1.0          # same frame (de-normalised; radius 2)
+    monkeypatch.setenv("TPU3_STEPS_PER_EPOCH", "2")
+    main.main(["--phase", "train", "--h5_data", "synthetic", "--num_point", "312", "--up_ratio", "4",
+               "--batch_size", "4", "--max_epoch", "2", "--stage_steps", "1", "--log_dir", str(tmp_path)])
