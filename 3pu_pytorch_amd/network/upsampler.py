@@ -365,11 +365,22 @@ class Level(torch.nn.Module):
         # feature expansion: every point r times, followed by its 1-d / 2-d code (:350-361)
         _, code_length, ratio = self.code.size()
         code = self.code.to(device=x.device, dtype=x.dtype)                  # (1,L,r)
-        code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)
-        x = torch.cat([x.unsqueeze(2).expand(-1, -1, ratio, -1), code], dim=-1)
-        x = x.reshape(B, N * ratio, x.size(-1))
-        # coordinate regression (:363-369) + residual (:371-372)
-        x = self.up_layer.up_layer1.forward_cl(x)
+        up1 = self.up_layer.up_layer1
+        if not torch.is_grad_enabled() and up1.pointwise() and up1.activation == "relu":
+            # inference: W [x_i ; code_j] = W_x x_i + W_c code_j -- the 264-channel part is the same
+            # for the r replicas of a point, so it is computed once per point and the (B, N*r, 265)
+            # concatenation of the reference is never built (half the FLOPs of this layer)
+            w = up1.conv.weight.view(up1.conv.weight.size(0), -1)
+            cin = x.size(-1)
+            a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)                 # (B,N,128)
+            c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])          # (r,128)
+            x = torch.relu_(a.unsqueeze(2) + c.view(1, 1, ratio, -1)).reshape(B, N * ratio, -1)
+        else:
+            code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)
+            x = torch.cat([x.unsqueeze(2).expand(-1, -1, ratio, -1), code], dim=-1)
+            x = x.reshape(B, N * ratio, x.size(-1))
+            # coordinate regression (:363-369) + residual (:371-372)
+            x = up1.forward_cl(x)
         x = self.up_layer.up_layer2.forward_cl(x)
         x = self.fc_layer1.forward_cl(x)
         x = self.fc_layer2.forward_cl(x)
