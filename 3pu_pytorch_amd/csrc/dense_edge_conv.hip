@@ -141,50 +141,77 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
             *(f32x4 *)(T + e * DEC_TS + 32 + 4 * g) = t2;
         }
         const int pend = min(16, n - pb);
-        for (int p = 0; p < pend; ++p) {
-            const int i = pb + p;
-            const f32x4 c0 = *(const f32x4 *)(T + p * DEC_TS + 4 * g);
-            const f32x4 c1 = *(const f32x4 *)(T + p * DEC_TS + 16 + 4 * g);
-            const f32x4 c2 = *(const f32x4 *)(T + p * DEC_TS + 32 + 4 * g);
-            f32x4 m0, m1, m2;
+        // neighbour indices of the point about to be processed (one register per tile); the next
+        // point's are requested while the current one computes, so the global-load latency is hidden
+        auto load_idx = [&](int i, int (&j)[TILES]) {
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 const size_t io = ((size_t)blockIdx.x * n + i) * a.idx_stride + a.idx_off + 16 * t + e;
-                int j = a.idx64 ? (int)((const long long *)a.idx)[io] : ((const int *)a.idx)[io];
-                j = min(max(j, 0), n - 1);
-                const float *xj = xs + j * DEC_S + 6 * g;
-                f32x4 h0 = c0;
-#pragma unroll
-                for (int s = 0; s < 6; ++s)
-                    h0 = mfma4(w0b[s], xj[s], h0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h0[r] = fmaxf(h0[r], 0.f);
-                f32x4 h1 = c1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h1 = mfma4(w1a[r], h0[r], h1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h1[r] = fmaxf(h1[r], 0.f);
-                f32x4 h2 = c2;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h2 = mfma4(w2a[r], h1[r], h2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h2 = mfma4(w2b[r], h0[r], h2);
-                if (t == 0) {
-                    m0 = h0; m1 = h1; m2 = h2;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        m0[r] = fmaxf(m0[r], h0[r]);
-                        m1[r] = fmaxf(m1[r], h1[r]);
-                        m2[r] = fmaxf(m2[r], h2[r]);
-                    }
-                }
+                j[t] = a.idx64 ? (int)((const long long *)a.idx)[io] : ((const int *)a.idx)[io];
             }
+        };
+        int jn[TILES];
+        load_idx(pb, jn);
+        for (int p = 0; p < pend; ++p) {
+            const int i = pb + p;
+            const float *xj[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                xj[t] = xs + min(max(jn[t], 0), n - 1) * DEC_S + 6 * g;
+            if (p + 1 < pend)
+                load_idx(i + 1, jn);
+            const f32x4 c0 = *(const f32x4 *)(T + p * DEC_TS + 4 * g);
+            const f32x4 c1 = *(const f32x4 *)(T + p * DEC_TS + 16 + 4 * g);
+            const f32x4 c2 = *(const f32x4 *)(T + p * DEC_TS + 32 + 4 * g);
+            // the TILES edge tiles of the point are independent accumulator chains: issuing their
+            // MFMAs alternately hides the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
+            f32x4 h0[TILES], h1[TILES], h2[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                h0[t] = c0;
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    h0[t] = mfma4(w0b[s], xj[t][s], h0[t]);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h0[t][r] = fmaxf(h0[t][r], 0.f);
+                h1[t] = c1;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    h1[t] = mfma4(w1a[r], h0[t][r], h1[t]);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h1[t][r] = fmaxf(h1[t][r], 0.f);
+                h2[t] = c2;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    h2[t] = mfma4(w2a[r], h1[t][r], h2[t]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    h2[t] = mfma4(w2b[r], h0[t][r], h2[t]);
+            f32x4 m0 = h0[0], m1 = h1[0], m2 = h2[0];
+#pragma unroll
+            for (int t = 1; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m0[r] = fmaxf(m0[r], h0[t][r]);
+                    m1[r] = fmaxf(m1[r], h1[t][r]);
+                    m2[r] = fmaxf(m2[r], h2[t][r]);
+                }
             // ---- max over the 16 edges of the row; one lane per channel group writes ----------------
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
