@@ -17,7 +17,7 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 class KnnLayout(ctypes.Structure):
     """tpu3_knn_layout (include/tpu3.h)."""
     _fields_ = [("n_arr", _vp), ("m_arr", _vp), ("pts_of", _vp), ("grp", _vp),
-                ("bp", _i), ("groups", _i)]
+                ("bp", _i), ("groups", _i), ("cand", _vp), ("cand_count", _vp)]
 
 
 # name -> (restype, argtypes); exactly the functions include/tpu3.h declares
@@ -37,7 +37,9 @@ SIGNATURES = {
     "tpu3_knn_unique_prepare_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout),
                                          _vp, _vp, _vp, _sz]),
     "tpu3_knn_unique_workspace_bytes": (_sz, [_i, _i]),
-    "tpu3_interlevel_skip_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f]),
+    "tpu3_interlevel_skip_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _i]),
+    "tpu3_knn_unique_compact_i32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_knn_graph_self_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp, _vp, _sz]),
     "tpu3_knn_graph_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp]),
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

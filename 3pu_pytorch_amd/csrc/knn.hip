@@ -37,6 +37,8 @@ struct KnnArgs {
     void *idx;               // (b,m,k) i32 / i64
     int idx64;
     float *dist;             // (b,m,k) or null
+    const int32_t *cand;     // (bp,n) ascending indices of the first occurrences, or null
+    const int32_t *cand_count;   // (bp)
 };
 
 __device__ __forceinline__ void store_idx(const KnnArgs &a, size_t off, int v)
@@ -150,6 +152,15 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     const bool optimistic = use_dup && a.mode == 1;
     const float dmax = (use_dup && !optimistic) ? tpu3_unmono(a.uws[4 + (a.grp ? a.grp[b] : 0)]) : 0.f;
     float dupmin = __builtin_inff(), dqmax = -__builtin_inff();
+    // Optimistic mode over a COMPACTED candidate list (the ascending indices of the first
+    // occurrences): the duplicates are not even visited -- the merged cloud of overlapping patches
+    // holds every point ~5 times.  Positions in the list are in index order, so ties resolve as
+    // before; they are translated to row indices at the end.  A duplicate's distance equals its first
+    // occurrence's bit for bit, so max D over the list is max D over all rows and the nearest
+    // distance is a lower bound of every duplicate's: the same verification applies.
+    const bool compact = optimistic && a.cand != nullptr;
+    const int32_t *CAND = compact ? a.cand + (size_t)pb * a.n : nullptr;
+    const int nscan = compact ? a.cand_count[pb] : n;
 
     float q[C], rq;
     load_query<C>(q, rq, a.query + ((size_t)b * a.m + (live ? qi : 0)) * a.c, a.c, live);
@@ -164,13 +175,15 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     const float *P = a.points + (size_t)pb * a.n * a.c;
     const uint8_t *DUP = use_dup ? a.dup + (size_t)pb * a.n : nullptr;
 
-    for (int j0 = 0; j0 < n; j0 += TILE) {
-        const int len = min(TILE, n - j0);
+    for (int j0 = 0; j0 < nscan; j0 += TILE) {
+        const int len = min(TILE, nscan - j0);
         __syncthreads();
         for (int i = threadIdx.x; i < len; i += blockDim.x) {
             // optimistic: the slot carries the dup flag itself; otherwise the addend max(D)*dup
-            const float add = use_dup ? (optimistic ? (float)DUP[j0 + i] : dmax * (float)DUP[j0 + i]) : 0.f;
-            stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, add);
+            const int src = compact ? CAND[j0 + i] : j0 + i;
+            const float add = compact ? 0.f
+                                      : (use_dup ? (optimistic ? (float)DUP[src] : dmax * (float)DUP[src]) : 0.f);
+            stage_row<C>(tile + i * F4, P + (size_t)src * a.c, a.c, add);
             if (C == 3)
                 addend[i] = add;
         }
@@ -211,10 +224,12 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     if (live) {
         const size_t o = ((size_t)b * a.m + qi) * a.k;
         float tk = __builtin_inff();
+        if (compact && nscan < n)
+            dupmin = bd[0];
 #pragma unroll
         for (int i = 0; i < KMAX; ++i)
             if (i < a.k) {
-                store_idx(a, o + i, bi[i]);
+                store_idx(a, o + i, (compact && bi[i] < nscan) ? CAND[bi[i]] : bi[i]);
                 if (a.dist)
                     a.dist[o + i] = bd[i];
                 if (i == a.k - 1)
@@ -249,6 +264,12 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
     __shared__ float4 tile[TILE * F4];
     if (a.uws && a.uws[0] != 0)
         return;
+    // a.mode == 2: self query (query set == point set) without a de-duplication pre-pass.  Identical
+    // rows have D == 0 exactly (|q|^2, <q,p> and |p|^2 are then the same fmaf chain), so if no query
+    // holds a second zero among its k smallest distances, no row is duplicated and the result is final; otherwise
+    // uws[2] is raised and the caller's gated launches (hash de-duplication + exact kernels) redo it.
+    const bool self_check = a.mode == 2;
+    bool saw_zero = false;
     const int b = blockIdx.y;
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int n = a.n_arr ? a.n_arr[pb] : a.n;
@@ -280,6 +301,17 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
             }
     }
     const float t1 = ds[0], tk = ds[K - 1];
+    if (self_check && live) {
+        // the query's own row is one zero; a second one (or a list so degenerate that zeros could
+        // have been pushed out of it) asks for the exact path
+        int zeros = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            zeros += ds[i] == 0.f ? 1 : 0;
+        saw_zero = zeros >= 2 || !(tk > 0.f);
+    }
+    if (saw_zero)
+        a.uws[2] = 1u;
     int quota = 0;
 #pragma unroll
     for (int i = 0; i < K; ++i)
@@ -545,16 +577,22 @@ __device__ __forceinline__ uint32_t knn_row_hash(const float *__restrict__ r, in
     }
     return h ^ (h >> 15);
 }
+// gate_word >= 0: the kernel runs only if uws[gate_word] != 0 (then launched with a small grid
+// that strides over the (block, point set) work items)
 __global__ __launch_bounds__(256) void knn_dup_hash_insert_kernel(int n_pad, int c, int tsize,
                                                                   const float *__restrict__ points,
                                                                   const int32_t *__restrict__ n_arr,
-                                                                  uint32_t *__restrict__ table)
+                                                                  uint32_t *__restrict__ table, int bp, int nblk,
+                                                                  const uint32_t *__restrict__ uws, int gate_word)
 {
-    const int b = blockIdx.y;
-    const int n = n_arr ? n_arr[b] : n_pad;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    if (gate_word >= 0 && uws[gate_word] == 0)
         return;
+    for (int w = blockIdx.x; w < bp * nblk; w += gridDim.x) {
+    const int b = w / nblk;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const int i = (w - b * nblk) * blockDim.x + threadIdx.x;
+    if (i >= n)
+        continue;
     const float *P = points + (size_t)b * n_pad * c;
     uint32_t *T = table + (size_t)b * tsize;
     const float *row = P + (size_t)i * c;
@@ -564,26 +602,31 @@ __global__ __launch_bounds__(256) void knn_dup_hash_insert_kernel(int n_pad, int
         if (o == 0xFFFFFFFFu) {
             o = atomicCAS(T + s, 0xFFFFFFFFu, (uint32_t)i);
             if (o == 0xFFFFFFFFu)
-                return;
+                break;
         }
         if (knn_rows_equal(P + (size_t)o * c, row, c)) {
             atomicMin(T + s, (uint32_t)i);
-            return;
+            break;
         }
         s = (s + 1) & (uint32_t)(tsize - 1);
     }
+    }   // work items
 }
 __global__ __launch_bounds__(256) void knn_dup_hash_lookup_kernel(int n_pad, int c, int tsize,
                                                                   const float *__restrict__ points,
                                                                   const int32_t *__restrict__ n_arr,
                                                                   const uint32_t *__restrict__ table,
-                                                                  uint8_t *__restrict__ dup, uint32_t *__restrict__ uws)
+                                                                  uint8_t *__restrict__ dup, uint32_t *__restrict__ uws,
+                                                                  int bp, int nblk, int gate_word)
 {
-    const int b = blockIdx.y;
-    const int n = n_arr ? n_arr[b] : n_pad;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    if (gate_word >= 0 && uws[gate_word] == 0)
         return;
+    for (int w = blockIdx.x; w < bp * nblk; w += gridDim.x) {
+    const int b = w / nblk;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const int i = (w - b * nblk) * blockDim.x + threadIdx.x;
+    if (i >= n)
+        continue;
     const float *P = points + (size_t)b * n_pad * c;
     const uint32_t *T = table + (size_t)b * tsize;
     const float *row = P + (size_t)i * c;
@@ -604,6 +647,49 @@ __global__ __launch_bounds__(256) void knn_dup_hash_lookup_kernel(int n_pad, int
     dup[(size_t)b * n_pad + i] = d;
     if (d)
         uws[0] = 1u;
+    }   // work items
+}
+
+// cand[b, :count[b]] = ascending indices of the rows of point set b that are not duplicates
+__global__ __launch_bounds__(256) void knn_compact_kernel(int n_pad, const int32_t *__restrict__ n_arr,
+                                                          const uint8_t *__restrict__ dup,
+                                                          const uint32_t *__restrict__ uws,
+                                                          int32_t *__restrict__ cand, int32_t *__restrict__ count)
+{
+    __shared__ int wtot[4];
+    if (uws[0] == 0)
+        return;                 // nothing duplicated anywhere: the list is not consulted
+    const int b = blockIdx.x;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int i = j0 + threadIdx.x;
+        const bool keep = i < n && dup[(size_t)b * n_pad + i] == 0;
+        const unsigned long long mask = __ballot(keep);
+        const int below = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0)
+            wtot[wave] = __builtin_popcountll(mask);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w)
+            off += wtot[w];
+        if (keep)
+            cand[(size_t)b * n_pad + off + below] = i;
+        base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    }
+    if (threadIdx.x == 0)
+        count[b] = base;
+}
+
+__global__ __launch_bounds__(256) void knn_fill_gated_kernel(uint32_t *__restrict__ p, size_t words,
+                                                             const uint32_t *__restrict__ uws, int gate_word)
+{
+    if (uws[gate_word] == 0)
+        return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 0xFFFFFFFFu;
 }
 
 // grouped[b,q,t,:] = points[b, idx[b,q,t], :]
@@ -752,14 +838,17 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
     const tpu3_knn_layout L = layout ? *layout : tpu3_knn_layout{nullptr, nullptr, nullptr, nullptr, b, 1};
     KnnArgs a{m, n, c, k, b, 1, query, points, L.n_arr, L.m_arr, L.pts_of, L.grp, dup, uws, 0, 0, idx,
               idx_elem_size == 8, dist};
+    if ((L.cand == nullptr) != (L.cand_count == nullptr)) return TPU3_EINVAL;
     int r = -100;
     if (k <= 64 && c <= 32) {
         if (dup) {
             // optimistic pass (duplicates skipped + verified), then -- only if some query could not
             // verify -- max(D) and the reference arithmetic; both follow-ups early-exit on uws[1] == 0
             a.mode = 1;
+            a.cand = L.cand; a.cand_count = L.cand_count;
             r = dispatch_insert(s, b, a);
             if (r) return r;
+            a.cand = nullptr; a.cand_count = nullptr;
             KnnArgs d = a;
             d.mode = 0; d.gate = 1; d.dup = nullptr;
             r = launch_dmax(s, b, d, uws);
@@ -794,6 +883,64 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
 // dup/uws from tpu3_knn_unique_prepare_f32; when any row is duplicated the exact sorted kernels run
 // instead (device-side gate, no host synchronisation).  Supported: c <= 32, k in {17, 33}; other
 // sizes return TPU3_ELIMIT (callers then use tpu3_knn_f32).
+// Self kNN graph without a de-duplication pre-pass (see knn_graph_kernel, mode 2): x (b,n,c) is both
+// query and point set; dup (b,n) and uws are scratch owned by the call (uws is zeroed here); workspace
+// = tpu3_knn_unique_workspace_bytes(b, n) bytes for the (rarely needed) hash tables.
+extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
+                                       const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,
+                                       void *workspace, size_t workspace_bytes)
+{
+    if (bad_dims(b, n, n, c, k)) return TPU3_EINVAL;
+    if (c > 32 || (k != 17 && k != 33)) return TPU3_ELIMIT;
+    if (b == 0 || n == 0) return TPU3_OK;
+    if (k > n) return TPU3_EINVAL;
+    if (!x || !idx || !dup || !uws) return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    const tpu3_knn_layout L = layout ? *layout : tpu3_knn_layout{nullptr, nullptr, nullptr, nullptr, b, 1};
+    if (L.pts_of || L.n_arr || L.m_arr) return TPU3_EINVAL;      // dense self query only
+    const int groups = L.grp ? L.groups : 1;
+    const size_t need = tpu3_knn_unique_workspace_bytes(b, n);
+    if (need == 0 || !workspace || workspace_bytes < need) return TPU3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(uws, 0, (size_t)TPU3_KNN_UWS_WORDS(groups) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
+    KnnArgs a{n, n, c, k, b, 1, x, x, nullptr, nullptr, nullptr, L.grp, dup, uws, 2, 0, idx, 0, nullptr};
+    int threads = ((n + 63) / 64) * 64;
+    if (threads > 512) threads = 256;
+    const dim3 g((n + threads - 1) / threads, b);
+#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+    if (k == 33) {
+        if (c == 3) KG(3, 33); else if (c <= 8) KG(8, 33); else if (c <= 16) KG(16, 33);
+        else if (c <= 24) KG(24, 33); else KG(32, 33);
+    } else {
+        if (c == 3) KG(3, 17); else if (c <= 8) KG(8, 17); else if (c <= 16) KG(16, 17);
+        else if (c <= 24) KG(24, 17); else KG(32, 17);
+    }
+#undef KG
+    int r = tpu3_launch_status();
+    if (r) return r;
+    // everything below runs only if some query saw a zero distance to another row (uws[2])
+    const int tsize = knn_dup_table_size(n);
+    const int nblk = (n + 255) / 256;
+    long grid = (long)nblk * b;
+    if (grid > KNN_GATED_GRID) grid = KNN_GATED_GRID;
+    hipLaunchKernelGGL(knn_fill_gated_kernel, dim3(KNN_GATED_GRID), dim3(256), 0, s, (uint32_t *)workspace,
+                       need / sizeof(uint32_t), (const uint32_t *)uws, 2);
+    hipLaunchKernelGGL(knn_dup_hash_insert_kernel, dim3((unsigned)grid), dim3(256), 0, s, n, c, tsize, x, nullptr,
+                       (uint32_t *)workspace, b, nblk, (const uint32_t *)uws, 2);
+    hipLaunchKernelGGL(knn_dup_hash_lookup_kernel, dim3((unsigned)grid), dim3(256), 0, s, n, c, tsize, x, nullptr,
+                       (const uint32_t *)workspace, dup, uws, b, nblk, 2);
+    r = tpu3_launch_status();
+    if (r) return r;
+    // real duplicates (uws[0]): max(D) per group + the exact sorted kernel with the reference arithmetic
+    KnnArgs d = a;
+    d.mode = 0; d.gate = 0; d.dup = nullptr;
+    r = launch_dmax(s, b, d, uws);
+    if (r) return r;
+    a.mode = 0; a.gate = -1;
+    return dispatch_insert(s, b, a);
+}
+
 extern "C" int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
                                   const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
                                   uint32_t *uws, int32_t *idx)
@@ -832,6 +979,18 @@ extern "C" int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int
     return dispatch_insert(s, b, a);
 }
 
+extern "C" int tpu3_knn_unique_compact_i32(tpu3_stream_t stream, int bp, int n, const int32_t *n_arr,
+                                           const uint8_t *dup, const uint32_t *uws, int32_t *cand,
+                                           int32_t *cand_count)
+{
+    if (bp < 0 || n < 0) return TPU3_EINVAL;
+    if (bp == 0 || n == 0) return TPU3_OK;
+    if (!dup || !uws || !cand || !cand_count) return TPU3_EINVAL;
+    hipLaunchKernelGGL(knn_compact_kernel, dim3(bp), dim3(256), 0, (hipStream_t)stream, n, n_arr, dup, uws, cand,
+                       cand_count);
+    return tpu3_launch_status();
+}
+
 extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c,
                                            const float *query, const float *points,
                                            const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws,
@@ -865,10 +1024,12 @@ extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, i
     const int tsize = knn_dup_table_size(n);
     e = hipMemsetAsync(ws, 0xFF, need, s);
     if (e != hipSuccess) return (int)e;
-    const dim3 g((n + 255) / 256, bp);
-    hipLaunchKernelGGL(knn_dup_hash_insert_kernel, g, dim3(256), 0, s, n, c, tsize, points, L.n_arr, (uint32_t *)ws);
+    const int nblk = (n + 255) / 256;
+    const dim3 g((unsigned)((long)nblk * bp));
+    hipLaunchKernelGGL(knn_dup_hash_insert_kernel, g, dim3(256), 0, s, n, c, tsize, points, L.n_arr, (uint32_t *)ws,
+                       bp, nblk, (const uint32_t *)uws, -1);
     hipLaunchKernelGGL(knn_dup_hash_lookup_kernel, g, dim3(256), 0, s, n, c, tsize, points, L.n_arr,
-                       (const uint32_t *)ws, dup, uws);
+                       (const uint32_t *)ws, dup, uws, bp, nblk, -1);
     int r = tpu3_launch_status();
     if (own) {
         e = hipFreeAsync(ws, s);

@@ -32,6 +32,8 @@ struct SkipArgs {
     const void *idx;                 // (B,n,k)
     int idx64;
     float scale;                     // 0.2
+    int per_cloud;                   // patches per previous cloud when they are contiguous, else 0
+    int remap_blocks;                // blocks covered by the XCD-aware mapping (a multiple of 8 clouds)
 };
 
 __device__ __forceinline__ float block_sum256(float v, float *red)
@@ -52,7 +54,15 @@ __global__ __launch_bounds__(SK_THREADS) void skip_fused_kernel(SkipArgs a)
     float *df = ds + n * K;          // n*K feature distances
     int *nb = (int *)(df + n * K);   // n*K neighbour rows
     float *red = (float *)(nb + n * K);
-    const int b = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  All patches of one
+    // previous cloud gather from the same (de-duplicated: ~1.5 MB) slice of prev_feat, so they are
+    // sent to the same XCD: block i -> XCD i % 8 handles cloud (i % 8) + 8 * (slot / per_cloud).
+    int b = blockIdx.x;
+    if (b < a.remap_blocks) {
+        const int x = b & 7, slot = b >> 3;
+        const int cl = slot / a.per_cloud;
+        b = (x + 8 * cl) * a.per_cloud + (slot - cl * a.per_cloud);
+    }
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *XYZ = a.xyz + (size_t)b * n * 3;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(SK_THREADS) void skip_fused_kernel(SkipArgs a)
 extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
                                         float *feat, int feat_stride, const float *prev_xyz,
                                         const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
-                                        int idx_elem_size, float scale)
+                                        int idx_elem_size, float scale, int patches_per_cloud)
 {
     if (b < 0 || n <= 0 || k <= 0 || k > SK_KMAX || c <= 0 || c > 64 * SK_CPL || m <= 0) return TPU3_EINVAL;
     if (feat_stride < c || (idx_elem_size != 4 && idx_elem_size != 8)) return TPU3_EINVAL;
@@ -172,7 +182,10 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
     if (!xyz || !feat || !prev_xyz || !prev_feat || !idx) return TPU3_EINVAL;
     const size_t lds = ((size_t)3 * n * k + 16) * sizeof(float);
     if (lds > 150 * 1024) return TPU3_ELIMIT;
-    SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale};
+    int per = patches_per_cloud > 0 && b % patches_per_cloud == 0 ? patches_per_cloud : 0;
+    const int remap = per ? (b / per / 8) * 8 * per : 0;
+    SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale,
+               per, remap};
     hipError_t e = hipFuncSetAttribute((const void *)skip_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -29,6 +29,8 @@ class HipBackend(object):
 
     name = "hip-gfx950"
 
+    COMPACT_MIN_N = 1024      # unique=True: point sets this large get a first-occurrence list
+
     def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True):
         """query (B,M,C), points (Bp,N,C) f32 contiguous device tensors ->
         idx int64 (B,M,k), dist f32 (B,M,k) | None, grouped f32 (B,M,k,C) | None.
@@ -42,6 +44,7 @@ class HipBackend(object):
         if c2 != c:
             raise RuntimeError("group_knn: query/points channel mismatch (%d vs %d)" % (c, c2))
         lay_ref = None
+        lay = None
         keep = []
         groups = 1
         if layout is not None:
@@ -76,6 +79,18 @@ class HipBackend(object):
                 L.check(lib.tpu3_knn_unique_prepare_f32(s, b, m, n, c, L.ptr(query), L.ptr(points),
                                                         lay_ref, L.ptr(dup), L.ptr(uws), L.ptr(ws), need),
                         "tpu3_knn_unique_prepare_f32")
+                if n >= self.COMPACT_MIN_N and k <= 64 and c <= 32:
+                    # list of first occurrences: the search then skips the duplicated rows entirely
+                    cand = torch.empty((bp, n), dtype=torch.int32, device=dev)
+                    cand_count = torch.empty((bp,), dtype=torch.int32, device=dev)
+                    if lay is None:
+                        lay = L.KnnLayout()
+                        lay.bp, lay.groups = bp, 1
+                        lay_ref = ctypes.byref(lay)
+                    L.check(lib.tpu3_knn_unique_compact_i32(s, bp, n, lay.n_arr, L.ptr(dup), L.ptr(uws),
+                                                            L.ptr(cand), L.ptr(cand_count)),
+                            "tpu3_knn_unique_compact_i32")
+                    lay.cand, lay.cand_count = L.ptr(cand), L.ptr(cand_count)
             L.check(lib.tpu3_knn_f32(s, b, m, n, c, k, L.ptr(query), L.ptr(points), lay_ref, L.ptr(dup),
                                      L.ptr(uws), L.ptr(idx), 8, L.ptr(dist), L.ptr(grouped)),
                     "tpu3_knn_f32")
@@ -118,6 +133,12 @@ class HipBackend(object):
             s = L.stream_of(x)
             need = lib.tpu3_knn_unique_workspace_bytes(b, n)
             ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
+            dense = layout is None or all(layout.get(nm) is None for nm in ("n_arr", "m_arr", "pts_of"))
+            if need and dense:
+                # no de-duplication pre-pass: the kernel notices by itself whether one is needed
+                L.check(lib.tpu3_knn_graph_self_f32(s, b, n, c, k, L.ptr(x), lay_ref, L.ptr(dup), L.ptr(uws),
+                                                    L.ptr(idx), L.ptr(ws), need), "tpu3_knn_graph_self_f32")
+                return idx
             L.check(lib.tpu3_knn_unique_prepare_f32(s, b, n, n, c, L.ptr(x), L.ptr(x), lay_ref, L.ptr(dup),
                                                     L.ptr(uws), L.ptr(ws), need), "tpu3_knn_unique_prepare_f32")
             L.check(lib.tpu3_knn_graph_f32(s, b, n, n, c, k, L.ptr(x), L.ptr(x), lay_ref, L.ptr(dup), L.ptr(uws),
@@ -182,9 +203,10 @@ class HipBackend(object):
                 L.ptr(out), out.stride(1)), "tpu3_dense_edge_conv_f32")
         return out
 
-    def interlevel_skip(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2):
+    def interlevel_skip(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2, per_cloud=0):
         """Fused skip connection (inference): feat (B,N,C) is updated in place
-        (x_i += scale * sum_k w_k f_k with the reference's bilateral weights)."""
+        (x_i += scale * sum_k w_k f_k with the reference's bilateral weights).  per_cloud: patches
+        [i*per_cloud, (i+1)*per_cloud) share a previous cloud (scheduling hint, 0 = unknown)."""
         for t, nm in ((xyz, "xyz"), (feat, "feat"), (prev_xyz, "prev_xyz"), (prev_feat, "prev_feat")):
             L.require_device(t, nm)
             L.require_dtype(t, torch.float32, nm)
@@ -194,7 +216,8 @@ class HipBackend(object):
         with torch.cuda.device(feat.device):
             L.check(L.lib().tpu3_interlevel_skip_f32(
                 L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
-                L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale)),
+                L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale),
+                int(per_cloud)),
                 "tpu3_interlevel_skip_f32")
         return feat
 

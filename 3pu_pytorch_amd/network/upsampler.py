@@ -167,7 +167,7 @@ class Net(torch.nn.Module):
             norm_cl = norm.transpose(2, 1).contiguous()
             owner = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), P)
             up_cl, feat = level.forward_cl(
-                patch_cl, norm_cl, (old_xyz, old_feat, old_count), owner=owner, groups=B)
+                patch_cl, norm_cl, (old_xyz, old_feat, old_count), owner=owner, groups=B, per_owner=P)
             if self.trace is not None:
                 self.trace.append(dict(patch_xyz=patch_cl.transpose(2, 1), out_norm=up_cl.transpose(2, 1),
                                        patch_num=patch_num))
@@ -265,12 +265,13 @@ class Level(torch.nn.Module):
     # skip connection and the regressor (25 GB / 10 GB for the 15 360 level-4 patches of 8 clouds)
     max_patches = 4096
 
-    def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1):
+    def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):
         """Channel-last level; large batches are processed in chunks of whole owner groups (every
-        patch is independent apart from the per-group unique-max, so chunks are exact)."""
+        patch is independent apart from the per-group unique-max, so chunks are exact).
+        per_owner > 0: owner is `per_owner` consecutive patches per id (scheduling hint)."""
         B = xyz_normalized.size(0)
         if B <= self.max_patches or torch.is_grad_enabled():
-            return self._forward_cl(xyz, xyz_normalized, previous, owner, groups)
+            return self._forward_cl(xyz, xyz_normalized, previous, owner, groups, per_owner)
         if owner is None:
             bounds = list(range(0, B, self.max_patches)) + [B]
         else:
@@ -278,18 +279,22 @@ class Level(torch.nn.Module):
             per = B // groups if groups > 0 and B % groups == 0 else None
             if per is None or per > self.max_patches:
                 bounds = list(range(0, B, self.max_patches)) + [B]
+                per_owner = 0
             else:
-                step = (self.max_patches // per) * per
+                owners = self.max_patches // per
+                if owners > 8:
+                    owners -= owners % 8        # whole sets of 8 clouds: one per XCD (skip kernel)
+                step = owners * per
                 bounds = list(range(0, B, step)) + [B]
         outs, feats = [], []
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             own = None if owner is None else owner[lo:hi].contiguous()
-            o, f = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups)
+            o, f = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups, per_owner)
             outs.append(o)
             feats.append(f)
         return torch.cat(outs, dim=0), torch.cat(feats, dim=0)
 
-    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1):
+    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):
         """Channel-last level:
             xyz, xyz_normalized  (B,N,3)
             previous             None or (prev_xyz (Bp,M,3), prev_feat (Bp,M,C), prev_count (Bp,)|None)
@@ -348,7 +353,7 @@ class Level(torch.nn.Module):
             if fused:
                 operations.BACKEND.interlevel_skip(
                     xyz.contiguous(), x, prev_xyz.contiguous(), prev_feat.contiguous(),
-                    None if pts_of is None else layout["pts_of"], knn_idx)
+                    None if pts_of is None else layout["pts_of"], knn_idx, per_cloud=per_owner)
                 return self._regress(x, xyz_normalized, B, N)
             bsel = (torch.arange(B, device=xyz.device) if pts_of is None else pts_of).view(-1, 1, 1)
             knn_feats = prev_feat[bsel, knn_idx]                              # (B,N,K,C)

@@ -118,6 +118,11 @@ typedef struct {
     const int32_t *grp;
     int bp;
     int groups;
+    /* optional, unique=True only: per point set the ascending indices of its first occurrences
+     * (bp,n) and their number (bp), from tpu3_knn_unique_compact_i32.  tpu3_knn_f32 then visits
+     * only those rows (same result; the merged cloud of overlapping patches holds every point ~5x). */
+    const int32_t *cand;
+    const int32_t *cand_count;
 } tpu3_knn_layout;
 
 /* Number of u32 words of the unique=True scratch `uws` for `groups` groups (>= 1). */
@@ -153,6 +158,15 @@ int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, 
                        const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
                        uint32_t *uws, int32_t *idx);
 
+/* The same graph for a SELF query (x is both query and point set) without a de-duplication
+ * pre-pass: identical rows have D == 0 exactly, so the kernel itself notices whether any row could
+ * be duplicated; only then the hash de-duplication and the exact kernels run (device-side gates).
+ * dup (b,n) u8 and uws (TPU3_KNN_UWS_WORDS(groups) u32) are scratch; workspace =
+ * tpu3_knn_unique_workspace_bytes(b, n) bytes (n >= 128). */
+int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
+                            const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,
+                            void *workspace, size_t workspace_bytes);
+
 /* unique=True pre-pass: dup (bp,n) u8 = 1 iff an identical row exists at a smaller index of
  * the same point set (complement of np.unique(axis=0, return_index=True), operations.py:194-200).
  * O(n) per point set (open-addressing table of class representatives) above 1024 points,
@@ -166,6 +180,13 @@ int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, int n, int c
                                 const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws,
                                 void *workspace, size_t workspace_bytes);
 size_t tpu3_knn_unique_workspace_bytes(int bp, int n);
+
+/* Candidate list of a de-duplicated point set batch (see tpu3_knn_layout.cand): cand (bp,n) i32,
+ * cand_count (bp) i32 from dup/uws of tpu3_knn_unique_prepare_f32; n_arr (bp) live sizes or NULL.
+ * Left untouched (and never consulted) when no row is duplicated at all (uws[0] == 0). */
+int tpu3_knn_unique_compact_i32(tpu3_stream_t stream, int bp, int n, const int32_t *n_arr,
+                                const uint8_t *dup, const uint32_t *uws, int32_t *cand,
+                                int32_t *cand_count);
 
 /* Fused DenseEdgeConv block, inference (network/layers.py:44-64 for in_channels 24, growth 12,
  * 3 dense layers -- the configuration of every Level, network/upsampler.py:210-223):
@@ -188,11 +209,13 @@ int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, co
  * xyz (b,n,3) patch coordinates; feat (b,n,feat_stride) in/out, the first c channels are x_i;
  * prev_xyz (bp,m,3), prev_feat (bp,m,c) previous level's merged cloud; pts_of (b) i32 maps a patch
  * to its previous cloud (NULL = identity); idx (b,n,k) i32/i64 neighbour rows (from tpu3_knn_f32,
- * k <= 8, c <= 320).  Nothing of size (b,n,k,c) is materialised. */
+ * k <= 8, c <= 320).  Nothing of size (b,n,k,c) is materialised.  patches_per_cloud > 0 states
+ * that patches [i*ppc, (i+1)*ppc) share previous cloud pts_of[i*ppc] (a scheduling hint that keeps a
+ * cloud's gathers in one XCD's L2; the result does not depend on it), 0 = unknown. */
 int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
                              float *feat, int feat_stride, const float *prev_xyz,
                              const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
-                             int idx_elem_size, float scale);
+                             int idx_elem_size, float scale, int patches_per_cloud);
 
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */

@@ -333,16 +333,18 @@ def test_knn_graph_is_the_exact_topk_set(orc, dev, b, n, c, k, dups):
         assert (np.diff(idx[:, :, 1:], axis=-1) > 0).all()
 
 
-def test_knn_layout_shared_points_groups_and_ragged(orc, dev):
+@pytest.mark.parametrize("n", [700, 1500])
+def test_knn_layout_shared_points_groups_and_ragged(orc, dev, n):
     """One launch that fuses several reference calls: query sets map onto shared point sets
-    (pts_of), max(D) is kept per group, and point/query counts are ragged."""
+    (pts_of), max(D) is kept per group, and point/query counts are ragged.  n = 1500 also takes
+    the compacted first-occurrence candidate list (tpu3_knn_unique_compact_i32)."""
     ops = pkg("network.operations")
     rng = np.random.default_rng(5)
-    bp, n, c, k, m = 3, 700, 3, 5, 312
+    bp, c, k, m = 3, 3, 5, 312
     pts = sphere(1, n, bp)
-    pts[0, 350:] = pts[0, :350]                      # point set 0 has duplicates
-    pts[2, 600:] = pts[2, :100]
-    n_arr = np.array([700, 650, 700], np.int32)
+    pts[0, n // 2:] = pts[0, :n - n // 2]            # point set 0 has duplicates
+    pts[2, n - 100:] = pts[2, :100]
+    n_arr = np.array([n, n - 50, n], np.int32)
     pts_of = np.array([0, 0, 1, 1, 1, 2], np.int32)
     grp = pts_of.copy()
     b = len(pts_of)
