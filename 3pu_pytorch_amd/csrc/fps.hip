@@ -16,14 +16,30 @@
 //     slot order already yields the lane's winner; waves then reduce (distance, tie key).
 #include "tpu3_dev.h"
 
+#include <cstdlib>
+
 // fps_bucket.hip: exact work-skipping kernel for point sets beyond the register-resident limit
 size_t tpu3_fps_bucket_workspace_bytes(int b, int n);
-int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
-                           void *workspace, size_t workspace_bytes);
+int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32_t *m_arr,
+                           const float *xyz, float *temp, int32_t *idx, void *workspace, size_t workspace_bytes);
 
 namespace {
 
 constexpr int FPS_RESIDENT_MAX = 25600;
+
+// Point sets of at least this size whose sample count is large enough go to the bucketed kernel even
+// though they would fit the register-resident one: 4 waves per element instead of 16, so a whole
+// batch of patches-per-cloud sets runs concurrently, and the pruning skips most of every round.
+// TPU3_FPS_BUCKET_MIN_N overrides the default (tuning knob; results are identical either way).
+int fps_bucket_min_n()
+{
+    static const int v = [] {
+        const char *e = getenv("TPU3_FPS_BUCKET_MIN_N");
+        return e ? atoi(e) : 16384;
+    }();
+    return v;
+}
+constexpr int FPS_BUCKET_MIN_M = 256;
 
 struct FpsArgs {
     int n, m;                 // padded sizes (strides)
@@ -177,7 +193,7 @@ int launch_resident(hipStream_t s, int b, const FpsArgs &a)
 
 extern "C" size_t tpu3_fps_workspace_bytes(int b, int n)
 {
-    if (b <= 0 || n <= FPS_RESIDENT_MAX)
+    if (b <= 0 || (n <= FPS_RESIDENT_MAX && n < fps_bucket_min_n()))
         return 0;
     return tpu3_fps_bucket_workspace_bytes(b, n);
 }
@@ -196,6 +212,20 @@ extern "C" int tpu3_fps_ragged_f32(tpu3_stream_t stream, int b, int n, int m, co
     FpsArgs a{n, m, n_arr, m_arr, xyz, temp, idx};
     // W must be a multiple of bs = min(512, 2^floor(log2 n)) (tie rule, see header comment):
     // n < 512 -> bs <= 256 -> W = 256; otherwise W >= 512.
+    if (n > FPS_RESIDENT_MAX || (n >= fps_bucket_min_n() && m >= FPS_BUCKET_MIN_M)) {
+        // Morton buckets + exact pruning (fps_bucket.hip)
+        const size_t need = tpu3_fps_bucket_workspace_bytes(b, n);
+        if (need) {
+            if (workspace && workspace_bytes >= need)
+                return tpu3_fps_bucket_launch(s, b, n, m, n_arr, m_arr, xyz, temp, idx, workspace, workspace_bytes);
+            void *ws = nullptr;                 // caller gave no scratch: stream-ordered allocation
+            hipError_t e = hipMallocAsync(&ws, need, s);
+            if (e != hipSuccess) return (int)e;
+            const int r = tpu3_fps_bucket_launch(s, b, n, m, n_arr, m_arr, xyz, temp, idx, ws, need);
+            e = hipFreeAsync(ws, s);
+            return r ? r : (int)e;
+        }
+    }
     if (n <= 256) return launch_resident<256, 1>(s, b, a);
     if (n < 512) return launch_resident<256, 2>(s, b, a);
     if (n <= 1024) return launch_resident<512, 2>(s, b, a);
@@ -208,20 +238,6 @@ extern "C" int tpu3_fps_ragged_f32(tpu3_stream_t stream, int b, int n, int m, co
     if (n <= 16384) return launch_resident<1024, 16>(s, b, a);
     if (n <= 20480) return launch_resident<1024, 20>(s, b, a);
     if (n <= FPS_RESIDENT_MAX) return launch_resident<1024, 25>(s, b, a);
-    if (!n_arr && !m_arr) {
-        // large dense sets: Morton buckets + exact pruning (fps_bucket.hip)
-        const size_t need = tpu3_fps_bucket_workspace_bytes(b, n);
-        if (need) {
-            if (workspace && workspace_bytes >= need)
-                return tpu3_fps_bucket_launch(s, b, n, m, xyz, temp, idx, workspace, workspace_bytes);
-            void *ws = nullptr;                 // caller gave no scratch: stream-ordered allocation
-            hipError_t e = hipMallocAsync(&ws, need, s);
-            if (e != hipSuccess) return (int)e;
-            const int r = tpu3_fps_bucket_launch(s, b, n, m, xyz, temp, idx, ws, need);
-            e = hipFreeAsync(ws, s);
-            return r ? r : (int)e;
-        }
-    }
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, s, a);
     return tpu3_launch_status();
 }

@@ -37,16 +37,45 @@ namespace {
 
 constexpr int FB_GS = 16;        // buckets per group = lanes per DPP row
 
+// Arguments of batch element 0; fb_elem() derives element i.  User arrays are dense (b, n, ...)
+// slabs, the per-element workspace arrays repeat every `per_elem` bytes, the sort arrays every
+// `sort_stride` words.
 struct FbArgs {
-    int n, m, nb, nbpad, npad, ng;
+    int n, m, nb, nbpad, npad, ng;      // n, m: slab strides = upper bounds of the live sizes
+    int bsz, lb;                        // points per bucket; log2 of the tie-rule block size
+    const int32_t *n_arr, *m_arr;       // live sizes per element, or null
     const float *xyz;     // (n,3) original order
     float *temp;          // (n)
     int32_t *idx;         // (m)
     float4 *sp;           // (npad) Morton order: x, y, z, running distance
     uint32_t *skey;       // (npad) tie key of the original index (0xFFFFFFFF = padding)
     uint32_t *ib;         // (8, nbpad) initial bucket table: max, key, x, y, z, box0, box1, box2
+    float *bbox;          // (8)
+    size_t per_elem;
+    size_t sort_stride;
     unsigned long long *prof;   // PROF builds only
 };
+
+// element i of the batch: pointers advanced, n / m / nb / lb replaced by the element's live values
+__device__ __forceinline__ FbArgs fb_elem(const FbArgs &a0, int i)
+{
+    FbArgs a = a0;
+    a.xyz = a0.xyz + (size_t)i * a0.n * 3;
+    a.temp = a0.temp + (size_t)i * a0.n;
+    a.idx = a0.idx + (size_t)i * a0.m;
+    a.sp = (float4 *)((char *)a0.sp + (size_t)i * a0.per_elem);
+    a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * a0.per_elem);
+    a.ib = (uint32_t *)((char *)a0.ib + (size_t)i * a0.per_elem);
+    a.bbox = (float *)((char *)a0.bbox + (size_t)i * a0.per_elem);
+    if (a0.n_arr) {
+        a.n = min(max(a0.n_arr[i], 0), a0.n);
+        a.nb = (a.n + a0.bsz - 1) / a0.bsz;
+        a.lb = tpu3_fps_log2_bs(a.n);
+    }
+    if (a0.m_arr)
+        a.m = min(max(a0.m_arr[i], 0), a0.m);
+    return a;
+}
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
 {
@@ -59,9 +88,13 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 }
 
 // bounding box of one cloud -> bbox[6] = lo.xyz, hi.xyz
-__global__ __launch_bounds__(1024) void fb_bbox_kernel(int n, const float *__restrict__ xyz, float *__restrict__ bbox)
+__global__ __launch_bounds__(1024) void fb_bbox_kernel(FbArgs a0)
 {
     __shared__ float red[6][16];
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    const int n = a.n;
+    const float *__restrict__ xyz = a.xyz;
+    float *__restrict__ bbox = a.bbox;
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (int i = threadIdx.x; i < n; i += blockDim.x)
@@ -86,13 +119,23 @@ __global__ __launch_bounds__(1024) void fb_bbox_kernel(int n, const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void fb_morton_kernel(int n, const float *__restrict__ xyz,
-                                                        const float *__restrict__ bbox,
-                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+__global__ __launch_bounds__(256) void fb_morton_kernel(FbArgs a0, uint32_t *__restrict__ keys0,
+                                                        uint32_t *__restrict__ vals0)
 {
+    const FbArgs a = fb_elem(a0, blockIdx.y);
+    const int n = a.n;
+    const float *__restrict__ xyz = a.xyz;
+    const float *__restrict__ bbox = a.bbox;
+    uint32_t *__restrict__ keys = keys0 + (size_t)blockIdx.y * a0.sort_stride;
+    uint32_t *__restrict__ vals = vals0 + (size_t)blockIdx.y * a0.sort_stride;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    if (i >= a0.n)
         return;
+    if (i >= n) {               // slot beyond a ragged element's live size: sorts behind every point
+        keys[i] = 0x40000000u;
+        vals[i] = (uint32_t)i;
+        return;
+    }
     uint32_t code = 0;
     for (int a = 0; a < 3; ++a) {
         const float lo = bbox[a], ext = bbox[3 + a] - lo;
@@ -105,10 +148,13 @@ __global__ __launch_bounds__(256) void fb_morton_kernel(int n, const float *__re
 }
 
 // Morton-ordered float4 (x,y,z,temp) + tie keys; slots past n repeat the last live point with temp = -1
-__global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a, const uint32_t *__restrict__ order, int lb)
+__global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32_t *__restrict__ order0)
 {
+    const FbArgs a = fb_elem(a0, blockIdx.y);
+    const uint32_t *__restrict__ order = order0 + (size_t)blockIdx.y * a0.sort_stride;
+    const int lb = a.lb;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.npad)
+    if (i >= a.npad || a.n <= 0)
         return;
     const bool live = i < a.n;
     const uint32_t o = order[live ? i : a.n - 1];
@@ -117,11 +163,12 @@ __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a, const uint32_
     a.skey[i] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a, int lb)
+__global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a0)
 {
+    const FbArgs a = fb_elem(a0, blockIdx.y);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n)
-        a.temp[tpu3_fps_tiekey_to_index(a.skey[i], lb)] = a.sp[i].w;
+    if (i < a.n && a.m > 0)
+        a.temp[tpu3_fps_tiekey_to_index(a.skey[i], a.lb)] = a.sp[i].w;
 }
 
 // lane-local best of one bucket (64*PPL points), optionally after folding sample q into it
@@ -183,8 +230,9 @@ __device__ __forceinline__ void fb_store(const FbBucket<PPL> &b, float4 *__restr
 // initial bucket table (one wave per bucket, whole GPU): max / key / xyz and the fp16 box, rounded
 // outward so that it still contains every point
 template <int PPL>
-__global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a)
+__global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a0)
 {
+    const FbArgs a = fb_elem(a0, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int beta = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (beta >= a.nbpad)
@@ -246,20 +294,6 @@ struct FbSlots {        // cross-wave hand-off, up to 8 waves
     float x[2][8], y[2][8], z[2][8];
 };
 
-// arguments of batch element i from those of element 0: user arrays are dense (b, n, ...) slabs,
-// workspace arrays repeat every `per_elem` bytes
-__host__ __device__ inline FbArgs fb_elem(const FbArgs &a0, size_t per_elem, int i)
-{
-    FbArgs a = a0;
-    a.xyz = a0.xyz + (size_t)i * a0.n * 3;
-    a.temp = a0.temp + (size_t)i * a0.n;
-    a.idx = a0.idx + (size_t)i * a0.m;
-    a.sp = (float4 *)((char *)a0.sp + (size_t)i * per_elem);
-    a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * per_elem);
-    a.ib = (uint32_t *)((char *)a0.ib + (size_t)i * per_elem);
-    return a;
-}
-
 // LDS bytes of the main kernel: 8 words per bucket, 11 per group-table entry, the slots
 constexpr size_t fb_lds_bytes(int nbpad, int nw, int ngpt)
 {
@@ -267,13 +301,15 @@ constexpr size_t fb_lds_bytes(int nbpad, int nw, int ngpt)
 }
 
 template <int NW, int NGPT, int PPL, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0, size_t per_elem, int lb)
+__global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
 {
     constexpr int W = NW * 64;
     constexpr int GT = NGPT * W;                    // group-table entries (owner order)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FbArgs a = fb_elem(a0, per_elem, blockIdx.x);
-    const int nbpad = a.nbpad, ng = a.ng;
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    const int nbpad = a.nbpad, ng = a.ng, lb = a.lb;
+    if (a.n <= 0 || a.m <= 0)
+        return;
     // bucket table, indexed by bucket id (a DPP row reads 16 consecutive children)
     int *t_max = (int *)smem;
     uint32_t *t_key = (uint32_t *)(t_max + nbpad);
@@ -507,14 +543,25 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FbPlan {
     int ppl, nw, ngpt, nb, nbpad, npad, ng;
+    bool segmented;       // one segmented sort for the batch instead of a device sort per element
     size_t ks, ps, bs;    // byte sizes: key array, per-point float array, bucket word array
-    size_t per_elem;      // bytes of one batch element's arrays
+    size_t per_elem;      // bytes of one batch element's arrays (sp, skey, ib, bbox)
+    size_t sort_bytes;    // 4 key/value arrays x b
     size_t sort_temp;     // rocPRIM temporary storage
     size_t total;
 };
 
 constexpr int FB_NW = 4;            // waves per workgroup (one per SIMD)
 constexpr int FB_NB_MAX = 4096;     // buckets: 32 B of LDS each
+constexpr int FB_SORT_BITS = 31;    // 30 Morton bits + the dead-slot bit of ragged elements
+
+// segment i of the batch-wide sort arrays: [i * stride, i * stride + n)
+struct FbSegOffset {
+    unsigned int stride, add;
+    __host__ __device__ unsigned int operator()(unsigned int i) const { return i * stride + add; }
+};
+using FbCount = rocprim::counting_iterator<unsigned int>;
+using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 
 bool fb_plan(int b, int n, FbPlan &p)
 {
@@ -536,17 +583,29 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.ks = align256(sizeof(uint32_t) * (size_t)n);
     p.ps = align256(sizeof(float) * (size_t)p.npad);
     p.bs = align256(sizeof(uint32_t) * (size_t)p.nbpad);
-    p.per_elem = 4 * p.ks + 5 * p.ps + 8 * p.bs + align256(8 * sizeof(float));
+    p.per_elem = 5 * p.ps + 8 * p.bs + align256(8 * sizeof(float));
+    p.sort_bytes = 4 * p.ks * (size_t)b;
+    p.segmented = b >= 4 && n <= 65536 && (size_t)b * (p.ks / 4) < 0x7FFFFFFFu;
     size_t tb = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                    (uint32_t *)nullptr, (size_t)n, 0, 30, (hipStream_t)0);
+    if (p.segmented) {
+        const unsigned int stride = (unsigned int)(p.ks / 4);
+        const FbOffsetIt bi(FbCount(0), FbSegOffset{stride, 0u});
+        const FbOffsetIt ei(FbCount(0), FbSegOffset{stride, (unsigned int)n});
+        (void)rocprim::segmented_radix_sort_pairs(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                  (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                  (unsigned int)((size_t)b * stride), (unsigned int)b, bi, ei, 0,
+                                                  FB_SORT_BITS, (hipStream_t)0);
+    } else {
+        (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                        (uint32_t *)nullptr, (size_t)n, 0, FB_SORT_BITS, (hipStream_t)0);
+    }
     p.sort_temp = align256(tb);
-    p.total = (size_t)b * p.per_elem + p.sort_temp;
+    p.total = p.sort_bytes + (size_t)b * p.per_elem + p.sort_temp;
     return true;
 }
 
 template <int PPL, bool PROF>
-int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p, int lb)
+int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
 {
     if (p.ngpt != 1)
         return TPU3_ELIMIT;
@@ -555,67 +614,85 @@ int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p, int 
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(FB_NW * 64), lds, s, a0, p.per_elem, lb);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(FB_NW * 64), lds, s, a0);
     return tpu3_launch_status();
 }
 
-int fb_run(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx, void *workspace,
-           size_t workspace_bytes, unsigned long long *prof)
+int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32_t *m_arr, const float *xyz,
+           float *temp, int32_t *idx, void *workspace, size_t workspace_bytes, unsigned long long *prof)
 {
     FbPlan p;
     if (!fb_plan(b, n, p))
         return TPU3_ELIMIT;
     if (!workspace || workspace_bytes < p.total)
         return TPU3_EINVAL;
+    if (b > 65535)
+        return TPU3_ELIMIT;
     char *base = (char *)workspace;
-    char *sort_tmp = base + (size_t)b * p.per_elem;
-    const int lb = tpu3_fps_log2_bs(n);
+    // workspace: [k_in | k_out | v_in | v_out] (b x ks each), b element slabs, sort temp
+    uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + (size_t)b * p.ks);
+    uint32_t *v_in = (uint32_t *)(base + 2 * (size_t)b * p.ks), *v_out = (uint32_t *)(base + 3 * (size_t)b * p.ks);
+    char *slabs = base + p.sort_bytes;
+    char *sort_tmp = slabs + (size_t)b * p.per_elem;
     FbArgs a0;
     a0.n = n; a0.m = m; a0.nb = p.nb; a0.nbpad = p.nbpad; a0.npad = p.npad; a0.ng = p.ng;
+    a0.bsz = 64 * p.ppl; a0.lb = tpu3_fps_log2_bs(n);
+    a0.n_arr = n_arr; a0.m_arr = m_arr;
     a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = prof;
-    char *q0 = base + 4 * p.ks;
-    a0.sp = (float4 *)q0;
-    a0.skey = (uint32_t *)(q0 + 4 * p.ps);
-    a0.ib = (uint32_t *)(q0 + 5 * p.ps);
-    for (int i = 0; i < b; ++i) {
-        char *e = base + (size_t)i * p.per_elem;
-        uint32_t *k_in = (uint32_t *)e, *k_out = (uint32_t *)(e + p.ks);
-        uint32_t *v_in = (uint32_t *)(e + 2 * p.ks), *v_out = (uint32_t *)(e + 3 * p.ks);
-        float *bbox = (float *)(e + 4 * p.ks + 5 * p.ps + 8 * p.bs);
-        const FbArgs a = fb_elem(a0, p.per_elem, i);
-        hipLaunchKernelGGL(fb_bbox_kernel, dim3(1), dim3(1024), 0, s, n, a.xyz, bbox);
-        hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, a.xyz, bbox, k_in, v_in);
-        size_t tb = p.sort_temp;
-        hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 30, s);
+    a0.sp = (float4 *)slabs;
+    a0.skey = (uint32_t *)(slabs + 4 * p.ps);
+    a0.ib = (uint32_t *)(slabs + 5 * p.ps);
+    a0.bbox = (float *)(slabs + 5 * p.ps + 8 * p.bs);
+    a0.per_elem = p.per_elem;
+    a0.sort_stride = p.ks / 4;
+
+    hipLaunchKernelGGL(fb_bbox_kernel, dim3(b), dim3(1024), 0, s, a0);
+    hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0, k_in, v_in);
+    size_t tb = p.sort_temp;
+    if (p.segmented) {
+        const unsigned int stride = (unsigned int)a0.sort_stride;
+        const FbOffsetIt bi(FbCount(0), FbSegOffset{stride, 0u});
+        const FbOffsetIt ei(FbCount(0), FbSegOffset{stride, (unsigned int)n});
+        const hipError_t se = rocprim::segmented_radix_sort_pairs((void *)sort_tmp, tb, k_in, k_out, v_in, v_out,
+                                                                  (unsigned int)((size_t)b * stride), (unsigned int)b,
+                                                                  bi, ei, 0, FB_SORT_BITS, s);
         if (se != hipSuccess)
             return (int)se;
-        hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256), dim3(256), 0, s, a, v_out, lb);
-        const dim3 gi((p.nbpad + 3) / 4);
-        switch (p.ppl) {
-        case 1: hipLaunchKernelGGL(fb_bucket_init_kernel<1>, gi, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(fb_bucket_init_kernel<2>, gi, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(fb_bucket_init_kernel<4>, gi, dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(fb_bucket_init_kernel<8>, gi, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(fb_bucket_init_kernel<16>, gi, dim3(256), 0, s, a); break;
+    } else {
+        for (int i = 0; i < b; ++i) {
+            const size_t o = (size_t)i * a0.sort_stride;
+            tb = p.sort_temp;
+            const hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k_in + o, k_out + o, v_in + o,
+                                                            v_out + o, (size_t)n, 0, FB_SORT_BITS, s);
+            if (se != hipSuccess)
+                return (int)se;
         }
+    }
+    hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
+    const dim3 gi((p.nbpad + 3) / 4, b);
+    switch (p.ppl) {
+    case 1: hipLaunchKernelGGL(fb_bucket_init_kernel<1>, gi, dim3(256), 0, s, a0); break;
+    case 2: hipLaunchKernelGGL(fb_bucket_init_kernel<2>, gi, dim3(256), 0, s, a0); break;
+    case 4: hipLaunchKernelGGL(fb_bucket_init_kernel<4>, gi, dim3(256), 0, s, a0); break;
+    case 8: hipLaunchKernelGGL(fb_bucket_init_kernel<8>, gi, dim3(256), 0, s, a0); break;
+    default: hipLaunchKernelGGL(fb_bucket_init_kernel<16>, gi, dim3(256), 0, s, a0); break;
     }
     int r;
     if (prof) {
         if (p.ppl != 1) return TPU3_EINVAL;
-        r = fb_launch_main<1, true>(s, b, a0, p, lb);
+        r = fb_launch_main<1, true>(s, b, a0, p);
     } else {
         switch (p.ppl) {
-        case 1: r = fb_launch_main<1, false>(s, b, a0, p, lb); break;
-        case 2: r = fb_launch_main<2, false>(s, b, a0, p, lb); break;
-        case 4: r = fb_launch_main<4, false>(s, b, a0, p, lb); break;
-        case 8: r = fb_launch_main<8, false>(s, b, a0, p, lb); break;
-        default: r = fb_launch_main<16, false>(s, b, a0, p, lb); break;
+        case 1: r = fb_launch_main<1, false>(s, b, a0, p); break;
+        case 2: r = fb_launch_main<2, false>(s, b, a0, p); break;
+        case 4: r = fb_launch_main<4, false>(s, b, a0, p); break;
+        case 8: r = fb_launch_main<8, false>(s, b, a0, p); break;
+        default: r = fb_launch_main<16, false>(s, b, a0, p); break;
         }
     }
     if (r)
         return r;
-    for (int i = 0; i < b; ++i)
-        hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fb_elem(a0, p.per_elem, i), lb);
+    hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);
     return tpu3_launch_status();
 }
 
@@ -627,11 +704,12 @@ size_t tpu3_fps_bucket_workspace_bytes(int b, int n)
     return fb_plan(b, n, p) ? p.total : 0;
 }
 
-// Dense batch (no ragged sizes).  Returns TPU3_ELIMIT when n is beyond the bucket plan.
-int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
-                           void *workspace, size_t workspace_bytes)
+// n_arr / m_arr: live sizes per element (device, may be null).  Returns TPU3_ELIMIT when n is beyond
+// the bucket plan.
+int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32_t *m_arr,
+                           const float *xyz, float *temp, int32_t *idx, void *workspace, size_t workspace_bytes)
 {
-    return fb_run(s, b, n, m, xyz, temp, idx, workspace, workspace_bytes, nullptr);
+    return fb_run(s, b, n, m, n_arr, m_arr, xyz, temp, idx, workspace, workspace_bytes, nullptr);
 }
 
 // Development probe (not part of include/tpu3.h): the same kernel with per-phase cycle counters;
@@ -640,5 +718,5 @@ extern "C" int tpu3_debug_fps_bucket_profile(void *stream, int n, int m, const f
                                              int32_t *idx, void *workspace, size_t workspace_bytes,
                                              unsigned long long *prof)
 {
-    return fb_run((hipStream_t)stream, 1, n, m, xyz, temp, idx, workspace, workspace_bytes, prof);
+    return fb_run((hipStream_t)stream, 1, n, m, nullptr, nullptr, xyz, temp, idx, workspace, workspace_bytes, prof);
 }

@@ -213,11 +213,13 @@ class HipBackend(object):
         L.require_device(idx, "idx")
         B, N, C = feat.shape
         K = idx.size(2)
+        need = L.lib().tpu3_interlevel_skip_workspace_bytes(B, N, K)
+        ws = torch.empty((need,), dtype=torch.uint8, device=feat.device)
         with torch.cuda.device(feat.device):
             L.check(L.lib().tpu3_interlevel_skip_f32(
                 L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
                 L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale),
-                int(per_cloud)),
+                int(per_cloud), L.ptr(ws), need),
                 "tpu3_interlevel_skip_f32")
         return feat
 

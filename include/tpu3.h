@@ -215,7 +215,11 @@ int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, co
 int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
                              float *feat, int feat_stride, const float *prev_xyz,
                              const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
-                             int idx_elem_size, float scale, int patches_per_cloud);
+                             int idx_elem_size, float scale, int patches_per_cloud, void *workspace,
+                             size_t workspace_bytes);
+/* scratch of the call above ((2k+2) floats per point); workspace may be NULL (stream-ordered
+ * allocation inside) */
+size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */

@@ -72,8 +72,8 @@ def test_fps_bucketed_continues_from_given_temp(orc, dev):
     np.testing.assert_array_equal(temp.cpu().numpy(), t2)
 
 
-def test_fps_streaming_kernel_large_ragged(orc, dev):
-    """Ragged batches beyond the resident limit fall back to the streaming kernel."""
+def test_fps_bucketed_large_ragged(orc, dev):
+    """Ragged batches beyond the resident limit: the bucketed kernel with per-element live sizes."""
     ops = pkg("network.operations")
     n, m = 30000, 300
     xyz = sphere(7, n, 2)
@@ -82,6 +82,36 @@ def test_fps_streaming_kernel_large_ragged(orc, dev):
     for i in range(2):
         ref_idx, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], m)
         np.testing.assert_array_equal(idx[i], ref_idx[0])
+
+
+@pytest.mark.parametrize("b,n,m", [(7, 24960, 2496), (5, 17000, 300)])
+def test_fps_bucketed_batched_segmented_sort_ragged(orc, dev, b, n, m):
+    """The per-level resample of a batch of merged patch sets (n >= 16384, m >= 256): one batched
+    setup (segmented Morton sort) + one bucket-kernel launch for all elements, with ragged point
+    AND sample counts, an empty element and a tiny one; indices and temp bit-exact per element."""
+    ops, L = pkg("network.operations"), pkg("_lib")
+    xyz = sphere(11 + n, n, b)
+    n_arr = np.array([n, n - 312, n - 1, 700, 0, n - 5000, n][:b], np.int32)
+    m_arr = np.array([m, m - 1, m // 2, 300, 5, 1, m][:b], np.int32)
+    x = _t(xyz, dev)
+    idx = ops.fps(x, m, _t(n_arr, dev), _t(m_arr, dev)).cpu().numpy()
+    for i in range(b):
+        if n_arr[i] == 0:
+            continue
+        ref_idx, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], int(m_arr[i]))
+        np.testing.assert_array_equal(idx[i, :m_arr[i]], ref_idx[0])
+    # dense batch through the C ABI: temp comes back in the original order
+    lib = L.lib()
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    out = torch.zeros((b, m), dtype=torch.int32, device=dev)
+    need = lib.tpu3_fps_workspace_bytes(b, n)
+    assert need > 0
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    L.check(lib.tpu3_fps_ragged_f32(L.stream_of(x), b, n, m, None, None, L.ptr(x), L.ptr(temp), L.ptr(out),
+                                    L.ptr(ws), need), "tpu3_fps_ragged_f32")
+    ref_idx, ref_temp = orc.fps(xyz, m)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
 
 
 @pytest.mark.parametrize("n", [300, 700, 3000])

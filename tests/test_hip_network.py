@@ -92,7 +92,14 @@ def test_net_eval_batched_equals_single_on_device(dev):
     # identical kernels and identical inputs per patch; the GEMMs see different batch sizes, so
     # allow rounding-level differences in the values and demand the same point sets
     assert together.shape == single.shape == (5, 3, 2496)
-    assert ((together - single).abs().amax(dim=1) <= 1e-5).float().mean() > 0.93
+    # (a flipped near-tie in a kNN choice perturbs the rest of THAT patch: most patches must agree to
+    # rounding, and none may differ by more than such a perturbation)
+    diff = (together - single).abs().amax(dim=1)                    # (5, 2496)
+    agree = (diff <= 1e-5).float().mean(dim=1)
+    assert agree.median() > 0.99 and (agree > 0.99).sum() >= 3
+    # a perturbed patch may resample (FPS) a different subset in a different order: compare as sets
+    nn = torch.cdist(together.transpose(1, 2), single.transpose(1, 2)).amin(dim=2)     # (5, 2496)
+    assert nn.mean(dim=1).max() < 0.02       # point spacing on the unit sphere is ~0.07
 
 
 @pytest.mark.parametrize("ratio", [2, 4, 16])
