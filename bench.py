@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# The step keeps ~9 HIP streams busy (network sub-batches + the final-FPS launches of several
+# steps).  The HIP runtime multiplexes streams onto 4 hardware queues by default, and a stream that
+# lands behind a 300 ms final-FPS kernel on the same queue stalls (measured: 302 vs 190 ms/step).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -48,6 +53,8 @@ def main():
     ap.add_argument("--clouds", type=int, default=8,
                     help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs)")
     ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
+    ap.add_argument("--net_streams", type=int, default=4,
+                    help="sub-batches of clouds whose network stages run on concurrent streams")
     ap.add_argument("--no_overlap", action="store_true",
                     help="run the final FPS on the main stream instead of a side stream")
     ap.add_argument("--num_shape_point", type=int, default=5000)
@@ -81,6 +88,7 @@ def main():
     # side streams, used round-robin: the final FPS launches of consecutive steps occupy different
     # CUs (one per cloud) and overlap each other as well as the following steps' network stages
     sides = None if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(args.fps_streams)]
+    nets = [torch.cuda.Stream(device=dev) for _ in range(args.net_streams)] if args.net_streams > 1 else None
     counter = [0]
 
     def step():
@@ -89,8 +97,9 @@ def main():
         # the final FPS of this step (one CU per cloud, a pure latency chain) runs on a side stream
         # and overlaps with the network stages of the NEXT step; everything is inside the timed region
         if args.diag_skip_final_fps:
-            return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False)[:, :, :N * r].contiguous()
-        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=side)   # (C,3,N*r)
+            return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False,
+                                 net_streams=nets)[:, :, :N * r].contiguous()
+        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=side, net_streams=nets)   # (C,3,N*r)
         if world > 1:                                                       # reassemble: ONE all-gather
             if side is not None:
                 with torch.cuda.stream(side):
