@@ -80,22 +80,12 @@ __device__ __forceinline__ int fps_block_argmax(FpsShared<NW> &sh, int parity, i
     return tpu3_fps_tiekey_to_index(win, lb);
 }
 
-// Hand-off with the winner's coordinates: the resident kernel never goes back to memory for them
-// (the coordinates of sample `old` are a dependent load from L2/MALL -- 0.5-1 us -- at the head of
-// every round otherwise).
-template <int NW>
-struct FpsSharedXyz {
-    int d[2][NW];
-    uint32_t key[2][NW];
-    float x[2][NW], y[2][NW], z[2][NW];
-};
-
 // ---- register-resident kernel: n <= W * PPT ---------------------------------------------
 template <int W, int PPT>
 __global__ __launch_bounds__(W) void fps_resident_kernel(FpsArgs a)
 {
     constexpr int NW = W / 64;
-    __shared__ FpsSharedXyz<NW> sh;
+    __shared__ FpsShared<NW> sh;
     const int b = blockIdx.x;
     const int n = a.n_arr ? a.n_arr[b] : a.n;
     const int m = a.m_arr ? a.m_arr[b] : a.m;
@@ -121,11 +111,11 @@ __global__ __launch_bounds__(W) void fps_resident_kernel(FpsArgs a)
             pt[j] = -1.0f;
         }
     }
+    int old = 0;
     if (t == 0)
         I[0] = 0;
-    const int lane = t & 63, wave = t >> 6;
-    float x1 = P[0], y1 = P[1], z1 = P[2];
     for (int r = 1; r < m; ++r) {
+        const float x1 = P[old * 3 + 0], y1 = P[old * 3 + 1], z1 = P[old * 3 + 2];
         float best = -1.0f;
         int bj = 0;
 #pragma unroll
@@ -139,41 +129,9 @@ __global__ __launch_bounds__(W) void fps_resident_kernel(FpsArgs a)
             }
         }
         const uint32_t key = tpu3_fps_tiekey(t + bj * W, lb);
-        // wave winner (distance, tie key) and ITS coordinates: the slot index is made wave-uniform so
-        // that the register array is addressed by a scalar branch, not per lane
-        const int dbits = __float_as_int(best);
-        const int wmax = tpu3_wave_max_i32(dbits);
-        const uint32_t wkey = tpu3_wave_min_u32(dbits == wmax ? key : 0xFFFFFFFFu);
-        const unsigned long long who = __ballot(dbits == wmax && key == wkey);
-        const int wl = __builtin_ctzll(who | (1ull << 63));
-        const int wj = __builtin_amdgcn_readlane(bj, wl);
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (wj == j) {
-                cx = px[j]; cy = py[j]; cz = pz[j];
-            }
-        const int par = r & 1;
-        if (lane == wl) {
-            sh.d[par][wave] = wmax;
-            sh.key[par][wave] = wkey;
-            sh.x[par][wave] = cx; sh.y[par][wave] = cy; sh.z[par][wave] = cz;
-        }
-        __syncthreads();
-        int ww = 0;
-        uint32_t win = wkey;
-        if (NW > 1) {
-            const int bd = lane < NW ? sh.d[par][lane] : (int)0x80000000;
-            const uint32_t bk = lane < NW ? sh.key[par][lane] : 0xFFFFFFFFu;
-            const int rmax = tpu3_row_max_i32(bd);          // NW <= 16: one DPP row holds all slots
-            const uint32_t rk = tpu3_row_min_u32(bd == rmax ? bk : 0xFFFFFFFFu);
-            win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
-            const unsigned long long wv = __ballot(lane < NW && bd == rmax && bk == win);
-            ww = __builtin_ctzll(wv | (1ull << 63)) & (NW - 1);
-        }
-        x1 = sh.x[par][ww]; y1 = sh.y[par][ww]; z1 = sh.z[par][ww];
+        old = fps_block_argmax<NW>(sh, r & 1, __float_as_int(best), key, lb);
         if (t == 0)
-            I[r] = tpu3_fps_tiekey_to_index(win, lb);
+            I[r] = old;
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
