@@ -182,6 +182,24 @@ def test_pipeline_on_device_against_reference_driver(orc, dev):
     assert _set_close(orc, final, g["final"]) >= 0.99
 
 
+def test_pipeline_concurrent_sub_batches_and_side_stream(orc, dev):
+    """upsample(net_streams=..., fps_stream=...): clouds split over concurrent streams, final FPS on
+    a side stream.  Every cloud is independent, so the result must be the single-stream one up to
+    the rounding of differently shaped GEMMs (compared as point sets, like the other network tests)."""
+    pipe = pkg("pipeline")
+    net = _net(dev)
+    clouds = torch.cat([torch.from_numpy(np.ascontiguousarray(sphere(40 + i, 1000).transpose(0, 2, 1)))
+                        for i in range(3)]).to(dev)
+    ref = pipe.upsample(net, clouds, 312, 4, 3)
+    nets = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    side = torch.cuda.Stream(device=dev)
+    out = pipe.upsample(net, clouds, 312, 4, 3, net_streams=nets, fps_stream=side)
+    side.synchronize()
+    assert out.shape == ref.shape == (3, 3, 4000)
+    for i in range(3):
+        assert _set_close(orc, out[i:i + 1].cpu().numpy(), ref[i:i + 1].cpu().numpy()) >= 0.99
+
+
 def test_full_size_config_c2_properties(orc, dev):
     """BASELINE config C2 at full size (5000 -> 80000, 16x, 48 patches): properties that do not
     need a 300 s CPU run -- shape, finiteness, the FPS prefix property (the first m' picks of an

@@ -1,2 +1,3 @@
 cd /root/repo
-echo resident-old; TPU3_FPS_BUCKET_MIN_N=100000 python tools/fps_real_probe.py | tail -3
+timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
