@@ -88,7 +88,7 @@ def shard_range(total, rank, world):
 
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-             timing=None, fps_stream=None, net_streams=None):
+             timing=None, fps_stream=None, net_streams=None, sub_batch=4):
     """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
     the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
     Every rank passes the same `clouds` and receives the full result.
@@ -98,19 +98,23 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     on ONE compute unit per cloud; on its own stream it overlaps with the network stages of the
     next call, which use the other 255 CUs.  The result is then only valid after that stream has
     been synchronised (the caller's job).
-    `net_streams`: optional list of streams; the clouds are then split into that many sub-batches
-    whose network stages run concurrently.  The per-level resampling FPS is a latency chain on a
-    few wavefronts per patch set while the kNN / DenseEdgeConv kernels are throughput-bound: one
-    sub-batch's FPS hides under another's matrix work."""
+    `net_streams`: optional list of streams; the clouds are then split into sub-batches of
+    `sub_batch` clouds whose network stages run concurrently (round-robin over the streams).  The
+    per-level resampling FPS is a latency chain on a few wavefronts per patch set while the kNN /
+    DenseEdgeConv kernels are throughput-bound: one sub-batch's FPS hides under another's matrix
+    work."""
     C, _, N = clouds.shape
     rank, world = _world()
-    if (shard is None or world == 1) and net_streams and len(net_streams) > 1 and C >= len(net_streams):
+    if (shard is None or world == 1) and net_streams and len(net_streams) > 1 and C > 1:
         cur = torch.cuda.current_stream()
         parts = []
-        for s, ids in zip(net_streams, torch.arange(C).chunk(len(net_streams))):
+        per = max(1, min(int(sub_batch), -(-C // len(net_streams))))
+        for s in net_streams:
             s.wait_stream(cur)
+        for i, lo in enumerate(range(0, C, per)):
+            s = net_streams[i % len(net_streams)]
             with torch.cuda.stream(s):
-                sub = clouds[int(ids[0]):int(ids[-1]) + 1]
+                sub = clouds[lo:lo + per]
                 _, patches, _ = extract_outer_patches(sub, num_point, patch_num_ratio)
                 P = patches.size(1)
                 up, _ = upsample_patches(net, patches.reshape(sub.size(0) * P, num_point, 3), up_ratio)
@@ -129,7 +133,7 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
         ids, per = shard_range(C, rank, world)
         mine = clouds[ids]
         local = upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
-                         timing=timing, fps_stream=fps_stream, net_streams=net_streams)
+                         timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch)
         if fps_stream is not None:
             torch.cuda.current_stream().wait_stream(fps_stream)
         out = _all_gather_cat(local)                         # (world*per, 3, N*r) in cloud order

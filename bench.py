@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clouds", type=int, default=8,
+    ap.add_argument("--clouds", type=int, default=16,
                     help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs)")
     ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
     ap.add_argument("--net_streams", type=int, default=4,

@@ -84,9 +84,9 @@ def test_fps_bucketed_large_ragged(orc, dev):
         np.testing.assert_array_equal(idx[i], ref_idx[0])
 
 
-@pytest.mark.parametrize("b,n,m", [(7, 24960, 2496), (5, 17000, 300)])
+@pytest.mark.parametrize("b,n,m", [(7, 26000, 2496), (5, 40000, 300)])
 def test_fps_bucketed_batched_segmented_sort_ragged(orc, dev, b, n, m):
-    """The per-level resample of a batch of merged patch sets (n >= 16384, m >= 256): one batched
+    """A batch of point sets beyond the register-resident limit (n > 25 600): one batched
     setup (segmented Morton sort) + one bucket-kernel launch for all elements, with ragged point
     AND sample counts, an empty element and a tiny one; indices and temp bit-exact per element."""
     ops, L = pkg("network.operations"), pkg("_lib")
