@@ -604,6 +604,10 @@ bool fb_plan(int b, int n, FbPlan &p)
     return true;
 }
 
+// measurement hook (bench.py): events recorded on the launch stream immediately around the next
+// fb_main_kernel launch, see tpu3_debug_fps_bucket_events
+hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 template <int PPL, bool PROF>
 int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
 {
@@ -614,7 +618,11 @@ int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
+    const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (e0) (void)hipEventRecord(e0, s);
     hipLaunchKernelGGL(kern, dim3(b), dim3(FB_NW * 64), lds, s, a0);
+    if (e1) (void)hipEventRecord(e1, s);
     return tpu3_launch_status();
 }
 
@@ -710,6 +718,16 @@ int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const int32_t *n_
                            const float *xyz, float *temp, int32_t *idx, void *workspace, size_t workspace_bytes)
 {
     return fb_run(s, b, n, m, n_arr, m_arr, xyz, temp, idx, workspace, workspace_bytes, nullptr);
+}
+
+// Measurement hook (not part of include/tpu3.h): the NEXT bucketed-FPS call records `start` / `stop`
+// (hipEvent_t, created by the caller) on its stream right before / after fb_main_kernel, so that a
+// caller can time exactly that kernel on whatever stream it runs.  One-shot; host-side state only.
+extern "C" int tpu3_debug_fps_bucket_events(void *start, void *stop)
+{
+    g_ev_start = (hipEvent_t)start;
+    g_ev_stop = (hipEvent_t)stop;
+    return TPU3_OK;
 }
 
 // Development probe (not part of include/tpu3.h): the same kernel with per-phase cycle counters;

@@ -85,6 +85,19 @@ def main():
     clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
 
     timing = []
+    # HIP events placed by the library immediately around fb_main_kernel on ITS stream (the events
+    # in `timing` bracket the whole final-FPS operator: Morton sort, bucket setup, kernel, write-back)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    tlib = ctypes.CDLL(pkg("_lib").LIB_PATH)
+    tlib.tpu3_debug_fps_bucket_events.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    kernel_events = []
+
+    def arm_kernel_events():
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e0)) == 0 and hip.hipEventCreate(ctypes.byref(e1)) == 0
+        tlib.tpu3_debug_fps_bucket_events(e0, e1)
+        kernel_events.append((e0, e1))
     # side streams, used round-robin: the final FPS launches of consecutive steps occupy different
     # CUs (one per cloud) and overlap each other as well as the following steps' network stages
     sides = None if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(args.fps_streams)]
@@ -96,6 +109,8 @@ def main():
         counter[0] += 1
         # the final FPS of this step (one CU per cloud, a pure latency chain) runs on a side stream
         # and overlaps with the network stages of the NEXT step; everything is inside the timed region
+        if not args.diag_skip_final_fps:
+            arm_kernel_events()
         if args.diag_skip_final_fps:
             return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False,
                                  net_streams=nets)[:, :, :N * r].contiguous()
@@ -171,7 +186,15 @@ def main():
                           "ms_per_step": ms, "algorithmic_bytes_per_step": byt, "traffic": None})
 
     total_points = world * C * N * r * args.steps
-    fps_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
+    op_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
+    fps_ms = None
+    if kernel_events:
+        vals = []
+        for e0, e1 in kernel_events[args.warmup:]:
+            ms = ctypes.c_float()
+            if hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) == 0:
+                vals.append(ms.value)
+        fps_ms = float(np.mean(vals)) if vals else None
 
     if rank == 0:
         P = pipe.num_outer_patches(N, npnt, 3)
@@ -182,7 +205,7 @@ def main():
         roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, C),
                 "bound": "hbm", "achieved": alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None,
                 "peak": 8000.0, "unit": "GB/s", "traffic": None,
-                "launch_ms": fps_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                "launch_ms": fps_ms, "operator_ms": op_ms, "algorithmic_bytes_per_launch": alg_bytes}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
         # HBM traffic of that launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
         # gfx950 correction + WRITE_SIZE, KiB -> bytes); only valid for the profiled configuration
