@@ -71,11 +71,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    # TPU3_BENCH_BACKEND=gloo + TPU3_BENCH_ONE_DEVICE=1: functional check of the N > 1 code path on
+    # a single-GPU box (all ranks share cuda:0, collectives through gloo); never a measurement
+    backend = os.environ.get("TPU3_BENCH_BACKEND", "nccl")
+    if os.environ.get("TPU3_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ops, pipe, ups = pkg("network.operations"), pkg("pipeline"), pkg("network.upsampler")
     assert ops.BACKEND.name == "hip-gfx950"

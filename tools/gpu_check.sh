@@ -1,7 +1,3 @@
 cd /root/repo
-run() { echo "$@"; timeout 150 python bench.py --no_cpu_baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'] if d.get('roofline') else '')"; }
-run
-run --clouds 32 --steps 6
-run --clouds 24 --steps 6
-run --clouds 8
-run --clouds 1 --steps 6
+export TPU3_BENCH_BACKEND=gloo TPU3_BENCH_ONE_DEVICE=1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --clouds 4 --no_cpu_baseline 2>&1 | tail -5 | cut -c1-600
