@@ -1,0 +1,290 @@
+// mlp.hip -- per-point linear layers of a Level on the fp32 matrix cores (inference, gfx950).
+//
+// The reference runs every 1x1 convolution as its own cuDNN call followed by separate bias / ReLU
+// kernels (network/layers.py:115-204, network/upsampler.py:293-369).  Two shapes dominate what is
+// left of a Level after the DenseEdgeConv blocks:
+//   * the "prep" convolutions 84 / 144 / 204 -> 24 + ReLU (upsampler.py:298,303,308): skinny (24
+//     outputs), bound by streaming the input rows; a vendor GEMM tile wastes most of its width;
+//   * the regressor tail (upsampler.py:363-372): relu(a_i + c_j) -> 128 -> 128 -> 64 -> 3 + residual
+//     for each of the r replicas of a point, where a_i = W_x x_i + b is the per-point half of
+//     up_layer1 and c_j = W_c code_j the per-replica half: three GEMMs and five elementwise passes
+//     over (B, N*r, 128) tensors in the unfused form.
+//
+// Both kernels use v_mfma_f32_16x16x4_f32 with the weights as A operand (16 outputs x 4 k) and the
+// activations as B operand (4 k x 16 points): lane l supplies point l & 15, k slot l >> 4, and holds
+// of the 16x16 result the outputs 4 (l >> 4) + r, r = 0..3, of ITS point.  The k slots of the four
+// MFMAs of a 16-channel slab are permuted (MFMA j, slot q <-> channel 16 s + 4 q + j) so that
+//   - a lane fetches its four B (and A) values of a slab as ONE float4, and
+//   - the accumulator tile t of a layer IS the B operand of slab t of the next layer (bias / ReLU
+//     applied in place): the whole tail runs register to register.
+// fp32 MFMA accumulates in k order with one rounding per product, so results differ from a vendor
+// GEMM only by the summation order (tests compare at 1e-5).
+#include "tpu3_dev.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f ld4(const float *p) { return *(const v4f *)p; }
+
+// ---------------------------------------------------------------------------------------------
+// y[m, cout] = act(x[m, cin] W^T + b), cout <= 32
+// ---------------------------------------------------------------------------------------------
+struct LinArgs {
+    long m;
+    int cin, cout, xs, ys, relu;
+    const float *x, *w, *b;
+    float *y;
+};
+
+constexpr int LS_CIN_MAX = 320;           // weights staged in LDS: 32 x (320 + 4) floats = 41 KB
+
+template <int TOUT>
+__global__ __launch_bounds__(256) void linear_small_kernel(LinArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 * TOUT][cin + 4], zero padded
+    const int S = a.cin + 4;
+    for (int i = threadIdx.x; i < 16 * TOUT * (a.cin >> 2); i += blockDim.x) {
+        const int o = i / (a.cin >> 2), c4 = i - o * (a.cin >> 2);
+        const v4f v = o < a.cout ? ld4(a.w + (size_t)o * a.cin + 4 * c4) : (v4f){0.f, 0.f, 0.f, 0.f};
+        *(v4f *)(wl + o * S + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const int nslab = (a.cin + 15) >> 4;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 16 + pt;
+        const float *xr = a.x + (row < a.m ? row : a.m - 1) * a.xs;
+        v4f acc[TOUT];
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t)
+            acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // eight slabs per trip: all their row loads are in flight together (the kernel is bound by
+        // streaming x); slabs past cin contribute zero operands
+        for (int s0 = 0; s0 < nslab; s0 += 8) {
+            v4f bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = 16 * (s0 + u) + 4 * q;
+                bv[u] = ld4(xr + (ch < a.cin ? ch : 0));        // cin % 4 == 0
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = 16 * (s0 + u) + 4 * q;
+                const bool ok = ch < a.cin;
+                const v4f b = ok ? bv[u] : (v4f){0.f, 0.f, 0.f, 0.f};
+                v4f av[TOUT];
+#pragma unroll
+                for (int t = 0; t < TOUT; ++t)
+                    av[t] = *(const v4f *)(wl + (16 * t + pt) * S + (ok ? ch : 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < TOUT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][j], b[j], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+            const int o = 16 * t + 4 * q;                       // cout % 4 == 0
+            if (o < a.cout && row < a.m) {
+                v4f v = acc[t];
+                if (a.b)
+                    v += ld4(a.b + o);
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(v4f *)(a.y + row * a.ys + o) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// regressor tail: out[(i*r + j), 0..2] = W4 relu(W3 relu(W2 relu(a_i + c_j) + b2) + b3) + b4 + res_i
+// a (m,128) incl. the bias of up_layer1; c (r,128); W2 (128,128); W3 (64,128); W4 (3,64)
+// ---------------------------------------------------------------------------------------------
+constexpr int RT_C1 = 128, RT_C2 = 128, RT_C3 = 64, RT_C4 = 3;
+constexpr int RT_S = 132;                 // LDS row stride of the 128-wide weight rows (floats)
+constexpr int RT_S4 = 68;                 // ... of the 64-wide rows of W4 (padded to 16 rows)
+constexpr int RT_RMAX = 4;                // replicas per point
+
+struct TailArgs {
+    long m;
+    int r;
+    const float *a, *c, *w2, *b2, *w3, *b3, *w4, *b4, *res;
+    float *out;
+};
+
+constexpr size_t rt_lds_floats()
+{
+    return (size_t)RT_C2 * RT_S + RT_C3 * RT_S + 16 * RT_S4 + RT_C2 + RT_C3 + 16 + RT_RMAX * RT_C1;
+}
+
+__global__ __launch_bounds__(512) void regress_tail_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *w2 = lds;                              // [128][132]
+    float *w3 = w2 + RT_C2 * RT_S;                // [64][132]
+    float *w4 = w3 + RT_C3 * RT_S;                // [16][68], rows >= 3 zero
+    float *b2 = w4 + 16 * RT_S4;                  // [128]
+    float *b3 = b2 + RT_C2;                       // [64]
+    float *b4 = b3 + RT_C3;                       // [16]
+    float *cc = b4 + 16;                          // [r][128]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RT_C2 * RT_C1; i += blockDim.x)
+        w2[(i >> 7) * RT_S + (i & 127)] = a.w2[i];
+    for (int i = tid; i < RT_C3 * RT_C2; i += blockDim.x)
+        w3[(i >> 7) * RT_S + (i & 127)] = a.w3[i];
+    for (int i = tid; i < 16 * RT_C3; i += blockDim.x)
+        w4[(i >> 6) * RT_S4 + (i & 63)] = (i >> 6) < RT_C4 ? a.w4[i] : 0.f;
+    for (int i = tid; i < RT_C2; i += blockDim.x)
+        b2[i] = a.b2[i];
+    for (int i = tid; i < RT_C3; i += blockDim.x)
+        b3[i] = a.b3[i];
+    for (int i = tid; i < 16; i += blockDim.x)
+        b4[i] = i < RT_C4 ? a.b4[i] : 0.f;
+    for (int i = tid; i < a.r * RT_C1; i += blockDim.x)
+        cc[i] = a.c[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    for (long tile = (long)blockIdx.x * nw + wave; tile < ntiles; tile += (long)gridDim.x * nw) {
+        const long row = tile * 16 + pt;
+        const long rowc = row < a.m ? row : a.m - 1;
+        // a_i in B-operand form: slab s holds channels 16 s + 4 q .. + 3
+        v4f av[RT_C1 / 16];
+#pragma unroll
+        for (int s = 0; s < RT_C1 / 16; ++s)
+            av[s] = ld4(a.a + rowc * RT_C1 + 16 * s + 4 * q);
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (q == 0) {
+            rx = a.res[rowc * 3 + 0]; ry = a.res[rowc * 3 + 1]; rz = a.res[rowc * 3 + 2];
+        }
+        for (int j = 0; j < a.r; ++j) {
+            // h0 = relu(a + c_j)
+            v4f h0[RT_C1 / 16];
+#pragma unroll
+            for (int s = 0; s < RT_C1 / 16; ++s) {
+                const v4f c = ld4(cc + j * RT_C1 + 16 * s + 4 * q);
+                v4f v = av[s] + c;
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                h0[s] = v;
+            }
+            // layer 2: 128 -> 128, ReLU
+            v4f h1[RT_C2 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C2 / 16; ++t)
+                h1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            // (consecutive MFMAs go to different accumulator tiles: a tile's own chain is dependent)
+#pragma unroll
+            for (int s = 0; s < RT_C1 / 16; ++s) {
+                v4f w[RT_C2 / 16];
+#pragma unroll
+                for (int t = 0; t < RT_C2 / 16; ++t)
+                    w[t] = ld4(w2 + (16 * t + pt) * RT_S + 16 * s + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int t = 0; t < RT_C2 / 16; ++t)
+                        h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][k], h0[s][k], h1[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keep the next slabs' LDS reads from piling up in VGPRs
+            }
+#pragma unroll
+            for (int t = 0; t < RT_C2 / 16; ++t) {
+                v4f v = h1[t] + ld4(b2 + 16 * t + 4 * q);
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                h1[t] = v;
+            }
+            // layer 3: 128 -> 64, ReLU
+            v4f h2[RT_C3 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C3 / 16; ++t)
+                h2[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < RT_C2 / 16; ++s) {
+                v4f w[RT_C3 / 16];
+#pragma unroll
+                for (int t = 0; t < RT_C3 / 16; ++t)
+                    w[t] = ld4(w3 + (16 * t + pt) * RT_S + 16 * s + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int t = 0; t < RT_C3 / 16; ++t)
+                        h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][k], h1[s][k], h2[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < RT_C3 / 16; ++t) {
+                v4f v = h2[t] + ld4(b3 + 16 * t + 4 * q);
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                h2[t] = v;
+            }
+            // layer 4: 64 -> 3 (one output tile, rows >= 3 are zero weights), bias, residual
+            v4f o = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < RT_C3 / 16; ++s) {
+                const v4f w = ld4(w4 + pt * RT_S4 + 16 * s + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], h2[s][k], o, 0, 0, 0);
+            }
+            if (q == 0 && row < a.m) {          // lanes 0-15 hold outputs 0..3 of their point
+                float *dst = a.out + (row * a.r + j) * 3;
+                dst[0] = (o.x + b4[0]) + rx;
+                dst[1] = (o.y + b4[1]) + ry;
+                dst[2] = (o.z + b4[2]) + rz;
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
+                                     int x_stride, const float *w, const float *bias, int relu, float *y,
+                                     int y_stride)
+{
+    if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
+    if (cout > 32 || cin > LS_CIN_MAX || cin % 4 || cout % 4 || x_stride % 4 || y_stride % 4) return TPU3_ELIMIT;
+    if (x_stride < cin || y_stride < cout) return TPU3_EINVAL;
+    if (m == 0) return TPU3_OK;
+    if (!x || !w || !y) return TPU3_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15) != 0) return TPU3_ELIMIT;
+    LinArgs a{m, cin, cout, x_stride, y_stride, relu, x, w, bias, y};
+    const long tiles = (m + 15) / 16;
+    long blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;       // persistent: the weights are staged once per workgroup
+    const int tout = cout <= 16 ? 1 : 2;
+    const size_t lds = (size_t)16 * tout * (cin + 4) * sizeof(float);
+    if (tout == 1)
+        hipLaunchKernelGGL(linear_small_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(linear_small_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, const float *c,
+                                     const float *w2, const float *b2, const float *w3, const float *b3,
+                                     const float *w4, const float *b4, const float *residual, float *out)
+{
+    if (m < 0 || r <= 0 || r > RT_RMAX) return TPU3_EINVAL;
+    if (m == 0) return TPU3_OK;
+    if (!a || !c || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !residual || !out) return TPU3_EINVAL;
+    if (((uintptr_t)a & 15) != 0) return TPU3_ELIMIT;
+    TailArgs t{m, r, a, c, w2, b2, w3, b3, w4, b4, residual, out};
+    const size_t lds = rt_lds_floats() * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)regress_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const long tiles = (m + 15) / 16;
+    long blocks = (tiles + 7) / 8;
+    if (blocks > 256) blocks = 256;             // one persistent workgroup per CU (106 KB of weights each)
+    hipLaunchKernelGGL(regress_tail_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, t);
+    return tpu3_launch_status();
+}

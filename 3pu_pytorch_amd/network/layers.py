@@ -122,6 +122,18 @@ class DenseEdgeConv(nn.Module):
         return y.transpose(2, 1).contiguous(), idx
 
 
+def _fused_linear(layer, x):
+    """Inference shortcut of a pointwise Conv1d / Conv2d with at most 32 outputs (the prep
+    convolutions of a Level): linear + bias + ReLU in one MFMA kernel that reads the input rows in
+    place (e.g. a channel slice of the level's feature buffer).  None = not applicable."""
+    be = operations.BACKEND
+    if (torch.is_grad_enabled() or not hasattr(be, "linear_small") or not x.is_cuda
+            or layer.activation not in (None, "relu") or layer.conv.out_channels > 32):
+        return None
+    w = layer.conv.weight
+    return be.linear_small(x, w.view(w.size(0), -1), layer.conv.bias, layer.activation == "relu")
+
+
 def _make_norm(normalization, out_channels, momentum, dims):
     if normalization == 'batch':
         cls = nn.BatchNorm2d if dims == 2 else nn.BatchNorm1d
@@ -168,6 +180,9 @@ class Conv2d(nn.Module):
     def forward_cl(self, x):
         """channel-last (..., C_in) -> (..., C_out)."""
         assert self.pointwise()
+        y = _fused_linear(self, x)
+        if y is not None:
+            return y
         x = linear_1x1(self.conv, x)
         if self.activation is not None:
             x = self.act(x)
@@ -205,6 +220,9 @@ class Conv1d(nn.Module):
 
     def forward_cl(self, x):
         assert self.pointwise()
+        y = _fused_linear(self, x)
+        if y is not None:
+            return y
         x = linear_1x1(self.conv, x)
         if self.activation is not None:
             x = self.act(x)

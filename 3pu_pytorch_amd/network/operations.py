@@ -223,6 +223,44 @@ class HipBackend(object):
                 "tpu3_interlevel_skip_f32")
         return feat
 
+    def linear_small(self, x, weight, bias, relu):
+        """Per-point linear layer with <= 32 outputs on channel-last rows: x (..., C_in) with unit
+        channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),
+        weight (C_out, C_in) -> (..., C_out), or None when the shape is not covered."""
+        cin, cout = x.size(-1), weight.size(0)
+        if cout > 32 or cin > 320 or cin % 4 or cout % 4 or x.stride(-1) != 1 or x.dtype != torch.float32:
+            return None
+        rs = x.stride(-2)
+        lead = x.shape[:-1]
+        m = 1
+        for d in lead:
+            m *= d
+        # all leading dims must collapse onto the row stride
+        exp = rs
+        for d, st in zip(reversed(lead), reversed(x.stride()[:-1])):
+            if d != 1 and st != exp:
+                return None
+            exp *= d
+        if rs % 4 or (x.data_ptr() & 15) or (weight.data_ptr() & 15):
+            return None
+        w = weight.contiguous()
+        y = torch.empty(lead + (cout,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_linear_small_f32(L.stream_of(x), m, cin, cout, L.ptr(x), rs, L.ptr(w),
+                                                  L.ptr(bias), 1 if relu else 0, L.ptr(y), cout),
+                    "tpu3_linear_small_f32")
+        return y
+
+    def regress_tail(self, a, c, w2, b2, w3, b3, w4, b4, residual):
+        """a (M,128), c (r,128), residual (M,3) -> (M*r, 3); see tpu3_regress_tail_f32."""
+        m, r = a.size(0), c.size(0)
+        out = torch.empty((m * r, 3), dtype=torch.float32, device=a.device)
+        ts = [t.contiguous() for t in (a, c, w2, b2, w3, b3, w4, b4, residual)]
+        with torch.cuda.device(a.device):
+            L.check(L.lib().tpu3_regress_tail_f32(L.stream_of(a), m, r, *[L.ptr(t) for t in ts], L.ptr(out)),
+                    "tpu3_regress_tail_f32")
+        return out
+
     def normalize(self, pc, n_arr=None):
         """pc (B,3,N) f32 contiguous -> (out (B,3,N), centroid (B,3,1), radius (B,1,1))."""
         L.require_device(pc, "pc")

@@ -379,6 +379,18 @@ class Level(torch.nn.Module):
             cin = x.size(-1)
             a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)                 # (B,N,128)
             c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])          # (r,128)
+            up2, fc1, fc2 = self.up_layer.up_layer2, self.fc_layer1, self.fc_layer2
+            be = operations.BACKEND
+            if (hasattr(be, "regress_tail") and x.is_cuda and ratio <= 4 and a.size(-1) == 128
+                    and all(l.pointwise() for l in (up2, fc1, fc2))
+                    and (up2.activation, fc1.activation, fc2.activation) == ("relu", "relu", None)
+                    and (up2.conv.out_channels, fc1.conv.out_channels, fc2.conv.out_channels) == (128, 64, 3)):
+                # relu(a_i + c_j) -> 128 -> 64 -> 3 + residual, register to register (csrc/mlp.hip)
+                flat = lambda l: l.conv.weight.view(l.conv.weight.size(0), -1)
+                out = be.regress_tail(a.reshape(B * N, 128), c, flat(up2), up2.conv.bias, flat(fc1),
+                                      fc1.conv.bias, flat(fc2), fc2.conv.bias,
+                                      xyz_normalized.reshape(B * N, 3))
+                return out.view(B, N * ratio, 3), point_features
             x = torch.relu_(a.unsqueeze(2) + c.view(1, 1, ratio, -1)).reshape(B, N * ratio, -1)
         else:
             code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)

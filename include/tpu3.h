@@ -221,6 +221,27 @@ int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, c
  * allocation inside) */
 size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 
+/* Per-point linear layer with a small output width, inference (the "prep" convolutions of a
+ * Level, network/upsampler.py:298,303,308: 84 / 144 / 204 -> 24 + ReLU; any kernel-size-1
+ * nn.Conv1d / nn.Conv2d on channel-last data, network/layers.py:115-204):
+ *   y[i, 0..cout) = act(W x[i, 0..cin) + bias),  x (m, x_stride) rows, y (m, y_stride) rows,
+ *   w (cout, cin) row-major = the convolution weight, bias (cout) or NULL, relu != 0 -> ReLU.
+ * cout <= 32; cin, cout and both strides multiples of 4, 16-byte aligned bases (else TPU3_ELIMIT:
+ * callers then use their generic GEMM path).  fp32 MFMA. */
+int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                          const float *w, const float *bias, int relu, float *y, int y_stride);
+
+/* Regressor tail of a Level, inference (network/upsampler.py:363-372) for the reference's widths
+ * 128 -> 128 -> 64 -> 3: for point i and replica j < r (r <= 4)
+ *   out[i*r + j, 0..3) = W4 relu(W3 relu(W2 relu(a_i + c_j) + b2) + b3) + b4 + residual_i
+ * a (m,128) = the per-point half of up_layer1 incl. its bias, c (r,128) = its per-replica (code)
+ * half, w2 (128,128), w3 (64,128), w4 (3,64) row-major convolution weights, residual (m,3) the
+ * normalised input coordinates, out (m*r,3).  One launch instead of three GEMMs and five
+ * elementwise passes over (m*r,128) tensors. */
+int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, const float *c,
+                          const float *w2, const float *b2, const float *w3, const float *b3,
+                          const float *w4, const float *b4, const float *residual, float *out);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,

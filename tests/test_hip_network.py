@@ -287,6 +287,50 @@ def test_interlevel_skip_fused_matches_unfused(dev, monkeypatch):
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("m,cin,cout,relu,off", [(1000, 84, 24, True, 180), (777, 204, 24, True, 60),
+                                                (50, 144, 24, False, 120), (33, 16, 32, True, 0),
+                                                (5, 8, 4, False, 0)])
+def test_linear_small_matches_torch(dev, m, cin, cout, relu, off):
+    """tpu3_linear_small_f32 (prep convolutions) against torch on the same rows (fp64 reference),
+    reading a channel slice of a wider buffer in place."""
+    ops = pkg("network.operations")
+    g = torch.Generator(device="cpu").manual_seed(m + cin)
+    buf = torch.randn(m, off + cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    x = buf[:, off:]
+    y = ops.BACKEND.linear_small(x, w, b, relu)
+    assert y is not None and y.shape == (m, cout)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = torch.relu(ref) if relu else ref
+    assert (y.double() - ref).abs().max() < 1e-5
+    # rows that are not 16-byte aligned are declined, not mis-computed
+    wide = torch.randn(m, cin + 4, generator=g).to(dev)
+    assert ops.BACKEND.linear_small(wide[:, 1:1 + cin], w, b, relu) is None
+
+
+@pytest.mark.parametrize("m,r", [(312, 2), (1000, 2), (17, 4), (4096 * 3 + 5, 1)])
+def test_regress_tail_matches_torch(dev, m, r):
+    """tpu3_regress_tail_f32 against the unfused torch formulation (fp64 reference)."""
+    ops = pkg("network.operations")
+    g = torch.Generator(device="cpu").manual_seed(m)
+    a = torch.randn(m, 128, generator=g).to(dev)
+    c = torch.randn(r, 128, generator=g).to(dev)
+    w2 = (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev)
+    w3 = (torch.randn(64, 128, generator=g) / 128 ** 0.5).to(dev)
+    w4 = (torch.randn(3, 64, generator=g) / 8).to(dev)
+    b2, b3, b4 = (torch.randn(n, generator=g).to(dev) for n in (128, 64, 3))
+    res = torch.randn(m, 3, generator=g).to(dev)
+    out = ops.BACKEND.regress_tail(a, c, w2, b2, w3, b3, w4, b4, res)
+    d = lambda t: t.double()
+    h = torch.relu(d(a).unsqueeze(1) + d(c).unsqueeze(0))                       # (m,r,128)
+    h = torch.relu(h @ d(w2).t() + d(b2))
+    h = torch.relu(h @ d(w3).t() + d(b3))
+    ref = (h @ d(w4).t() + d(b4) + d(res).unsqueeze(1)).reshape(m * r, 3)
+    assert out.shape == (m * r, 3)
+    assert (out.double() - ref).abs().max() < 2e-5
+
+
 def test_cli_test_and_train_phases(dev, tmp_path, monkeypatch):
     """The drop-in CLI on the device: --phase test on .xyz files (checkpoint in the reference's
     format) writes <name>.ply with N*up_ratio points; --phase train runs optimiser steps."""

@@ -1,3 +1,6 @@
 cd /root/repo
-export TPU3_BENCH_BACKEND=gloo TPU3_BENCH_ONE_DEVICE=1
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --clouds 4 --no_cpu_baseline 2>&1 | tail -5 | cut -c1-600
+timeout 1500 python -m pytest tests/test_hip_network.py -m gpu -x -q 2>&1 | tail -2
+run() { echo "$@"; timeout 200 python bench.py --no_cpu_baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'] if d.get('roofline') else '')"; }
+run
+run
+run --diag_skip_final_fps --steps 6
