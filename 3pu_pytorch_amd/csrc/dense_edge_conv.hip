@@ -68,6 +68,39 @@ __device__ __forceinline__ float row_max_f32(float v)
     return v;
 }
 
+// One DPP step of the 16-lane row max for twelve values at once: the modifier is fused into
+// v_max_f32 (hipcc emits v_mov_dpp + v_max + wait states per step and value), and the twelve
+// independent chains fill each other's DPP wait states.
+#define DEC_DPP_MAX12(CTRL)                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                           \
+                 "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %8, %8, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %9, %9, %9 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_max_f32_dpp %10, %10, %10 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_max_f32_dpp %11, %11, %11 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8),  \
+                   "+v"(v9), "+v"(v10), "+v"(v11))
+
+__device__ __forceinline__ void row_max12(f32x4 &a, f32x4 &b, f32x4 &c)
+{
+    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
+    float v8 = c[0], v9 = c[1], v10 = c[2], v11 = c[3];
+    DEC_DPP_MAX12("quad_perm:[1,0,3,2]");
+    DEC_DPP_MAX12("quad_perm:[2,3,0,1]");
+    DEC_DPP_MAX12("row_half_mirror");
+    DEC_DPP_MAX12("row_mirror");
+    a = (f32x4){v0, v1, v2, v3};
+    b = (f32x4){v4, v5, v6, v7};
+    c = (f32x4){v8, v9, v10, v11};
+}
+
 template <int TILES>     // TILES = k / 16
 __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 {
@@ -213,12 +246,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
                     m2[r] = fmaxf(m2[r], h2[t][r]);
                 }
             // ---- max over the 16 edges of the row; one lane per channel group writes ----------------
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                m0[r] = row_max_f32(m0[r]);
-                m1[r] = row_max_f32(m1[r]);
-                m2[r] = row_max_f32(m2[r]);
-            }
+            row_max12(m0, m1, m2);
             if (e == 0 && g < 3) {
                 float *o = O + (size_t)i * a.out_stride + 4 * g;
                 *(f32x4 *)(o) = m2;                  // [0,12)  max h2

@@ -65,8 +65,10 @@ __device__ __forceinline__ int fps_block_argmax(FpsShared<NW> &sh, int parity, i
                                                 uint32_t key, int lb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wmax = tpu3_wave_max_i32(dbits);
-    const uint32_t wkey = tpu3_wave_min_u32(dbits == wmax ? key : 0xFFFFFFFFu);
+    // fused-DPP max + ballot; the tie key is only reduced when several lanes share the maximum
+    int wl;
+    const int wmax = tpu3_wave_argmax(dbits, key, wl);
+    const uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)key, wl);
     if (NW == 1)
         return tpu3_fps_tiekey_to_index(wkey, lb);
     if (lane == 0) {
@@ -74,12 +76,17 @@ __device__ __forceinline__ int fps_block_argmax(FpsShared<NW> &sh, int parity, i
         sh.key[parity][wave] = wkey;
     }
     __syncthreads();
-    int bd = lane < NW ? sh.d[parity][lane] : (int)0x80000000;
-    uint32_t bk = lane < NW ? sh.key[parity][lane] : 0xFFFFFFFFu;
-    const int rmax = tpu3_row_max_i32(bd);          // NW <= 16: one DPP row holds all slots
-    bk = tpu3_row_min_u32(bd == rmax ? bk : 0xFFFFFFFFu);
-    const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)bk, 0);
-    return tpu3_fps_tiekey_to_index(win, lb);
+    const int bd = lane < NW ? sh.d[parity][lane] : (int)0x80000000;
+    const uint32_t bk = lane < NW ? sh.key[parity][lane] : 0xFFFFFFFFu;
+    const int rmax = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(bd), 0);     // NW <= 16: one DPP row
+    unsigned long long who = __ballot(lane < NW && bd == rmax);
+    if (__builtin_popcountll(who) != 1) {
+        const uint32_t rk = tpu3_row_min_u32(lane < NW && bd == rmax ? bk : 0xFFFFFFFFu);
+        const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
+        who = __ballot(lane < NW && bd == rmax && bk == win);
+    }
+    const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
+    return tpu3_fps_tiekey_to_index(sh.key[parity][ww], lb);
 }
 
 // ---- register-resident kernel: n <= W * PPT ---------------------------------------------
