@@ -27,17 +27,15 @@ namespace {
 
 constexpr int FPS_RESIDENT_MAX = 25600;
 
-// TPU3_FPS_BUCKET_MIN_N (tuning knob; results are identical either way): point sets of at least this
-// size whose sample count is large enough go to the bucketed kernel even though they would fit the
-// register-resident one -- 4 waves per element instead of 16, a whole batch of patch sets runs
-// concurrently.  Measured on the per-level resampling of the bench (384 sets of 24 960 -> 4992):
-// 19.7 ms bucketed vs 20.8 ms resident, 9.3 vs 7.1 ms for 12 480 -> 2496: no gain, so the default
-// keeps the resident kernel up to its limit.
+// Point sets of at least this size whose sample count is large enough take the pruned kernels of
+// fps_bucket.hip (Morton order + exact AABB pruning: rows in registers up to 25 600 points, buckets
+// in L2 beyond) instead of the plain register-resident kernel below, which updates every point in
+// every round.  TPU3_FPS_BUCKET_MIN_N overrides the threshold (results are identical either way).
 int fps_bucket_min_n()
 {
     static const int v = [] {
         const char *e = getenv("TPU3_FPS_BUCKET_MIN_N");
-        return e ? atoi(e) : FPS_RESIDENT_MAX + 1;
+        return e ? atoi(e) : 4096;
     }();
     return v;
 }

@@ -31,6 +31,8 @@
 #include <hip/hip_fp16.h>
 
 #include <cstring>
+#include <type_traits>
+#include <utility>
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -539,10 +541,185 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
             a.prof[wave * 16 + i] = pc[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Point sets that fit the register file (n <= 25 600): the same exact pruning with the points held
+// in VGPRs.  One 16-wave workgroup per set; a ROW is 64 consecutive points of the Morton order (a
+// compact region, = one bucket of the init kernel) and row r belongs to wave r % 16, slot r / 16
+// (lane l holds point 64 r + l: x, y, z, running distance), so the handful of neighbouring rows a
+// sample touches are re-scanned by different waves in parallel.  Per round lane j of a wave tests row j's
+// AABB (kept in that lane's registers together with the row's current maximum); only touched rows
+// are re-scanned -- the row index is wave-uniform, so the register array is addressed by scalar
+// branches -- and publish (max, tie key, xyz of that point) to a row table in LDS.  The register-
+// resident kernel of fps.hip spends 25 points x 10 VALU ops per lane and round on the same sets
+// (2.0 us per round, all 16 waves busy); here a round touches ~2 rows of the whole set.
+// ---------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void rb_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rb_static_for<I + 1, N>(f);
+    }
+}
+
+struct RbSlots {
+    int d[2][16];
+    uint32_t key[2][16];
+    float x[2][16], y[2][16], z[2][16];
+};
+
+constexpr size_t rb_lds_bytes(int r)
+{
+    return (size_t)16 * r * 64 * 4 + (size_t)16 * r * 5 * 4 + sizeof(RbSlots) + 64;
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void rb_main_kernel(FbArgs a0)
+{
+    constexpr int NW = 16, ROWS = NW * R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: tie keys [wave][slot][lane] and row records [wave][slot]{max, key, x, y, z}: everything a
+    // wave touches in the round loop is its own base address plus a compile-time offset (no
+    // per-row address registers -- with 100 VGPRs of points there is no room for them)
+    uint32_t *skl = (uint32_t *)smem;
+    uint32_t *tbl = skl + ROWS * 64;
+    RbSlots &sl = *(RbSlots *)(tbl + ROWS * 5);
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    if (a.n <= 0 || a.m <= 0)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = a.lb;
+    uint32_t *kw = skl + wave * R * 64 + lane;      // this lane's keys: kw[64 * j]
+    uint32_t *tw = tbl + wave * R * 5;              // this wave's records: tw[5 * j + field]
+
+    // row r = 16 * slot + wave (neighbouring rows go to different waves); lane l holds point 64 r + l
+    float px[R], py[R], pz[R], pt[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int slot = (j * NW + wave) * 64 + lane;
+        float4 v = make_float4(0.f, 0.f, 0.f, -1.0f);
+        uint32_t key = 0xFFFFFFFFu;
+        if (slot < a0.npad) {
+            v = a.sp[slot];
+            key = a.skey[slot];
+        }
+        px[j] = v.x; py[j] = v.y; pz[j] = v.z; pt[j] = v.w;
+        kw[64 * j] = key;
+    }
+    // Row records and boxes come from the bucket-init kernel (a row is a 64-point bucket); lane j < R
+    // keeps row j's AABB (fp16, rounded outward, packed) and current maximum in registers
+    for (int i = tid; i < ROWS; i += 1024) {
+        const int w = i / R, j = i - w * R, row = j * NW + w;
+        const bool in = row < a0.nbpad;
+        tbl[i * 5 + 0] = in ? a.ib[0 * a0.nbpad + row] : 0x80000000u;
+        tbl[i * 5 + 1] = in ? a.ib[1 * a0.nbpad + row] : 0xFFFFFFFFu;
+        tbl[i * 5 + 2] = in ? a.ib[2 * a0.nbpad + row] : 0u;
+        tbl[i * 5 + 3] = in ? a.ib[3 * a0.nbpad + row] : 0u;
+        tbl[i * 5 + 4] = in ? a.ib[4 * a0.nbpad + row] : 0u;
+    }
+    uint32_t bw0, bw1, bw2;
+    int rowmax = (int)0x80000000;
+    {
+        const int row = min(lane, R - 1) * NW + wave;
+        const bool in = lane < R && row < a0.nbpad;
+        const uint32_t pinf = 0x7C00u | (0x7C00u << 16);
+        bw0 = in ? a.ib[5 * a0.nbpad + row] : pinf;
+        bw1 = in ? a.ib[6 * a0.nbpad + row] : pinf;
+        bw2 = in ? a.ib[7 * a0.nbpad + row] : pinf;
+        rowmax = in ? (int)a.ib[0 * a0.nbpad + row] : (int)0x80000000;
+    }
+    __syncthreads();
+
+    float qx = a.xyz[0], qy = a.xyz[1], qz = a.xyz[2];
+    // re-scan of slot j (compile-time j): fold the sample in, row arg-max with the FPS tie rule,
+    // publish the record; returns the row's maximum (wave-uniform)
+    auto rescan = [&](auto jc) -> int {
+        constexpr int j = decltype(jc)::value;
+        const float t = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, pz[j] - qz), pt[j]);
+        pt[j] = t;
+        const int bits = __float_as_int(t);
+        const int wmax = tpu3_wave_max_i32_fast(bits);
+        unsigned long long tie = __ballot(bits == wmax);
+        if (__builtin_popcountll(tie) != 1) {                    // duplicated points: smallest tie key
+            const uint32_t k = kw[64 * j];
+            const uint32_t kmin = tpu3_wave_min_u32(bits == wmax ? k : 0xFFFFFFFFu);
+            tie = __ballot(bits == wmax && k == kmin);
+        }
+        if (lane == (int)__builtin_ctzll(tie)) {
+            tw[5 * j + 0] = (uint32_t)wmax; tw[5 * j + 1] = kw[64 * j];
+            tw[5 * j + 2] = __float_as_uint(px[j]); tw[5 * j + 3] = __float_as_uint(py[j]);
+            tw[5 * j + 4] = __float_as_uint(pz[j]);
+        }
+        return wmax;
+    };
+
+    if (tid == 0)
+        a.idx[0] = 0;
+    for (int r = 1; r < a.m; ++r) {
+        // ---- prune: which of this wave's rows can the sample change? ------------------------------
+        const float db = fb_dbox(qx, qy, qz, fb_half_lo(bw0), fb_half_hi(bw0), fb_half_lo(bw1), fb_half_hi(bw1),
+                                 fb_half_lo(bw2), fb_half_hi(bw2));
+        const unsigned long long mask = __ballot(lane < R && db < __int_as_float(rowmax));
+        if (mask)
+            rb_static_for<0, R>([&](auto jc) {
+                if ((mask >> decltype(jc)::value) & 1ull) {
+                    const int wm = rescan(jc);
+                    rowmax = lane == decltype(jc)::value ? wm : rowmax;
+                }
+            });
+        // ---- this wave's best row -----------------------------------------------------------------------
+        const int mine = lane < R ? rowmax : (int)0x80000000;
+        const int wv = tpu3_wave_max_i32_fast(mine);
+        unsigned long long tie = __ballot(mine == wv);
+        if (__builtin_popcountll(tie) != 1) {
+            const uint32_t k = lane < R ? tw[5 * lane + 1] : 0xFFFFFFFFu;
+            const uint32_t kmin = tpu3_wave_min_u32(mine == wv ? k : 0xFFFFFFFFu);
+            tie = __ballot(mine == wv && k == kmin);
+        }
+        const int bj = (int)__builtin_ctzll(tie | (1ull << 63)) % R;
+        const int par = r & 1;
+        if (lane == 0) {
+            sl.d[par][wave] = wv;
+            sl.key[par][wave] = tw[5 * bj + 1];
+            sl.x[par][wave] = __uint_as_float(tw[5 * bj + 2]);
+            sl.y[par][wave] = __uint_as_float(tw[5 * bj + 3]);
+            sl.z[par][wave] = __uint_as_float(tw[5 * bj + 4]);
+        }
+        __syncthreads();
+        // ---- arg-max over the 16 waves (one DPP row) -------------------------------------------------------
+        const int sd = lane < NW ? sl.d[par][lane] : (int)0x80000000;
+        const uint32_t sk = lane < NW ? sl.key[par][lane] : 0xFFFFFFFFu;
+        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+        unsigned long long who = __ballot(lane < NW && sd == gbest);
+        if (__builtin_popcountll(who) != 1) {
+            const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
+            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
+            who = __ballot(lane < NW && sd == gbest && sk == win);
+        }
+        const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
+        // (uniform values: keep them in SGPRs)
+        qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.x[par][ww])));
+        qy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.y[par][ww])));
+        qz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.z[par][ww])));
+        if (tid == 0)
+            a.idx[r] = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
+    }
+    // final running distances, back in the caller's order
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t key = kw[64 * j];
+        if (key != 0xFFFFFFFFu)
+            a.temp[tpu3_fps_tiekey_to_index(key, lb)] = pt[j];
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
 
 struct FbPlan {
     int ppl, nw, ngpt, nb, nbpad, npad, ng;
+    int rb_rows;          // > 0: register-resident kernel with this many rows per wave
     bool segmented;       // one segmented sort for the batch instead of a device sort per element
     size_t ks, ps, bs;    // byte sizes: key array, per-point float array, bucket word array
     size_t per_elem;      // bytes of one batch element's arrays (sp, skey, ib, bbox)
@@ -565,6 +742,15 @@ using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 
 bool fb_plan(int b, int n, FbPlan &p)
 {
+    p.rb_rows = 0;
+    if (n <= RB_MAX_N) {
+        const int rows = ((n + 63) / 64 + 15) / 16;
+        for (int r : {4, 7, 10, 13, 16, 20, 25})
+            if (r >= rows) {
+                p.rb_rows = r;
+                break;
+            }
+    }
     p.ppl = 0;
     for (int ppl : {1, 2, 4, 8, 16})
         if ((long)FB_NB_MAX * 64 * ppl >= n) {
@@ -677,6 +863,28 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
     }
     hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
+    if (p.rb_rows && !prof && p.ppl == 1) {
+        // the set fits the register file: rows (= 64-point buckets) in VGPRs, no write-back pass
+        hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
+        const size_t lds = rb_lds_bytes(p.rb_rows);
+        hipError_t e = hipSuccess;
+#define RB_LAUNCH(RR)                                                                                    \
+    e = hipFuncSetAttribute((const void *)rb_main_kernel<RR>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                            (int)lds);                                                                   \
+    if (e != hipSuccess) return (int)e;                                                                  \
+    hipLaunchKernelGGL(rb_main_kernel<RR>, dim3(b), dim3(1024), lds, s, a0)
+        switch (p.rb_rows) {
+        case 4: RB_LAUNCH(4); break;
+        case 7: RB_LAUNCH(7); break;
+        case 10: RB_LAUNCH(10); break;
+        case 13: RB_LAUNCH(13); break;
+        case 16: RB_LAUNCH(16); break;
+        case 20: RB_LAUNCH(20); break;
+        default: RB_LAUNCH(25); break;
+        }
+#undef RB_LAUNCH
+        return tpu3_launch_status();
+    }
     const dim3 gi((p.nbpad + 3) / 4, b);
     switch (p.ppl) {
     case 1: hipLaunchKernelGGL(fb_bucket_init_kernel<1>, gi, dim3(256), 0, s, a0); break;

@@ -286,15 +286,19 @@ class Level(torch.nn.Module):
                     owners -= owners % 8        # whole sets of 8 clouds: one per XCD (skip kernel)
                 step = owners * per
                 bounds = list(range(0, B, step)) + [B]
-        outs, feats = [], []
+        # every chunk writes its features straight into its rows of one (B,N,264) buffer
+        blocks = (self.layer1, self.layer2, self.layer3, self.layer4)
+        total = self.layer0.conv.out_channels + sum(b.in_channels + b.n * b.growth_rate for b in blocks)
+        feat_all = xyz_normalized.new_empty((B, xyz_normalized.size(1), total))
+        outs = []
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             own = None if owner is None else owner[lo:hi].contiguous()
-            o, f = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups, per_owner)
+            o, _ = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups, per_owner,
+                                    feat_buf=feat_all[lo:hi])
             outs.append(o)
-            feats.append(f)
-        return torch.cat(outs, dim=0), torch.cat(feats, dim=0)
+        return torch.cat(outs, dim=0), feat_all
 
-    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):
+    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0, feat_buf=None):
         """Channel-last level:
             xyz, xyz_normalized  (B,N,3)
             previous             None or (prev_xyz (Bp,M,3), prev_feat (Bp,M,C), prev_count (Bp,)|None)
@@ -318,7 +322,7 @@ class Level(torch.nn.Module):
                 y, _ = blk.forward_cl(x if prep is None else prep.forward_cl(x), layout=graph_layout)
                 x = torch.cat([y, x], dim=-1)
         else:
-            feat = x0.new_empty((B, N, total))
+            feat = feat_buf if feat_buf is not None else x0.new_empty((B, N, total))
             lo = total - x0.size(-1)
             feat[..., lo:] = x0
             for (blk, prep), wdt in zip(blocks, widths):

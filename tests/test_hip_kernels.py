@@ -57,6 +57,44 @@ def test_fps_bucketed_kernel_bit_exact(orc, dev, b, n, m, dups):
     np.testing.assert_array_equal(ops.fps(x, m).cpu().numpy(), ref_idx)
 
 
+@pytest.mark.parametrize("n,m", [(4100, 300), (9000, 900), (16000, 1600), (20480, 700), (25600, 2600)])
+def test_fps_register_resident_bucketed_kernel(orc, dev, n, m):
+    """4096 <= n <= 25 600 with >= 256 samples: Morton rows held in registers, exact AABB pruning
+    per 64-point row (rb_main_kernel, every rows-per-wave instantiation).  A ragged batch with
+    duplicated points (ties), an element that continues from given distances, bit-exact indices."""
+    ops, L = pkg("network.operations"), pkg("_lib")
+    rng = np.random.default_rng(n)
+    b = 5
+    xyz = sphere(n, n, b)
+    xyz[1] = xyz[1][rng.integers(0, n // 3, size=n)]            # every point ~3 times: tie rule
+    n_arr = np.array([n, n, n - 777, 4096 if n > 4096 else n, n - 1], np.int32)
+    m_arr = np.array([m, m, m - 1, 256, m // 2], np.int32)
+    idx = ops.fps(_t(xyz, dev), m, _t(n_arr, dev), _t(m_arr, dev)).cpu().numpy()
+    for i in range(b):
+        ref_idx, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], int(m_arr[i]))
+        np.testing.assert_array_equal(idx[i, :m_arr[i]], ref_idx[0])
+    # dense call through the C ABI: the running distances come back in the caller's order, and a
+    # second call continues from them
+    lib = L.lib()
+    x = _t(xyz[:2], dev)
+    temp = torch.full((2, n), 1e10, dtype=torch.float32, device=dev)
+    out = torch.zeros((2, m), dtype=torch.int32, device=dev)
+    need = lib.tpu3_fps_workspace_bytes(2, n)
+    assert need > 0
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    L.check(lib.tpu3_fps_ragged_f32(L.stream_of(x), 2, n, m, None, None, L.ptr(x), L.ptr(temp), L.ptr(out),
+                                    L.ptr(ws), need), "tpu3_fps_ragged_f32")
+    ref_idx, ref_temp = orc.fps(xyz[:2], m)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+    out2 = torch.zeros((2, 300), dtype=torch.int32, device=dev)
+    L.check(lib.tpu3_fps_ragged_f32(L.stream_of(x), 2, n, 300, None, None, L.ptr(x), L.ptr(temp), L.ptr(out2),
+                                    L.ptr(ws), need), "tpu3_fps_ragged_f32")
+    ref2, ref_temp2 = orc.fps(xyz[:2], 300, temp=ref_temp)
+    np.testing.assert_array_equal(out2.cpu().numpy(), ref2)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp2)
+
+
 def test_fps_bucketed_continues_from_given_temp(orc, dev):
     """temp is in/out: a second call that starts from the first call's distances must behave like
     the plain algorithm started from them (the bucket table is built from the caller's temp)."""

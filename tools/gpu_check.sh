@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -2
+timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -3
