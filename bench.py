@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
     ap.add_argument("--net_streams", type=int, default=4,
                     help="sub-batches of clouds whose network stages run on concurrent streams")
+    ap.add_argument("--sub_batch", type=int, default=4, help="clouds per network sub-batch")
     ap.add_argument("--no_overlap", action="store_true",
                     help="run the final FPS on the main stream instead of a side stream")
     ap.add_argument("--num_shape_point", type=int, default=5000)
@@ -120,9 +121,10 @@ def main():
         if not args.diag_skip_final_fps:
             arm_kernel_events()
         if args.diag_skip_final_fps:
-            return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False,
-                                 net_streams=nets)[:, :, :N * r].contiguous()
-        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=side, net_streams=nets)   # (C,3,N*r)
+            return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False, net_streams=nets,
+                                 sub_batch=args.sub_batch)[:, :, :N * r].contiguous()
+        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=side, net_streams=nets,
+                            sub_batch=args.sub_batch)                                  # (C,3,N*r)
         if world > 1:                                                       # reassemble: ONE all-gather
             if side is not None:
                 with torch.cuda.stream(side):
