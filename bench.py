@@ -215,7 +215,9 @@ def main():
         roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, C),
                 "bound": "hbm", "achieved": alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None,
                 "peak": 8000.0, "unit": "GB/s", "traffic": None,
-                "launch_ms": fps_ms, "operator_ms": op_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                "launch_ms": fps_ms, "operator_ms": op_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                # SURVEY 8d secondary figure: what an on-chip-resident FPS must move at least
+                "compulsory_bytes_per_launch": float(C) * (12.0 * n_merged + 4.0 * m_out)}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
         # HBM traffic of that launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
         # gfx950 correction + WRITE_SIZE, KiB -> bytes); only valid for the profiled configuration

@@ -232,6 +232,37 @@ def test_full_size_config_c2_properties(orc, dev):
     assert float(d_self[:, :, 1].min()) >= float(d_cover.max()) - 1e-6
 
 
+def test_config_c5_shapes_large_patches(orc, dev):
+    """BASELINE config C5 in miniature (num_point = 1024 outer patches, 312-point inner patches):
+    the first level runs on 1024-point patches (multi-tile kNN graph, 1024-point DenseEdgeConv,
+    k = 1024 patch extraction through the sort kernel), later levels re-patch to 312.  Properties:
+    shapes, finiteness, run-to-run determinism, the final FPS bit-exact against the oracle on a
+    prefix, and the level-1 output against the unfused torch formulation of the same weights."""
+    pipe, ops, ups = pkg("pipeline"), pkg("network.operations"), pkg("network.upsampler")
+    net = _net(dev)
+    cand = sphere(5, 20000)
+    cloud = torch.from_numpy(np.ascontiguousarray(cand.transpose(0, 2, 1))).to(dev)
+    P = pipe.num_outer_patches(20000, 1024, 3)
+    assert P == 58
+    merged = pipe.upsample(net, cloud, 1024, 4, 3, final_fps=False)
+    assert tuple(merged.shape) == (1, 3, P * 4096) and torch.isfinite(merged).all()
+    again = pipe.upsample(net, cloud, 1024, 4, 3, final_fps=False)
+    assert torch.equal(merged, again)
+    out = pipe.upsample(net, cloud, 1024, 4, 3)
+    assert tuple(out.shape) == (1, 3, 80000)
+    mcl = merged.transpose(2, 1).contiguous()
+    ref_idx, _ = orc.fps(mcl.cpu().numpy(), 200)
+    np.testing.assert_array_equal(ops.fps(mcl, 200).cpu().numpy(), ref_idx)
+    # level 1 on 1024-point patches: fused kernels vs the plain torch path (grad-enabled branch)
+    _, patches, _ = pipe.extract_outer_patches(cloud, 1024, 3)
+    pn, _, _ = ops.normalize_point_batch(patches.reshape(P, 1024, 3)[:6].transpose(2, 1).contiguous())
+    with torch.no_grad():
+        fused, _ = net.levels["level_1"](pn, pn, None)
+    with torch.enable_grad():
+        plain, _ = net.levels["level_1"](pn, pn, None)
+    assert ((fused - plain.detach()).abs().amax(dim=1) <= 1e-5).float().mean() > 0.99
+
+
 @pytest.mark.parametrize("P,N,k", [(3, 312, 32), (5, 100, 16), (2, 312, 48), (1, 17, 16)])
 def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
     """The MFMA kernel against the plain torch formulation of the same block (fp32 reference of the
