@@ -88,7 +88,7 @@ def shard_range(total, rank, world):
 
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-             timing=None, fps_stream=None, net_streams=None, sub_batch=4):
+             timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0):
     """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
     the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
     Every rank passes the same `clouds` and receives the full result.
@@ -97,7 +97,10 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     `fps_stream`: optional side stream for the final FPS.  That kernel is one long dependent chain
     on ONE compute unit per cloud; on its own stream it overlaps with the network stages of the
     next call, which use the other 255 CUs.  The result is then only valid after that stream has
-    been synchronised (the caller's job).
+    been synchronised (the caller's job).  A LIST of side streams (together with `net_streams`)
+    launches the final FPS per sub-batch, as soon as that sub-batch's network stages are done, on
+    the list's streams in turn starting at `fps_offset`: fewer clouds per launch (one per XCD keeps
+    a cloud's working set in that XCD's L2) and an earlier start.
     `net_streams`: optional list of streams; the clouds are then split into sub-batches of
     `sub_batch` clouds whose network stages run concurrently (round-robin over the streams).  The
     per-level resampling FPS is a latency chain on a few wavefronts per patch set while the kNN /
@@ -105,12 +108,29 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     work."""
     C, _, N = clouds.shape
     rank, world = _world()
+    # main.py:379-380: the one big FPS down to N * up_ratio points per cloud
+    def final(merged):
+        if timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        idx = operations.fps(merged, N * up_ratio)
+        if timing is not None:
+            ev[1].record()
+            timing.append(ev)
+        out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+        return out.transpose(2, 1).contiguous()
+
     if (shard is None or world == 1) and net_streams and len(net_streams) > 1 and C > 1:
         cur = torch.cuda.current_stream()
         parts = []
         per = max(1, min(int(sub_batch), -(-C // len(net_streams))))
+        split_fps = final_fps and isinstance(fps_stream, (list, tuple)) and len(fps_stream) > 0
+        result = clouds.new_empty((C, 3, N * up_ratio)) if split_fps else None
         for s in net_streams:
             s.wait_stream(cur)
+        if split_fps:
+            for f in fps_stream:
+                f.wait_stream(cur)                      # `result` is allocated on the current stream
         for i, lo in enumerate(range(0, C, per)):
             s = net_streams[i % len(net_streams)]
             with torch.cuda.stream(s):
@@ -118,7 +138,18 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
                 _, patches, _ = extract_outer_patches(sub, num_point, patch_num_ratio)
                 P = patches.size(1)
                 up, _ = upsample_patches(net, patches.reshape(sub.size(0) * P, num_point, 3), up_ratio)
-                parts.append(up.reshape(sub.size(0), P * up.size(1), 3))
+                part = up.reshape(sub.size(0), P * up.size(1), 3)
+            if split_fps:
+                f = fps_stream[(fps_offset + i) % len(fps_stream)]
+                f.wait_stream(s)
+                part.record_stream(f)
+                with torch.cuda.stream(f):
+                    result[lo:lo + per].copy_(final(part))
+                result.record_stream(f)
+            else:
+                parts.append(part)
+        if split_fps:
+            return result
         for s in net_streams:
             cur.wait_stream(s)
         for t in parts:
@@ -133,9 +164,11 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
         ids, per = shard_range(C, rank, world)
         mine = clouds[ids]
         local = upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
-                         timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch)
-        if fps_stream is not None:
-            torch.cuda.current_stream().wait_stream(fps_stream)
+                         timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch,
+                         fps_offset=fps_offset)
+        for f in (fps_stream if isinstance(fps_stream, (list, tuple)) else [fps_stream]):
+            if f is not None:
+                torch.cuda.current_stream().wait_stream(f)
         out = _all_gather_cat(local)                         # (world*per, 3, N*r) in cloud order
         return out[:C]
     elif shard == "patches":
@@ -151,18 +184,8 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
         raise ValueError("shard must be None, 'clouds' or 'patches'")
     if not final_fps:
         return merged.transpose(2, 1).contiguous()
-    # main.py:379-380: the one big FPS down to N * up_ratio points per cloud
-    def final(merged):
-        if timing is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        idx = operations.fps(merged, N * up_ratio)
-        if timing is not None:
-            ev[1].record()
-            timing.append(ev)
-        out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
-        return out.transpose(2, 1).contiguous()
-
+    if isinstance(fps_stream, (list, tuple)):
+        fps_stream = fps_stream[fps_offset % len(fps_stream)] if fps_stream else None
     if fps_stream is None:
         return final(merged)
     fps_stream.wait_stream(torch.cuda.current_stream())

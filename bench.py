@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--clouds", type=int, default=16,
                     help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs)")
     ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
+    ap.add_argument("--fps_per_sub_batch", action="store_true",
+                    help="one final-FPS launch per network sub-batch instead of ONE per step (measured: "
+                         "320 vs 279 ms/step -- four times as many compute units sit under a latency chain)")
     ap.add_argument("--net_streams", type=int, default=4,
                     help="sub-batches of clouds whose network stages run on concurrent streams")
     ap.add_argument("--sub_batch", type=int, default=4, help="clouds per network sub-batch")
@@ -113,8 +116,12 @@ def main():
     nets = [torch.cuda.Stream(device=dev) for _ in range(args.net_streams)] if args.net_streams > 1 else None
     counter = [0]
 
+    split = sides is not None and nets is not None and args.fps_per_sub_batch
+    n_sub = -(-C // max(1, min(args.sub_batch, -(-C // max(1, args.net_streams))))) if split else 1
+
     def step():
         side = None if sides is None else sides[counter[0] % len(sides)]
+        off = counter[0] * n_sub
         counter[0] += 1
         # the final FPS of this step (one CU per cloud, a pure latency chain) runs on a side stream
         # and overlaps with the network stages of the NEXT step; everything is inside the timed region
@@ -123,8 +130,13 @@ def main():
         if args.diag_skip_final_fps:
             return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False, net_streams=nets,
                                  sub_batch=args.sub_batch)[:, :, :N * r].contiguous()
-        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=side, net_streams=nets,
-                            sub_batch=args.sub_batch)                                  # (C,3,N*r)
+        out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=sides if split else side,
+                            net_streams=nets, sub_batch=args.sub_batch, fps_offset=off)   # (C,3,N*r)
+        if split:
+            # the step's launches ran on sides[off .. off + n_sub): join them on the first of them
+            side = sides[off % len(sides)]
+            for i in range(1, n_sub):
+                side.wait_stream(sides[(off + i) % len(sides)])
         if world > 1:                                                       # reassemble: ONE all-gather
             if side is not None:
                 with torch.cuda.stream(side):
@@ -211,20 +223,21 @@ def main():
         n_merged = P * npnt * r
         m_out = N * r
         # algorithmic bytes of one final-FPS launch: 20 B per point per round x C clouds
-        alg_bytes = 20.0 * C * n_merged * (m_out - 1)
-        roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, C),
+        CL = min(args.sub_batch, -(-C // max(1, args.net_streams))) if split else C      # clouds per launch
+        alg_bytes = 20.0 * CL * n_merged * (m_out - 1)
+        roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
                 "bound": "hbm", "achieved": alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None,
                 "peak": 8000.0, "unit": "GB/s", "traffic": None,
                 "launch_ms": fps_ms, "operator_ms": op_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 # SURVEY 8d secondary figure: what an on-chip-resident FPS must move at least
-                "compulsory_bytes_per_launch": float(C) * (12.0 * n_merged + 4.0 * m_out)}
+                "compulsory_bytes_per_launch": float(CL) * (12.0 * n_merged + 4.0 * m_out)}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
         # HBM traffic of that launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
         # gfx950 correction + WRITE_SIZE, KiB -> bytes); only valid for the profiled configuration
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic_fb_main.json")) as f:
                 tr = json.load(f)
-            if tr.get("clouds_per_launch") == C and (N, npnt, r) == (5000, 312, 16):
+            if tr.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
                 roof["traffic"] = tr["traffic_bytes_per_launch"]
         except (OSError, ValueError):
             pass
@@ -239,6 +252,7 @@ def main():
                                    "%d outer patches, knn=32, random-init weights, Poisson-sphere input"
                                    % (C, N, npnt, r, P),
                        "clouds_per_gpu": C, "final_fps_overlap": sides is not None,
+                       "final_fps_launches_per_step": n_sub,
                        "parallelism": "clouds sharded, 1 all-gather/step" if world > 1 else "single GPU"},
             "roofline": roof,
             "rooflines_other": extra,

@@ -1,2 +1,6 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_hip_network.py -m gpu -x -q -k "c5" 2>&1 | tail -15
+run() { echo "$@"; timeout 300 python bench.py --no_cpu_baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'] if d.get('roofline') else '', d['roofline'].get('operator_ms'))"; }
+run
+run --fps_per_step
+run --fps_streams 12
+run --steps 5 --warmup 1
