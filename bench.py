@@ -257,7 +257,7 @@ def main():
             "roofline": roof,
             "rooflines_other": extra,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (bench contract)
             from oracle import cpu_baseline
             line["cpu_baseline"] = cpu_baseline.measure(N, npnt, r)
         else:
