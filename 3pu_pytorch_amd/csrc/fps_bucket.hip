@@ -30,6 +30,7 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -121,21 +122,30 @@ __global__ __launch_bounds__(1024) void fb_bbox_kernel(FbArgs a0)
     }
 }
 
+// keys64 != null: ONE device-wide sort of the whole batch on (element << 32 | key) -- every slot of an
+// element's stride gets a key, the padding behind n sorts last like the dead slots of a ragged element
 __global__ __launch_bounds__(256) void fb_morton_kernel(FbArgs a0, uint32_t *__restrict__ keys0,
-                                                        uint32_t *__restrict__ vals0)
+                                                        uint32_t *__restrict__ vals0,
+                                                        unsigned long long *__restrict__ keys64)
 {
     const FbArgs a = fb_elem(a0, blockIdx.y);
     const int n = a.n;
     const float *__restrict__ xyz = a.xyz;
     const float *__restrict__ bbox = a.bbox;
-    uint32_t *__restrict__ keys = keys0 + (size_t)blockIdx.y * a0.sort_stride;
-    uint32_t *__restrict__ vals = vals0 + (size_t)blockIdx.y * a0.sort_stride;
+    const size_t base = (size_t)blockIdx.y * a0.sort_stride;
+    uint32_t *__restrict__ vals = vals0 + base;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a0.n)
+    auto put = [&](uint32_t key) {
+        if (keys64)
+            keys64[base + i] = ((unsigned long long)blockIdx.y << 32) | key;
+        else
+            keys0[base + i] = key;
+        vals[i] = (uint32_t)i;
+    };
+    if (i >= (keys64 ? (int)a0.sort_stride : a0.n))
         return;
     if (i >= n) {               // slot beyond a ragged element's live size: sorts behind every point
-        keys[i] = 0x40000000u;
-        vals[i] = (uint32_t)i;
+        put(0x40000000u);
         return;
     }
     uint32_t code = 0;
@@ -145,8 +155,7 @@ __global__ __launch_bounds__(256) void fb_morton_kernel(FbArgs a0, uint32_t *__r
         q = fminf(fmaxf(q, 0.f), 1023.f);
         code |= spread10((uint32_t)q) << a;
     }
-    keys[i] = code;
-    vals[i] = (uint32_t)i;
+    put(code);
 }
 
 // Morton-ordered float4 (x,y,z,temp) + tie keys; slots past n repeat the last live point with temp = -1
@@ -721,6 +730,8 @@ struct FbPlan {
     int ppl, nw, ngpt, nb, nbpad, npad, ng;
     int rb_rows;          // > 0: register-resident kernel with this many rows per wave
     bool segmented;       // one segmented sort for the batch instead of a device sort per element
+    bool global64;        // large sets, several elements: one device sort on (element << 32 | key)
+    int ebits;            // bits of the element index in that key
     size_t ks, ps, bs;    // byte sizes: key array, per-point float array, bucket word array
     size_t per_elem;      // bytes of one batch element's arrays (sp, skey, ib, bbox)
     size_t sort_bytes;    // 4 key/value arrays x b
@@ -770,10 +781,18 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.ps = align256(sizeof(float) * (size_t)p.npad);
     p.bs = align256(sizeof(uint32_t) * (size_t)p.nbpad);
     p.per_elem = 5 * p.ps + 8 * p.bs + align256(8 * sizeof(float));
-    p.sort_bytes = 4 * p.ks * (size_t)b;
     p.segmented = b >= 4 && n <= 65536 && (size_t)b * (p.ks / 4) < 0x7FFFFFFFu;
+    p.global64 = !p.segmented && b >= 2;
+    p.ebits = 1;
+    while ((1 << p.ebits) < b)
+        ++p.ebits;
+    p.sort_bytes = (p.global64 ? 6 : 4) * p.ks * (size_t)b;       // 64-bit keys in and out + two value arrays
     size_t tb = 0;
-    if (p.segmented) {
+    if (p.global64) {
+        (void)rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                        (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)b * (p.ks / 4), 0,
+                                        32 + p.ebits, (hipStream_t)0);
+    } else if (p.segmented) {
         const unsigned int stride = (unsigned int)(p.ks / 4);
         const FbOffsetIt bi(FbCount(0), FbSegOffset{stride, 0u});
         const FbOffsetIt ei(FbCount(0), FbSegOffset{stride, (unsigned int)n});
@@ -826,6 +845,13 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     // workspace: [k_in | k_out | v_in | v_out] (b x ks each), b element slabs, sort temp
     uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + (size_t)b * p.ks);
     uint32_t *v_in = (uint32_t *)(base + 2 * (size_t)b * p.ks), *v_out = (uint32_t *)(base + 3 * (size_t)b * p.ks);
+    unsigned long long *k64_in = nullptr, *k64_out = nullptr;
+    if (p.global64) {           // [k64_in | k64_out | v_in | v_out]
+        k64_in = (unsigned long long *)base;
+        k64_out = (unsigned long long *)(base + 2 * (size_t)b * p.ks);
+        v_in = (uint32_t *)(base + 4 * (size_t)b * p.ks);
+        v_out = (uint32_t *)(base + 5 * (size_t)b * p.ks);
+    }
     char *slabs = base + p.sort_bytes;
     char *sort_tmp = slabs + (size_t)b * p.per_elem;
     FbArgs a0;
@@ -841,9 +867,15 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     a0.sort_stride = p.ks / 4;
 
     hipLaunchKernelGGL(fb_bbox_kernel, dim3(b), dim3(1024), 0, s, a0);
-    hipLaunchKernelGGL(fb_morton_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0, k_in, v_in);
+    hipLaunchKernelGGL(fb_morton_kernel, dim3((unsigned)((a0.sort_stride + 255) / 256), b), dim3(256), 0, s, a0, k_in,
+                       v_in, k64_in);
     size_t tb = p.sort_temp;
-    if (p.segmented) {
+    if (p.global64) {
+        const hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k64_in, k64_out, v_in, v_out,
+                                                        (size_t)b * a0.sort_stride, 0, 32 + p.ebits, s);
+        if (se != hipSuccess)
+            return (int)se;
+    } else if (p.segmented) {
         const unsigned int stride = (unsigned int)a0.sort_stride;
         const FbOffsetIt bi(FbCount(0), FbSegOffset{stride, 0u});
         const FbOffsetIt ei(FbCount(0), FbSegOffset{stride, (unsigned int)n});
