@@ -42,6 +42,20 @@ def test_argument_validation_without_gpu():
     assert lib.tpu3_gather_fwd(None, 1, 1, 4, 2, 3, 8, 8, 8) == -1         # element size 3
     assert lib.tpu3_knn_f32(None, 1, 4, 8, 3, 9, 8, 8, None, None, None, 8, 8, None, None) == -1  # k > n
     assert lib.tpu3_knn_f32(None, 1, 4, 8, 3, 2, 8, 8, None, None, None, 8, 2, None, None) == -1  # idx size
+    # the entry points added for the network stages
+    assert lib.tpu3_knn_graph_self_f32(None, 1, 8, 3, 17, 8, None, 8, 8, 8, None, 0) == -1      # k > n
+    assert lib.tpu3_knn_graph_self_f32(None, 1, 64, 3, 5, 8, None, 8, 8, 8, None, 0) == -2      # k not 17 / 33
+    assert lib.tpu3_knn_unique_compact_i32(None, 2, 8, None, None, None, None, None) == -1      # NULL pointers
+    assert lib.tpu3_knn_unique_compact_i32(None, 0, 8, None, None, None, None, None) == 0
+    assert lib.tpu3_linear_small_f32(None, 4, 84, 40, 8, 84, 8, None, 1, 8, 40) == -2           # 40 outputs
+    assert lib.tpu3_linear_small_f32(None, 4, 82, 24, 8, 84, 8, None, 1, 8, 24) == -2           # cin % 4
+    assert lib.tpu3_linear_small_f32(None, 4, 84, 24, 8, 80, 8, None, 1, 8, 24) == -1           # stride < cin
+    assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24) == 0
+    assert lib.tpu3_regress_tail_f32(None, 4, 5, *([8] * 10)) == -1                              # r > 4
+    assert lib.tpu3_regress_tail_f32(None, 0, 2, *([None] * 10)) == 0
+    assert lib.tpu3_interlevel_skip_workspace_bytes(3, 312, 5) == 3 * 312 * 12 * 4
+    assert lib.tpu3_interlevel_skip_f32(None, 1, 312, 9, 264, 8, 8, 264, 8, 8, 10, None, 8, 4, 0.2, 0, None, 0) == -1
+    assert lib.tpu3_fps_workspace_bytes(4, 1000) == 0 and lib.tpu3_fps_workspace_bytes(4, 30000) > 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
