@@ -730,6 +730,7 @@ template <int C>
 int dispatch_insert_k(hipStream_t s, int b, const KnnArgs &a)
 {
     if (a.k <= 2) return launch_insert<C, 2>(s, b, a);
+    if (C == 3 && a.k <= 5) return launch_insert<C, 5>(s, b, a);    // the inter-level search (fm_knn = 5)
     if (a.k <= 8) return launch_insert<C, 8>(s, b, a);
     if (a.k <= 16) return launch_insert<C, 16>(s, b, a);
     if (a.k <= 33) return launch_insert<C, 33>(s, b, a);
