@@ -22,10 +22,12 @@
 //   * D = 4 consecutive channels (4g..4g+3) of the lane's edge -- exactly what the next layer's B
 //     operand needs when its step r uses channel 4g+r, so h0/h1 feed the next MFMA straight from
 //     the accumulator registers, no shuffles, no LDS;
-//   * everything that depends on the centre x_i only is hoisted out of the edge loop:
+//   * everything that depends on ONE point only is hoisted out of the edge loop:
 //       W0 e = (W0a - W0b) x_i + W0b x_j,  W1 [h0,x_i] = W1a h0 + W1b x_i,  W2 [..] = W2a h1 + W2b h0 + W2c x_i
 //     the x_i terms (+ bias) are computed for 16 points at a time with the same MFMA and become the
-//     accumulators' initial values: 18 MFMAs per 16-edge tile instead of 33;
+//     accumulators' initial values, and z_j = W0b x_j is a per-POINT table (12 floats per point in
+//     LDS, computed once per patch): the first layer of an edge is a gather of z_j, an add and a
+//     ReLU -- 12 MFMAs per 16-edge tile instead of 33, and 12 instead of 24 gathered floats per edge;
 //   * max over the k edges = elementwise max over the tiles, then one 16-lane DPP row reduction.
 // Summation order differs from a BLAS GEMM (documented tolerance 1e-5 on the network outputs).
 #include "tpu3_dev.h"
@@ -37,7 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DEC_C = 24;        // input channels
 constexpr int DEC_G = 12;        // growth rate
 constexpr int DEC_S = 26;        // LDS row stride of the patch features (floats)
-constexpr int DEC_NW = 4;        // waves per workgroup
+constexpr int DEC_NW = 8;        // waves per workgroup
+constexpr int DEC_ZS = 12;       // floats per point in the z table
 constexpr int DEC_TS = 52;       // floats per point in the per-wave T buffer (3 x 16 + pad)
 
 struct DecArgs {
@@ -101,12 +104,15 @@ __device__ __forceinline__ void row_max12(f32x4 &a, f32x4 &b, f32x4 &c)
     c = (f32x4){v8, v9, v10, v11};
 }
 
-template <int TILES>     // TILES = k / 16
+// ZTAB: the per-point table z = W0b x fits LDS next to the features (patches up to ~700 points);
+// otherwise the first layer's W0b x_j is evaluated per edge (6 more MFMAs per tile).
+template <int TILES, bool ZTAB>     // TILES = k / 16
 __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *xs = lds;                                   // n * DEC_S
     float *tb = lds + ((a.n * DEC_S + 3) & ~3);        // DEC_NW * 16 * DEC_TS
+    float *zt = tb + DEC_NW * 16 * DEC_TS;             // n * DEC_ZS (+ 4 floats of slack)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 15, g = lane >> 4;
     const int n = a.n;
@@ -155,6 +161,19 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
     }
     __syncthreads();
 
+    // ---- z_p = W0b x_p for every point of the patch (columns = points) ------------------------------
+    for (int pb = wave * 16; ZTAB && pb < n; pb += DEC_NW * 16) {
+        const float *xp = xs + min(pb + e, n - 1) * DEC_S + 6 * g;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            z = mfma4(w0b[s], xp[s], z);
+        if (g < 3 && pb + e < n)
+            *(f32x4 *)(zt + (pb + e) * DEC_ZS + 4 * g) = z;
+    }
+    __syncthreads();
+    const int zoff = g < 3 ? 4 * g : 0;     // lanes of the padding channel group read finite values (x 0 weights)
+
     float *T = tb + wave * 16 * DEC_TS;
     for (int pb = wave * 16; pb < n; pb += DEC_NW * 16) {
         // ---- centre terms of 16 points (columns = points) -> T[p][0..15 | 16..31 | 32..47] --------
@@ -187,10 +206,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
         load_idx(pb, jn);
         for (int p = 0; p < pend; ++p) {
             const int i = pb + p;
-            const float *xj[TILES];
+            const float *zj[TILES];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
-                xj[t] = xs + min(max(jn[t], 0), n - 1) * DEC_S + 6 * g;
+            for (int t = 0; t < TILES; ++t) {
+                const int j = min(max(jn[t], 0), n - 1);
+                zj[t] = ZTAB ? zt + j * DEC_ZS + zoff : xs + j * DEC_S + 6 * g;
+            }
             if (p + 1 < pend)
                 load_idx(i + 1, jn);
             const f32x4 c0 = *(const f32x4 *)(T + p * DEC_TS + 4 * g);
@@ -199,21 +220,32 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
             // the TILES edge tiles of the point are independent accumulator chains: issuing their
             // MFMAs alternately hides the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
             f32x4 h0[TILES], h1[TILES], h2[TILES];
+            if (ZTAB) {
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
-                h0[t] = c0;
+                for (int t = 0; t < TILES; ++t) {
+                    const f32x4 z = *(const f32x4 *)zj[t];
 #pragma unroll
-            for (int s = 0; s < 6; ++s)
+                    for (int r = 0; r < 4; ++r)
+                        h0[t][r] = fmaxf(c0[r] + z[r], 0.f);
+                }
+            } else {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t)
-                    h0[t] = mfma4(w0b[s], xj[t][s], h0[t]);
+                    h0[t] = c0;
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
+                for (int s = 0; s < 6; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h0[t][r] = fmaxf(h0[t][r], 0.f);
-                h1[t] = c1;
+                    for (int t = 0; t < TILES; ++t)
+                        h0[t] = mfma4(w0b[s], zj[t][s], h0[t]);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h0[t][r] = fmaxf(h0[t][r], 0.f);
             }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                h1[t] = c1;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -271,22 +303,28 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (patches == 0) return TPU3_OK;
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return TPU3_EINVAL;
     if (((uintptr_t)out % 16) != 0) return TPU3_EINVAL;
-    const size_t lds = ((size_t)((n * DEC_S + 3) & ~3) + (size_t)DEC_NW * 16 * DEC_TS) * sizeof(float);
+    const size_t base = (size_t)((n * DEC_S + 3) & ~3) + (size_t)DEC_NW * 16 * DEC_TS;
+    const size_t with_z = (base + (size_t)n * DEC_ZS + 4) * sizeof(float);
+    const bool ztab = with_z <= 160 * 1024;
+    const size_t lds = ztab ? with_z : base * sizeof(float);
     if (lds > 160 * 1024) return TPU3_ELIMIT;
     DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride};
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define DEC_LAUNCH(T)                                                                                    \
-    e = hipFuncSetAttribute((const void *)dec_fused_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+#define DEC_LAUNCH1(T, Z)                                                                                \
+    e = hipFuncSetAttribute((const void *)dec_fused_kernel<T, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds);                                                                   \
     if (e != hipSuccess) return (int)e;                                                                  \
-    hipLaunchKernelGGL(dec_fused_kernel<T>, dim3(patches), dim3(DEC_NW * 64), lds, s, a)
+    hipLaunchKernelGGL((dec_fused_kernel<T, Z>), dim3(patches), dim3(DEC_NW * 64), lds, s, a)
+#define DEC_LAUNCH(T)                                                                                    \
+    if (ztab) { DEC_LAUNCH1(T, true); } else { DEC_LAUNCH1(T, false); }
     switch (k / 16) {
     case 1: DEC_LAUNCH(1); break;
     case 2: DEC_LAUNCH(2); break;
     case 3: DEC_LAUNCH(3); break;
     default: DEC_LAUNCH(4); break;
     }
+#undef DEC_LAUNCH1
 #undef DEC_LAUNCH
     return tpu3_launch_status();
 }
