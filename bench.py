@@ -48,7 +48,7 @@ def poisson_sphere(seed, n, dev, ops):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clouds", type=int, default=32,
                     help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs; more clouds in flight amortise the final-FPS latency chain)")
