@@ -31,10 +31,13 @@ class HipBackend(object):
 
     COMPACT_MIN_N = 1024      # unique=True: point sets this large get a first-occurrence list
 
-    def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True):
+    def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True, unique_cache=None):
         """query (B,M,C), points (Bp,N,C) f32 contiguous device tensors ->
         idx int64 (B,M,k), dist f32 (B,M,k) | None, grouped f32 (B,M,k,C) | None.
-        layout: None or dict(n_arr=, m_arr=, pts_of=, grp=, groups=) of int32 device tensors."""
+        layout: None or dict(n_arr=, m_arr=, pts_of=, grp=, groups=) of int32 device tensors.
+        unique_cache: optional dict owned by the caller; the de-duplication state of `points`
+        (first-occurrence mask, flags, candidate lists) is kept in it and reused by later calls that
+        search the SAME point sets (the chunks of one Level call), instead of being rebuilt."""
         L.require_device(query, "query")
         L.require_device(points, "points")
         L.require_dtype(query, torch.float32, "query")
@@ -72,24 +75,34 @@ class HipBackend(object):
             s = L.stream_of(query)
             dup = uws = None
             if unique:
-                dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
-                uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
-                need = lib.tpu3_knn_unique_workspace_bytes(bp, n)
-                ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
-                L.check(lib.tpu3_knn_unique_prepare_f32(s, b, m, n, c, L.ptr(query), L.ptr(points),
-                                                        lay_ref, L.ptr(dup), L.ptr(uws), L.ptr(ws), need),
-                        "tpu3_knn_unique_prepare_f32")
-                if n >= self.COMPACT_MIN_N and k <= 64 and c <= 32:
-                    # list of first occurrences: the search then skips the duplicated rows entirely
-                    cand = torch.empty((bp, n), dtype=torch.int32, device=dev)
-                    cand_count = torch.empty((bp,), dtype=torch.int32, device=dev)
+                n_arr_t = layout.get("n_arr") if layout is not None else None
+                key = (points.data_ptr(), tuple(points.shape), 0 if n_arr_t is None else n_arr_t.data_ptr(), groups)
+                st = unique_cache.get("state") if unique_cache is not None else None
+                if st is not None and st["key"] == key:
+                    dup, uws, cand, cand_count = st["dup"], st["uws"], st["cand"], st["cand_count"]
+                else:
+                    dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
+                    uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
+                    need = lib.tpu3_knn_unique_workspace_bytes(bp, n)
+                    ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
+                    L.check(lib.tpu3_knn_unique_prepare_f32(s, b, m, n, c, L.ptr(query), L.ptr(points),
+                                                            lay_ref, L.ptr(dup), L.ptr(uws), L.ptr(ws), need),
+                            "tpu3_knn_unique_prepare_f32")
+                    cand = cand_count = None
+                    if n >= self.COMPACT_MIN_N and k <= 64 and c <= 32:
+                        # list of first occurrences: the search then skips the duplicated rows entirely
+                        cand = torch.empty((bp, n), dtype=torch.int32, device=dev)
+                        cand_count = torch.empty((bp,), dtype=torch.int32, device=dev)
+                        L.check(lib.tpu3_knn_unique_compact_i32(s, bp, n, L.ptr(n_arr_t), L.ptr(dup), L.ptr(uws),
+                                                                L.ptr(cand), L.ptr(cand_count)),
+                                "tpu3_knn_unique_compact_i32")
+                    if unique_cache is not None:
+                        unique_cache["state"] = dict(key=key, dup=dup, uws=uws, cand=cand, cand_count=cand_count)
+                if cand is not None:
                     if lay is None:
                         lay = L.KnnLayout()
                         lay.bp, lay.groups = bp, 1
                         lay_ref = ctypes.byref(lay)
-                    L.check(lib.tpu3_knn_unique_compact_i32(s, bp, n, lay.n_arr, L.ptr(dup), L.ptr(uws),
-                                                            L.ptr(cand), L.ptr(cand_count)),
-                            "tpu3_knn_unique_compact_i32")
                     lay.cand, lay.cand_count = L.ptr(cand), L.ptr(cand_count)
             L.check(lib.tpu3_knn_f32(s, b, m, n, c, k, L.ptr(query), L.ptr(points), lay_ref, L.ptr(dup),
                                      L.ptr(uws), L.ptr(idx), 8, L.ptr(dist), L.ptr(grouped)),
@@ -308,9 +321,12 @@ def normalize_point_batch(pc, NCHW=True):
     return pc, centroid, furthest_distance
 
 
-def knn_query(k, query, points, unique=True, layout=None, want_dist=True, want_grouped=True):
+def knn_query(k, query, points, unique=True, layout=None, want_dist=True, want_grouped=True, unique_cache=None):
     """Channel-last kNN: query (B,M,C), points (Bp,N,C) -> (idx int64 (B,M,k), dist (B,M,k),
     grouped (B,M,k,C)).  The batched / ragged form of group_knn (see HipBackend.knn)."""
+    if unique_cache is not None:
+        return BACKEND.knn(k, query.contiguous(), points.contiguous(), unique, layout, want_dist, want_grouped,
+                           unique_cache=unique_cache)
     return BACKEND.knn(k, query.contiguous(), points.contiguous(), unique, layout, want_dist, want_grouped)
 
 

@@ -291,14 +291,16 @@ class Level(torch.nn.Module):
         total = self.layer0.conv.out_channels + sum(b.in_channels + b.n * b.growth_rate for b in blocks)
         feat_all = xyz_normalized.new_empty((B, xyz_normalized.size(1), total))
         outs = []
+        ucache = {} if hasattr(operations.BACKEND, "knn_graph") else None     # de-dup state of `previous`
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             own = None if owner is None else owner[lo:hi].contiguous()
             o, _ = self._forward_cl(xyz[lo:hi], xyz_normalized[lo:hi], previous, own, groups, per_owner,
-                                    feat_buf=feat_all[lo:hi])
+                                    feat_buf=feat_all[lo:hi], unique_cache=ucache)
             outs.append(o)
         return torch.cat(outs, dim=0), feat_all
 
-    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0, feat_buf=None):
+    def _forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0, feat_buf=None,
+                    unique_cache=None):
         """Channel-last level:
             xyz, xyz_normalized  (B,N,3)
             previous             None or (prev_xyz (Bp,M,3), prev_feat (Bp,M,C), prev_count (Bp,)|None)
@@ -353,7 +355,7 @@ class Level(torch.nn.Module):
             with torch.no_grad():
                 knn_idx, _, knn_points = operations.knn_query(
                     self.fm_knn, xyz.detach(), prev_xyz.detach(), unique=True, layout=layout,
-                    want_dist=False, want_grouped=not fused)
+                    want_dist=False, want_grouped=not fused, unique_cache=unique_cache)
             if fused:
                 operations.BACKEND.interlevel_skip(
                     xyz.contiguous(), x, prev_xyz.contiguous(), prev_feat.contiguous(),
