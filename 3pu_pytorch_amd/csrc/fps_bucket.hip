@@ -676,42 +676,45 @@ __global__ __launch_bounds__(1024) void rb_main_kernel(FbArgs a0)
                     rowmax = lane == decltype(jc)::value ? wm : rowmax;
                 }
             });
-        // ---- this wave's best row -----------------------------------------------------------------------
+        // ---- this wave's best row: every lane fetches ITS row's record while the maxima are reduced, so
+        // the winner can publish without a second LDS round trip ----------------------------------------------
+        const int lj = min(lane, R - 1);
+        const uint32_t rk = tw[5 * lj + 1];
+        const float rx = __uint_as_float(tw[5 * lj + 2]), ry = __uint_as_float(tw[5 * lj + 3]);
+        const float rz = __uint_as_float(tw[5 * lj + 4]);
         const int mine = lane < R ? rowmax : (int)0x80000000;
         const int wv = tpu3_wave_max_i32_fast(mine);
         unsigned long long tie = __ballot(mine == wv);
         if (__builtin_popcountll(tie) != 1) {
-            const uint32_t k = lane < R ? tw[5 * lane + 1] : 0xFFFFFFFFu;
-            const uint32_t kmin = tpu3_wave_min_u32(mine == wv ? k : 0xFFFFFFFFu);
-            tie = __ballot(mine == wv && k == kmin);
+            const uint32_t kmin = tpu3_wave_min_u32(mine == wv ? rk : 0xFFFFFFFFu);
+            tie = __ballot(mine == wv && rk == kmin);
         }
-        const int bj = (int)__builtin_ctzll(tie | (1ull << 63)) % R;
         const int par = r & 1;
-        if (lane == 0) {
+        if (lane == (int)__builtin_ctzll(tie | (1ull << 63))) {
             sl.d[par][wave] = wv;
-            sl.key[par][wave] = tw[5 * bj + 1];
-            sl.x[par][wave] = __uint_as_float(tw[5 * bj + 2]);
-            sl.y[par][wave] = __uint_as_float(tw[5 * bj + 3]);
-            sl.z[par][wave] = __uint_as_float(tw[5 * bj + 4]);
+            sl.key[par][wave] = rk;
+            sl.x[par][wave] = rx; sl.y[par][wave] = ry; sl.z[par][wave] = rz;
         }
         __syncthreads();
-        // ---- arg-max over the 16 waves (one DPP row) -------------------------------------------------------
+        // ---- arg-max over the 16 waves (one DPP row); lane l < 16 holds wave l's whole slot ----------------
         const int sd = lane < NW ? sl.d[par][lane] : (int)0x80000000;
         const uint32_t sk = lane < NW ? sl.key[par][lane] : 0xFFFFFFFFu;
+        const float sx = sl.x[par][lane & (NW - 1)], sy = sl.y[par][lane & (NW - 1)], sz = sl.z[par][lane & (NW - 1)];
         const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
         unsigned long long who = __ballot(lane < NW && sd == gbest);
         if (__builtin_popcountll(who) != 1) {
-            const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
-            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
+            const uint32_t wk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
+            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)wk, 0);
             who = __ballot(lane < NW && sd == gbest && sk == win);
         }
         const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
         // (uniform values: keep them in SGPRs)
-        qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.x[par][ww])));
-        qy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.y[par][ww])));
-        qz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sl.z[par][ww])));
+        qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), ww));
+        qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), ww));
+        qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), ww));
+        const uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
         if (tid == 0)
-            a.idx[r] = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
+            a.idx[r] = tpu3_fps_tiekey_to_index(wkey, lb);
     }
     // final running distances, back in the caller's order
 #pragma unroll
