@@ -527,6 +527,9 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
         if (PROF) tk3 = __builtin_amdgcn_s_memtime();
         const int sd = lane < NW ? sl.d[par][lane] : (int)0x80000000;
         const uint32_t sk = lane < NW ? sl.key[par][lane] : 0xFFFFFFFFu;
+        // lane l < NW holds wave l's whole slot: the winner's coordinates come by readlane, not by a
+        // second LDS round trip
+        const float sx = sl.x[par][lane & (NW - 1)], sy = sl.y[par][lane & (NW - 1)], sz = sl.z[par][lane & (NW - 1)];
         const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
         unsigned long long who = __ballot(lane < NW && sd == gbest);
         if (__builtin_popcountll(who) != 1) {
@@ -535,11 +538,11 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
             who = __ballot(lane < NW && sd == gbest && sk == win);
         }
         const int ww = __builtin_ctzll(who | (1ull << 63)) & 7;
-        qx = sl.x[par][ww];
-        qy = sl.y[par][ww];
-        qz = sl.z[par][ww];
+        qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), ww));
+        qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), ww));
+        qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), ww));
         if (tid == 0)
-            a.idx[r] = tpu3_fps_tiekey_to_index(sl.key[par][ww], lb);
+            a.idx[r] = tpu3_fps_tiekey_to_index((uint32_t)__builtin_amdgcn_readlane((int)sk, ww), lb);
         if (PROF) {
             const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
             pc[0] += tk1 - tk0; pc[1] += tk2 - tk1; pc[2] += tk3 - tk2; pc[3] += tk4 - tk3;
