@@ -353,7 +353,7 @@ template <int LOG2S>
 __global__ __launch_bounds__(1024) void knn_sort_kernel(KnnArgs a)
 {
     constexpr int S = 1 << LOG2S;
-    __shared__ uint64_t keys[S];
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];     // S keys (up to 128 KiB)
     const int b = blockIdx.y, qi = blockIdx.x;
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int n = a.n_arr ? a.n_arr[pb] : a.n;
@@ -752,17 +752,23 @@ int launch_sort(hipStream_t s, int b, const KnnArgs &a)
 {
     constexpr int S = 1 << LOG2S;
     const int threads = S / 2 > 1024 ? 1024 : (S / 2 < 64 ? 64 : S / 2);
-    hipLaunchKernelGGL((knn_sort_kernel<LOG2S>), dim3(a.m, b), dim3(threads), 0, s, a);
+    const size_t lds = (size_t)S * sizeof(uint64_t);
+    const hipError_t e = hipFuncSetAttribute((const void *)knn_sort_kernel<LOG2S>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((knn_sort_kernel<LOG2S>), dim3(a.m, b), dim3(threads), lds, s, a);
     return tpu3_launch_status();
 }
 
 int dispatch_sort(hipStream_t s, int b, const KnnArgs &a)
 {
     // slots: at least 2k (so every pass makes progress) and, if it fits, the whole candidate
-    // set in one pass; capped at 8192 keys = 64 KiB of LDS
+    // set in one pass; 8192 keys = 64 KiB of LDS, 16 384 only when k asks for it (the training
+    // data path extracts label patches of 16 x 312 = 4992 points)
     long need = a.n < 2L * a.k ? 2L * a.k : a.n;
+    if (2L * a.k > 16384) return TPU3_ELIMIT;
+    if (2L * a.k > 8192) return launch_sort<14>(s, b, a);
     if (need > 8192) need = 8192;
-    if (2L * a.k > 8192) return TPU3_ELIMIT;
     if (need <= 128) return launch_sort<7>(s, b, a);
     if (need <= 256) return launch_sort<8>(s, b, a);
     if (need <= 512) return launch_sort<9>(s, b, a);

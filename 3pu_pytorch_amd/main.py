@@ -7,8 +7,8 @@
 final FPS, de-normalise, write `<name>_input.ply` / `<name>.ply`) with the per-patch Python loop of
 pc_prediction (:214-246) replaced by the batched pipeline.  `--phase train` runs Model.optimize
 (model.py:53-66) with the reference's curriculum bookkeeping (main.py:118-124,141-182) on patch
-pairs; the HDF5 dataset (data.py) is a "next" row (h5py is not in this image) -- `--h5_data synthetic`
-trains on synthetic sphere pairs of the same array shapes.  `--phase vis` (interactive matplotlib) is
+pairs drawn from the data set (`--h5_data <file>`: data.py's H5Dataset, device-resident; .npz, or .hdf5
+with h5py) or, with `--h5_data synthetic`, from generated sphere pairs of the same array shapes.  `--phase vis` (interactive matplotlib) is
 out of scope.  Unlike the reference nothing is parsed or built at import time.
 """
 import argparse
@@ -140,15 +140,50 @@ def synthetic_pairs(batch_size, num_point, ratio, device, seed):
 
 
 def train(flags, net, device, num_point, model_dir):
-    """main.py:127-211 without visdom; curriculum: one more ratio per stage, Chamfer threshold after
-    60 % of a stage."""
-    if flags.h5_data != "synthetic":
-        raise SystemExit("--phase train: the HDF5 dataset path (data.py) needs h5py, which is outside the hot "
-                         "path and not in this image; use --h5_data synthetic")
+    """main.py:127-211 without visdom.  `--h5_data <file>`: the reference's loop over H5Dataset
+    (data.py; resident on the device, .npz or -- with h5py -- .hdf5) with its stage logic: a new
+    ratio per stage, "combined" sampling after half a stage, Chamfer threshold after 60 %.
+    `--h5_data synthetic`: the same schedule over generated Poisson-sphere pairs (no file needed)."""
     net.to(device)
     net.train()
     model = Model(net, "train", flags)
-    steps_per_epoch = int(os.environ.get("TPU3_STEPS_PER_EPOCH", "100"))
+    steps_per_epoch = int(os.environ.get("TPU3_STEPS_PER_EPOCH", "0"))
+    if flags.h5_data != "synthetic":
+        from .data import H5Dataset
+        dataset = H5Dataset(h5_path=flags.h5_data, num_shape_point=flags.num_shape_point, num_patch_point=num_point,
+                            batch_size=flags.batch_size, up_ratio=flags.up_ratio, step_ratio=flags.step_ratio,
+                            device=device)
+        steps_per_epoch = steps_per_epoch or len(dataset)
+        start_epoch = model.step // steps_per_epoch
+        stage, progress = get_stage_progress(model.step, flags.stage_steps)
+        dataset.set_max_ratio(flags.step_ratio ** (stage + 1))
+        if progress > 0.5:
+            dataset.set_combined()
+            if progress > 0.6:
+                model.chamfer_criteria.set_threshold(flags.cd_threshold)
+        else:
+            model.chamfer_criteria.unset_threshold()
+            dataset.unset_combined()
+        for epoch in range(start_epoch + 1, flags.max_epoch):
+            for i in range(steps_per_epoch):
+                input_pc, label_pc, ratio = dataset[i]           # device tensors (B,3,M), (B,3,r*M)
+                model.set_input(input_pc, ratio, label_pc=label_pc)
+                model.optimize()
+                new_stage, new_progress = get_stage_progress(model.step, flags.stage_steps)
+                if stage + 1 == new_stage:                      # next stage: one more ratio
+                    dataset.add_next_ratio()
+                    dataset.unset_combined()
+                    model.chamfer_criteria.unset_threshold()
+                if progress <= 0.5 and new_progress > 0.5:
+                    dataset.set_combined()
+                if new_progress > 0.6:
+                    model.chamfer_criteria.set_threshold(flags.cd_threshold)
+                stage, progress = new_stage, new_progress
+            print("epoch %d: " % epoch + ", ".join(["{}={}".format(k, v) for k, v in model.error_log.items()]))
+            if epoch % 20 == 0:
+                pytorch_utils.save_network(net, model_dir, "model", epoch_label=str(epoch), step=str(model.step))
+        return
+    steps_per_epoch = steps_per_epoch or 100
     start_epoch = model.step // steps_per_epoch
     stage, progress = get_stage_progress(model.step, flags.stage_steps)
     num_levels = net.num_levels

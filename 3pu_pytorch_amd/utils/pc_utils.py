@@ -1,6 +1,8 @@
 """Point-cloud I/O and host-side normalisation -- counterpart of the parts of the reference's
 utils/pc_utils.py that the `--phase test` flow uses (normalize_point_cloud :11-25,
-jitter_perturbation_point_cloud :28-42, load :223-241, save_ply :244-285).  numpy only (the
+jitter_perturbation_point_cloud :28-42, load :223-241, save_ply :244-285) and of the augmentation
+helpers the training data path uses (rotate_point_cloud_and_gt :45-79,
+random_scale_point_cloud_and_gt :82-97).  numpy only (the
 reference needs the third-party `plyfile`; the PLY subset it reads/writes -- a `vertex` element with
 float x,y,z first -- is parsed here directly)."""
 import os
@@ -25,6 +27,50 @@ def jitter_perturbation_point_cloud(batch_data, sigma=0.005, clip=0.02, is_2D=Fa
     jittered = np.clip(sigma * np.random.randn(B, N, C).astype(batch_data.dtype), -clip, clip)
     jittered[:, :, chn:] = 0
     return jittered + batch_data
+
+
+def rotation_matrices(batch, dtype=np.float32):
+    """`batch` random rotations Rz Ry Rx, drawn exactly like the reference's augmentation draws
+    them (one np.random.uniform(size=3) per element, angles in [0, 2 pi), matrices built in `dtype`;
+    reference :53-65).  Returned as (batch, 3, 3); points are rotated as p @ R."""
+    out = np.empty((batch, 3, 3), dtype=dtype)
+    for k in range(batch):
+        angles = np.random.uniform(size=(3)) * 2 * np.pi
+        Rx = np.array([[1, 0, 0],
+                       [0, np.cos(angles[0]), -np.sin(angles[0])],
+                       [0, np.sin(angles[0]), np.cos(angles[0])]], dtype=dtype)
+        Ry = np.array([[np.cos(angles[1]), 0, np.sin(angles[1])],
+                       [0, 1, 0],
+                       [-np.sin(angles[1]), 0, np.cos(angles[1])]], dtype=dtype)
+        Rz = np.array([[np.cos(angles[2]), -np.sin(angles[2]), 0],
+                       [np.sin(angles[2]), np.cos(angles[2]), 0],
+                       [0, 0, 1]], dtype=dtype)
+        out[k] = np.dot(Rz, np.dot(Ry, Rx))
+    return out
+
+
+def rotate_point_cloud_and_gt(batch_data, batch_gt=None):
+    """Random rotation per batch element, the same one for input and ground truth, in place
+    (reference :45-79).  (B,N,3) or (B,N,6) with normals in the last three channels."""
+    R = rotation_matrices(batch_data.shape[0], batch_data.dtype)
+    for k in range(batch_data.shape[0]):
+        for arr in (batch_data, batch_gt):
+            if arr is None:
+                continue
+            arr[k, ..., 0:3] = np.dot(arr[k, ..., 0:3].reshape((-1, 3)), R[k])
+            if arr.shape[-1] > 3:
+                arr[k, ..., 3:] = np.dot(arr[k, ..., 3:].reshape((-1, 3)), R[k])
+    return batch_data, batch_gt
+
+
+def random_scale_point_cloud_and_gt(batch_data, batch_gt=None, scale_low=0.5, scale_high=2):
+    """Random isotropic scale per batch element (reference :82-97)."""
+    B = batch_data.shape[0]
+    scales = np.random.uniform(scale_low, scale_high, (B, 1, 1)).astype(batch_data.dtype)
+    batch_data = np.concatenate([batch_data[:, :, :3] * scales, batch_data[:, :, 3:]], axis=-1)
+    if batch_gt is not None:
+        batch_gt = np.concatenate([batch_gt[:, :, :3] * scales, batch_gt[:, :, 3:]], axis=-1)
+    return batch_data, batch_gt, np.squeeze(scales)
 
 
 _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4",

@@ -104,3 +104,50 @@ def import_reference():
             elif k in sys.modules and k != "network":
                 del sys.modules[k]
     return ops, layers, ups, loss
+
+
+class _FakeH5File:
+    """h5py.File stand-in over a dict of arrays (dataset access `f[name][...]` and `close`)."""
+
+    def __init__(self, store):
+        self._store = store
+
+    def __getitem__(self, name):
+        return np.array(self._store[name])          # a fresh array, like a dataset read
+
+    def close(self):
+        pass
+
+
+def import_reference_data(store):
+    """Import the reference's data.py (H5Dataset) with `h5py` served from `store` (a dict
+    dataset-name -> array standing for the HDF5 file) and `plyfile` stubbed; its group_knn is the
+    reference's own (through import_reference).  Build container only."""
+    ops, layers, ups, loss = import_reference()
+    saved = {k: sys.modules.get(k) for k in ("h5py", "plyfile", "network", "network.operations", "misc",
+                                              "misc.logger", "utils", "utils.pc_utils", "data")}
+    h5 = types.ModuleType("h5py")
+    h5.File = lambda path, mode="r": _FakeH5File(store)
+    sys.modules["h5py"] = h5
+    sys.modules["plyfile"] = types.ModuleType("plyfile")
+    net_pkg = types.ModuleType("network")
+    net_pkg.operations = ops
+    sys.modules["network"] = net_pkg
+    sys.modules["network.operations"] = ops
+    for k in ("misc", "misc.logger", "utils", "utils.pc_utils", "data"):
+        sys.modules.pop(k, None)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        data = importlib.import_module("data")
+        pcu = importlib.import_module("utils.pc_utils")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for k in ("misc", "misc.logger", "utils", "utils.pc_utils", "data"):
+            if k in sys.modules:
+                sys.modules["_ref_" + k] = sys.modules.pop(k)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+    return data, pcu

@@ -314,6 +314,7 @@ def _knn_check(orc, dev, k, q, p, unique, layout=None):
     (64, 2, 100, 400, 7, False),       # odd channel counts / k
     (100, 2, 50, 300, 40, True),       # c > 32 and k > 64 -> sort kernel, generic dmax
     (1024, 1, 3, 20000, 3, False),     # chunked sort (n > LDS tile)
+    (4992, 1, 4, 30000, 3, True),      # label patches of the training data path (16 x 312): 16 384-key sort
     (1, 1, 5, 9, 3, False),
     (9, 1, 5, 9, 3, False),            # k == n
 ])

@@ -384,3 +384,27 @@ def test_cli_test_and_train_phases(dev, tmp_path, monkeypatch):
     monkeypatch.setenv("TPU3_STEPS_PER_EPOCH", "2")
     main.main(["--phase", "train", "--h5_data", "synthetic", "--num_point", "312", "--up_ratio", "4",
                "--batch_size", "4", "--max_epoch", "2", "--stage_steps", "1", "--log_dir", str(tmp_path)])
+    # the data set path: a small file in the reference's layout, resident on the device
+    h5 = pkg("data").write_synthetic(str(tmp_path), num_shapes=2, points=(1000, 2000, 4000))
+    main.main(["--phase", "train", "--h5_data", h5, "--num_point", "312", "--num_shape_point", "1000",
+               "--up_ratio", "4", "--batch_size", "4", "--max_epoch", "2", "--stage_steps", "1",
+               "--log_dir", str(tmp_path), "--id", "h5run"])
+
+
+def test_data_path_on_device_matches_reference_items(dev):
+    """data.H5Dataset on the device (patches through tpu3_knn_f32, incl. the sort kernel for
+    k = 256) against the items the reference's data.py produced (tests/golden/data_path.npz)."""
+    data = pkg("data")
+    g = golden("data_path.npz")
+    store = {k[len("store_"):]: g[k] for k in g.files if k.startswith("store_")}
+    ds = data.H5Dataset(str(g["file_name"]), num_shape_point=312, num_patch_point=64, up_ratio=4, step_ratio=2,
+                        batch_size=4, store=store, device=dev)
+    assert ds.input_array.is_cuda
+    for i in range(6):
+        if i == 4:
+            ds.unset_combined()
+            ds.set_max_ratio(2)
+        a, b, r = ds[i]
+        assert a.is_cuda and r == int(g["item%d_ratio" % i])
+        np.testing.assert_allclose(a.cpu().numpy(), g["item%d_input" % i], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(b.cpu().numpy(), g["item%d_label" % i], atol=1e-6, rtol=0)

@@ -1,3 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k fps 2>&1 | tail -2
-python tools/fps_probe.py 2>&1 | head -8
+timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -2
