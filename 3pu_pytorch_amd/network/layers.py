@@ -22,10 +22,42 @@ import torch.nn.functional as F
 from . import operations
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x W^T + b for few outputs over very many rows (the dense layers of DenseEdgeConv in
+    training: B*N*k rows, 12 outputs).  Forward and dX are ordinary GEMMs; dW = dy^T x is a 48 x 12
+    reduction over ~3e5 rows that the vendor GEMM runs at 0.6 TFLOP/s -- it goes through the
+    streaming MFMA kernel tpu3_linear_wgrad_f32 (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gy2 = gy.reshape(-1, gy.size(-1))
+        gx = gy.matmul(weight) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = operations.BACKEND.linear_wgrad(x.reshape(-1, x.size(-1)), gy2)
+            if gw is None:
+                gw = gy2.t().matmul(x.reshape(-1, x.size(-1)))
+        if ctx.needs_input_grad[2]:
+            gb = gy2.sum(dim=0)
+        return gx, gw, gb
+
+
 def linear_1x1(conv, x):
     """Apply a kernel-size-1 nn.Conv1d / nn.Conv2d to channel-last activations (..., C_in)."""
     w = conv.weight
-    return F.linear(x, w.view(w.size(0), w.size(1)), conv.bias)
+    w2 = w.view(w.size(0), w.size(1))
+    if (torch.is_grad_enabled() and w.requires_grad and x.is_cuda and w.size(0) <= 16 and w.size(1) <= 64
+            and x.numel() // x.size(-1) >= 16384 and x.is_contiguous() and conv.bias is not None
+            and hasattr(operations.BACKEND, "linear_wgrad")):
+        return _SkinnyLinear.apply(x, w2, conv.bias)
+    return F.linear(x, w2, conv.bias)
 
 
 class DenseEdgeConv(nn.Module):

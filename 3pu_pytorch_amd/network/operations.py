@@ -264,6 +264,22 @@ class HipBackend(object):
                     "tpu3_linear_small_f32")
         return y
 
+    def linear_wgrad(self, x, dy):
+        """x (M, C_in), dy (M, C_out) f32 rows with unit channel stride -> dW (C_out, C_in) =
+        dy^T x, or None when the shape is not covered (C_out <= 16, C_in <= 64)."""
+        m, cin = x.shape
+        cout = dy.size(1)
+        if cout > 16 or cin > 64 or x.stride(1) != 1 or dy.stride(1) != 1 or x.dtype != torch.float32:
+            return None
+        lib = L.lib()
+        need = lib.tpu3_linear_wgrad_workspace_bytes(m)
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(lib.tpu3_linear_wgrad_f32(L.stream_of(x), m, cin, cout, L.ptr(x), x.stride(0), L.ptr(dy),
+                                              dy.stride(0), L.ptr(dw), L.ptr(ws), need), "tpu3_linear_wgrad_f32")
+        return dw
+
     def regress_tail(self, a, c, w2, b2, w3, b3, w4, b4, residual):
         """a (M,128), c (r,128), residual (M,3) -> (M*r, 3); see tpu3_regress_tail_f32."""
         m, r = a.size(0), c.size(0)

@@ -242,6 +242,16 @@ int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, c
                           const float *w2, const float *b2, const float *w3, const float *b3,
                           const float *w4, const float *b4, const float *residual, float *out);
 
+/* Training: weight gradient of a kernel-size-1 convolution with few outputs over very many rows
+ * (the dense layers of DenseEdgeConv, network/layers.py:53-61: 48/36/48 -> 12 channels over
+ * B*N*k rows; what autograd computes for nn.Conv2d there):
+ *   dw[o][c] = sum_i dy[i][o] * x[i][c],  x (m, x_stride), dy (m, dy_stride), dw (cout, cin) row-major.
+ * cout <= 16, cin <= 64 (else TPU3_ELIMIT).  Deterministic (two stages, no atomics); workspace =
+ * tpu3_linear_wgrad_workspace_bytes(m) device bytes.  fp32 MFMA. */
+int tpu3_linear_wgrad_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                          const float *dy, int dy_stride, float *dw, void *workspace, size_t workspace_bytes);
+size_t tpu3_linear_wgrad_workspace_bytes(long m);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,

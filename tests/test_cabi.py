@@ -51,6 +51,9 @@ def test_argument_validation_without_gpu():
     assert lib.tpu3_linear_small_f32(None, 4, 82, 24, 8, 84, 8, None, 1, 8, 24) == -2           # cin % 4
     assert lib.tpu3_linear_small_f32(None, 4, 84, 24, 8, 80, 8, None, 1, 8, 24) == -1           # stride < cin
     assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24) == 0
+    assert lib.tpu3_linear_wgrad_f32(None, 100, 80, 12, 8, 80, 8, 12, 8, 8, 1 << 20) == -2       # cin > 64
+    assert lib.tpu3_linear_wgrad_f32(None, 100, 48, 12, 8, 48, 8, 12, 8, None, 0) == -1          # no workspace
+    assert lib.tpu3_linear_wgrad_workspace_bytes(319488) == 1024 * 16 * 64 * 4
     assert lib.tpu3_regress_tail_f32(None, 4, 5, *([8] * 10)) == -1                              # r > 4
     assert lib.tpu3_regress_tail_f32(None, 0, 2, *([None] * 10)) == 0
     assert lib.tpu3_interlevel_skip_workspace_bytes(3, 312, 5) == 3 * 312 * 12 * 4

@@ -340,6 +340,35 @@ def test_linear_small_matches_torch(dev, m, cin, cout, relu, off):
     assert ops.BACKEND.linear_small(wide[:, 1:1 + cin], w, b, relu) is None
 
 
+@pytest.mark.parametrize("m,cin,cout", [(319488, 48, 12), (20000, 36, 12), (70001, 64, 16), (100, 5, 3)])
+def test_linear_wgrad_matches_torch(dev, m, cin, cout):
+    """tpu3_linear_wgrad_f32 (dW = dy^T x of a skinny layer over many rows) against fp64, reading
+    strided rows; and the autograd Function built on it against plain F.linear."""
+    ops, layers = pkg("network.operations"), pkg("network.layers")
+    g = torch.Generator(device="cpu").manual_seed(m)
+    x = torch.randn(m, cin + 4, generator=g).to(dev)[:, :cin]
+    dy = torch.randn(m, cout, generator=g).to(dev)
+    dw = ops.BACKEND.linear_wgrad(x, dy)
+    ref = dy.double().t() @ x.double()
+    assert dw.shape == (cout, cin)
+    assert ((dw.double() - ref).abs() / (ref.abs() + m ** 0.5)).max() < 1e-5
+    assert torch.equal(dw, ops.BACKEND.linear_wgrad(x, dy))                 # deterministic
+    if m >= 16384:
+        conv = torch.nn.Conv2d(cin, cout, 1).to(dev)
+        xc = x.contiguous().requires_grad_(True)
+        y = layers.linear_1x1(conv, xc)
+        (y * dy).sum().backward()
+        gw, gb, gx = conv.weight.grad.clone(), conv.bias.grad.clone(), xc.grad.clone()
+        conv.zero_grad()
+        xr = x.contiguous().requires_grad_(True)
+        yr = torch.nn.functional.linear(xr, conv.weight.view(cout, cin), conv.bias)
+        (yr * dy).sum().backward()
+        assert torch.allclose(y, yr) and torch.allclose(gx, xr.grad)
+        assert ((gw.view(cout, cin) - conv.weight.grad.view(cout, cin)).abs().max()
+                <= 1e-5 * (1 + conv.weight.grad.abs().max()))
+        assert torch.allclose(gb, conv.bias.grad, rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("m,r", [(312, 2), (1000, 2), (17, 4), (4096 * 3 + 5, 1)])
 def test_regress_tail_matches_torch(dev, m, r):
     """tpu3_regress_tail_f32 against the unfused torch formulation (fp64 reference)."""

@@ -1,2 +1,3 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_hip_network.py -m gpu -x -q -k "wgrad or train" 2>&1 | tail -2
+timeout 600 python tools/train_probe.py 2>&1 | tail -5
