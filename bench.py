@@ -239,6 +239,10 @@ def main():
                 tr = json.load(f)
             if tr.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
                 roof["traffic"] = tr["traffic_bytes_per_launch"]
+                for e in extra:                              # per-step PMC traffic of the other two kernels
+                    for key, val in tr.get("others_per_step", {}).items():
+                        if e["kernel"].startswith(key) or key in e["kernel"]:
+                            e["traffic"] = val["traffic_bytes_per_step"]
         except (OSError, ValueError):
             pass
         line = {
