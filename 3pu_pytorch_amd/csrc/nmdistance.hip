@@ -8,6 +8,8 @@
 // kernel is compute-bound: B is staged through LDS in float4 (x,y,z,pad) tiles that every
 // lane reads as wave-uniform ds_read_b128 broadcasts, and each lane carries NQ query points in
 // registers so one LDS read feeds NQ distance evaluations.
+// When the queries alone give too few workgroups (one big cloud against another) the candidates
+// are split across workgroups as well and combined by a 64-bit atomic min (see below).
 // Backward: two scatter passes with hardware fp32 atomics (:154-173).
 #include "tpu3_dev.h"
 
@@ -81,6 +83,84 @@ __global__ __launch_bounds__(NM_THREADS) void nmdist_fwd_kernel(int n, int m,
     }
 }
 
+// Few query blocks (one large cloud against another: the evaluation metric at n = m = 80 000 gives 79
+// workgroups for 256 CUs): the CANDIDATE range is split across blockIdx.y as well, every workgroup
+// scans its chunk exactly as above and the chunks are combined by an atomic min on
+// (distance bits << 32 | index) -- distances are >= 0, so their bit patterns order like the values,
+// and the low word makes the lowest index win exact ties, as in the single-pass scan.
+template <int NQ>
+__global__ __launch_bounds__(NM_THREADS) void nmdist_fwd_split_kernel(int n, int m, int chunk,
+                                                                     const float *__restrict__ xyz1,
+                                                                     const float *__restrict__ xyz2,
+                                                                     unsigned long long *__restrict__ packed)
+{
+    __shared__ float4 tile[NM_TILE];
+    const int b = blockIdx.z;
+    const float *A = xyz1 + (size_t)b * n * 3;
+    const float *B = xyz2 + (size_t)b * m * 3;
+    const int c0 = blockIdx.y * chunk, c1 = min(m, c0 + chunk);
+    const int j0 = blockIdx.x * (NM_THREADS * NQ) + threadIdx.x;
+    float ax[NQ], ay[NQ], az[NQ], best[NQ];
+    int besti[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = j0 + q * NM_THREADS;
+        const bool live = j < n;
+        ax[q] = live ? A[j * 3 + 0] : 0.f;
+        ay[q] = live ? A[j * 3 + 1] : 0.f;
+        az[q] = live ? A[j * 3 + 2] : 0.f;
+        best[q] = 0.f;
+        besti[q] = c0;
+    }
+    for (int k0 = c0; k0 < c1; k0 += NM_TILE) {
+        const int len = min(NM_TILE, c1 - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += NM_THREADS) {
+            const float *p = B + (size_t)(k0 + i) * 3;
+            tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        int k = 0;
+        if (k0 == c0) {
+            const float4 p = tile[0];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                best[q] = tpu3_sqdist3(p.x - ax[q], p.y - ay[q], p.z - az[q]);
+            k = 1;
+        }
+#pragma unroll 4
+        for (; k < len; ++k) {
+            const float4 p = tile[k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float d = tpu3_sqdist3(p.x - ax[q], p.y - ay[q], p.z - az[q]);
+                if (d < best[q]) {
+                    best[q] = d;
+                    besti[q] = k0 + k;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int j = j0 + q * NM_THREADS;
+        if (j < n && c0 < c1)
+            atomicMin(packed + (size_t)b * n + j,
+                      ((unsigned long long)__float_as_uint(best[q] + 0.0f) << 32) | (unsigned int)besti[q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nmdist_unpack_kernel(long total, const unsigned long long *__restrict__ packed,
+                                                            float *__restrict__ dist, int32_t *__restrict__ idx)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const unsigned long long v = packed[i];
+        dist[i] = __uint_as_float((unsigned int)(v >> 32));
+        idx[i] = (int32_t)(unsigned int)v;
+    }
+}
+
 __global__ __launch_bounds__(256) void nmdist_bwd_kernel(int n, int m,
                                                          const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2,
@@ -110,8 +190,31 @@ __global__ __launch_bounds__(256) void nmdist_bwd_kernel(int n, int m,
 int nm_dir(hipStream_t s, int b, int n, int m, const float *a, const float *bb, float *dist, int32_t *idx)
 {
     if (n == 0) return TPU3_OK;
-    // enough workgroups to cover 256 CUs: fewer queries per lane for small problems
     const long total = (long)b * n;
+    const long qblocks = (long)b * ((n + NM_THREADS * 4 - 1) / (NM_THREADS * 4));
+    if (qblocks < 512 && m >= 2 * NM_TILE && total >= 4096) {
+        // too few query blocks for the chip: split the candidates as well
+        long splits = (1024 + qblocks - 1) / qblocks;
+        const long maxs = (m + NM_TILE - 1) / NM_TILE;
+        if (splits > maxs) splits = maxs;
+        if (splits > 65535) splits = 65535;
+        int chunk = (int)((m + splits - 1) / splits);
+        chunk = (chunk + NM_TILE - 1) / NM_TILE * NM_TILE;
+        splits = (m + chunk - 1) / chunk;
+        unsigned long long *packed = nullptr;
+        hipError_t e = hipMallocAsync((void **)&packed, (size_t)total * 8, s);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(packed, 0xFF, (size_t)total * 8, s);
+        if (e != hipSuccess) return (int)e;
+        const dim3 g((n + NM_THREADS * 4 - 1) / (NM_THREADS * 4), (unsigned)splits, b);
+        hipLaunchKernelGGL(nmdist_fwd_split_kernel<4>, g, dim3(NM_THREADS), 0, s, n, m, chunk, a, bb, packed);
+        hipLaunchKernelGGL(nmdist_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total,
+                           (const unsigned long long *)packed, dist, idx);
+        int r = tpu3_launch_status();
+        e = hipFreeAsync(packed, s);
+        return r ? r : (int)e;
+    }
+    // enough workgroups to cover 256 CUs: fewer queries per lane for small problems
     if (total >= 256L * NM_THREADS * 4 * 2) {
         const dim3 g((n + NM_THREADS * 4 - 1) / (NM_THREADS * 4), b);
         hipLaunchKernelGGL(nmdist_fwd_kernel<4>, g, dim3(NM_THREADS), 0, s, n, m, a, bb, dist, idx);

@@ -259,13 +259,16 @@ def test_nmdistance_forward_bit_exact(orc, dev, b, n, m):
     np.testing.assert_array_equal(d2.cpu().numpy(), rd2)
 
 
-def test_nmdistance_ties_go_to_lowest_index(orc, dev):
+@pytest.mark.parametrize("nt,nq", [(300, 700), (4000, 5000)])
+def test_nmdistance_ties_go_to_lowest_index(orc, dev, nt, nq):
+    """(4000, 5000): 12 000 targets take the candidate-split path (atomic min on distance|index);
+    the copies of a target sit in different chunks and the lowest index must still win."""
     losses = pkg("losses")
-    x2 = np.repeat(sphere(9, 300, 1), 3, axis=1)          # every target three times
-    x1 = sphere(10, 700, 1)
-    outs = [torch.empty((1, 700), device=dev), torch.empty((1, 900), device=dev),
-            torch.empty((1, 700), dtype=torch.int32, device=dev),
-            torch.empty((1, 900), dtype=torch.int32, device=dev)]
+    x2 = np.tile(sphere(9, nt, 1), (1, 3, 1))            # every target three times, nt apart
+    x1 = sphere(10, nq, 1)
+    outs = [torch.empty((1, nq), device=dev), torch.empty((1, 3 * nt), device=dev),
+            torch.empty((1, nq), dtype=torch.int32, device=dev),
+            torch.empty((1, 3 * nt), dtype=torch.int32, device=dev)]
     losses.nmdistance_forward(_t(x1, dev), _t(x2, dev), *outs)
     _, ri1, _, ri2 = orc.nmdistance_fwd(x1, x2)
     np.testing.assert_array_equal(outs[2].cpu().numpy(), ri1)
