@@ -321,6 +321,12 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
     const int nbpad = a.nbpad, ng = a.ng, lb = a.lb;
     if (a.n <= 0 || a.m <= 0)
         return;
+    // Bucket i (64 * PPL consecutive Morton points) belongs to wave i % NW; a wave groups ITS buckets
+    // 16 to a group in order.  Spatially adjacent buckets -- the handful a sample touches -- are thus
+    // re-scanned by different waves in parallel (with groups of 16 consecutive buckets one wave did
+    // most of a round's re-scans while the others waited at the barrier).  The LDS bucket table is
+    // stored wave-major (slot = (i % NW) * Q + i / NW), so a group's children are 16 consecutive words.
+    const int Q = nbpad / NW;
     // bucket table, indexed by bucket id (a DPP row reads 16 consecutive children)
     int *t_max = (int *)smem;
     uint32_t *t_key = (uint32_t *)(t_max + nbpad);
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
     // `slot` (per lane; < 0 = row idle).  Row arg-max over the 16 children with the FPS tie rule.
     auto refresh_groups = [&](int slot, bool with_box) {
         const bool valid = slot >= 0 && slot * NW + wave < ng;
-        const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+        const int beta = valid ? wave * Q + slot * FB_GS + col : 0;         // table index (see below)
         const int bits = valid ? t_max[beta] : (int)0x80000000;
         const uint32_t key = valid ? t_key[beta] : 0xFFFFFFFFu;
         const int rmax = tpu3_row_max_i32_fast(bits);
@@ -384,14 +390,15 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
 
     // ---- setup: bucket table from the init kernel's arrays, then every group's entry + AABB --------
     for (int i = tid; i < nbpad; i += W) {
-        t_max[i] = (int)a.ib[0 * nbpad + i];
-        t_key[i] = a.ib[1 * nbpad + i];
-        t_x[i] = __uint_as_float(a.ib[2 * nbpad + i]);
-        t_y[i] = __uint_as_float(a.ib[3 * nbpad + i]);
-        t_z[i] = __uint_as_float(a.ib[4 * nbpad + i]);
-        t_b0[i] = a.ib[5 * nbpad + i];
-        t_b1[i] = a.ib[6 * nbpad + i];
-        t_b2[i] = a.ib[7 * nbpad + i];
+        const int ti = (i % NW) * Q + i / NW;           // bucket i -> table slot
+        t_max[ti] = (int)a.ib[0 * nbpad + i];
+        t_key[ti] = a.ib[1 * nbpad + i];
+        t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
+        t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
+        t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
+        t_b0[ti] = a.ib[5 * nbpad + i];
+        t_b1[ti] = a.ib[6 * nbpad + i];
+        t_b2[ti] = a.ib[7 * nbpad + i];
     }
     for (int i = tid; i < GT; i += W) {
         g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu;
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
                     }
                 // ---- 2. children test ------------------------------------------------------------------
                 const bool valid = slot >= 0;
-                const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+                const int beta = valid ? wave * Q + slot * FB_GS + col : 0;
                 const uint32_t w0 = t_b0[beta], w1 = t_b1[beta], w2 = t_b2[beta];
                 const float db = fb_dbox(qx, qy, qz, fb_half_lo(w0), fb_half_hi(w0), fb_half_lo(w1), fb_half_hi(w1),
                                          fb_half_lo(w2), fb_half_hi(w2));
@@ -461,9 +468,10 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
                         bt &= bt - 1;
                     }
                     const int b0 = __builtin_amdgcn_readlane(beta, p0), b1 = __builtin_amdgcn_readlane(beta, p1);
+                    const int d0 = (b0 - wave * Q) * NW + wave, d1 = (b1 - wave * Q) * NW + wave;    // bucket ids
                     FbBucket<PPL> k0, k1;
-                    fb_load<PPL>(k0, sp, skey, b0, lane);
-                    fb_load<PPL>(k1, sp, skey, b1, lane);
+                    fb_load<PPL>(k0, sp, skey, d0, lane);
+                    fb_load<PPL>(k1, sp, skey, d1, lane);
                     const FbCand c0 = fb_apply<PPL>(k0, qx, qy, qz, true);
                     const FbCand c1 = fb_apply<PPL>(k1, qx, qy, qz, true);
                     int m0 = __float_as_int(c0.t), m1 = __float_as_int(c1.t);
@@ -485,9 +493,9 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
                     if (lane == (int)__builtin_ctzll(t1)) {
                         t_max[b1] = m1; t_key[b1] = c1.key; t_x[b1] = c1.x; t_y[b1] = c1.y; t_z[b1] = c1.z;
                     }
-                    fb_store<PPL>(k0, sp, b0, lane);        // stores last, off the dependent chain
+                    fb_store<PPL>(k0, sp, d0, lane);        // stores last, off the dependent chain
                     if (b1 != b0)
-                        fb_store<PPL>(k1, sp, b1, lane);
+                        fb_store<PPL>(k1, sp, d1, lane);
                     if (PROF) pc[5] += 1 + (b1 != b0);
                     if (PROF) { tb = __builtin_amdgcn_s_memtime(); pc[11] += tb - tc; }
                 }
@@ -778,7 +786,7 @@ bool fb_plan(int b, int n, FbPlan &p)
         return false;
     const int bsz = 64 * p.ppl;
     p.nb = (n + bsz - 1) / bsz;
-    p.nbpad = (p.nb + FB_GS - 1) / FB_GS * FB_GS;
+    p.nbpad = (p.nb + FB_GS * FB_NW - 1) / (FB_GS * FB_NW) * (FB_GS * FB_NW);       // whole groups per wave
     p.ng = p.nbpad / FB_GS;
     p.npad = p.nb * bsz;
     p.nw = FB_NW;
