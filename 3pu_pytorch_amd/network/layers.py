@@ -154,6 +154,56 @@ class DenseEdgeConv(nn.Module):
         return y.transpose(2, 1).contiguous(), idx
 
 
+class SampledDenseEdgeConv(DenseEdgeConv):
+    """Dense edge convolution evaluated at a sampled subset of the points (reference
+    layers.py:67-112; used only by AdaptiveLevel).  The subset is `nsample` furthest-point samples of
+    `xyz`, or -- for nsample == 1 -- the point closest to the centroid; each sampled point's graph is
+    its k nearest rows of the FULL feature set (the nearest of the k+1 dropped, as in the parent).
+
+    Device work goes through the same kernels as the parent (FPS, gather, kNN with unique=True);
+    the dense layers run channel-last on (B, nsample, k, C)."""
+
+    def get_local_graph_cl(self, query, x, k, layout=None):
+        """query (B,S,C), x (B,N,C) -> edge feature (B,S,k,2C) = [q_i, x_j - q_i], idx (B,S,k)."""
+        need_grad = (x.requires_grad or query.requires_grad) and torch.is_grad_enabled()
+        with torch.no_grad():
+            idx, _, knn_point = operations.knn_query(k + 1, query.detach(), x.detach(), unique=True,
+                                                     layout=layout, want_dist=False,
+                                                     want_grouped=not need_grad)
+        idx = idx[:, :, 1:]
+        if need_grad:
+            b = torch.arange(x.size(0), device=x.device).view(-1, 1, 1)
+            knn_point = x[b, idx]
+        else:
+            knn_point = knn_point[:, :, 1:, :]
+        center = query.unsqueeze(2).expand_as(knn_point)
+        return torch.cat([center, knn_point - center], dim=-1), idx
+
+    def sample(self, nsample, xyz):
+        """xyz (B,3,N) -> sampled_xyz (B,3,nsample), sampled_idx (B,nsample)   (reference :92-100)"""
+        if nsample == 1:
+            center = torch.mean(xyz, dim=-1, keepdim=True)
+            sampled_xyz, sampled_idx, _ = operations.group_knn(1, center, xyz, unique=False)
+            return sampled_xyz.squeeze(2), sampled_idx.squeeze(1)
+        sampled_idx, sampled_xyz = operations.furthest_point_sample(xyz, nsample, NCHW=True)
+        return sampled_xyz, sampled_idx
+
+    def forward(self, x, nsample, xyz):
+        """x (B,C,N), xyz (B,3,N) -> y (B,C + n*growth_rate, nsample), sampled_xyz (B,3,nsample),
+        sampled_idx (B,nsample)   (reference :91-112)."""
+        sampled_xyz, sampled_idx = self.sample(nsample, xyz)
+        sampled_x = operations.gather_points(x, sampled_idx)               # (B,C,nsample)
+        q = sampled_x.transpose(2, 1).contiguous()
+        edge, _ = self.get_local_graph_cl(q, x.transpose(2, 1).contiguous(), self.k)
+        k, n = self.k, self.n
+        y = torch.cat([F.relu(linear_1x1(self.mlps[0], edge)), q.unsqueeze(2).expand(-1, -1, k, -1)], dim=-1)
+        for i in range(1, n):
+            h = linear_1x1(self.mlps[i], y)
+            y = torch.cat([h if i == n - 1 else F.relu(h), y], dim=-1)
+        y, _ = torch.max(y, dim=2)
+        return y.transpose(2, 1).contiguous(), sampled_xyz, sampled_idx
+
+
 def _fused_linear(layer, x):
     """Inference shortcut of a pointwise Conv1d / Conv2d with at most 32 outputs (the prep
     convolutions of a Level): linear + bias + ReLU in one MFMA kernel that reads the input rows in
