@@ -290,6 +290,11 @@ class HipBackend(object):
                     "tpu3_regress_tail_f32")
         return out
 
+    def ball_query(self, query, xyz, radius, nsample):
+        """query (B,M,3), xyz (B,N,3) contiguous -> idx int32 (B,M,nsample) through the drop-in
+        `sampling.ball_query` entry point."""
+        return sampling.ball_query(query, xyz, radius, nsample)
+
     def normalize(self, pc, n_arr=None):
         """pc (B,3,N) f32 contiguous -> (out (B,3,N), centroid (B,3,1), radius (B,1,1))."""
         L.require_device(pc, "pc")
@@ -379,6 +384,35 @@ def group_knn(k, query, points, unique=True, NCHW=True):
     if NCHW:
         knn_trans = knn_trans.permute(0, 3, 1, 2)
     return knn_trans, point_indices, distances
+
+
+def group_ball(radius, nsample, query, points, NCHW=True):
+    """Ball-query grouping -- the consumer the reference's `sampling.ball_query` export
+    (sampling.cpp:59-81, sampling_cuda.cu:269-317) never got: for every query point the first
+    `nsample` points within `radius` in index order, the first hit replicated into the unused slots
+    (all zeros = point 0 when the ball is empty, as the kernel leaves them).
+    :param
+        radius, nsample   ball radius and neighbourhood size
+        query   Bx3xM or BxMx3
+        points  Bx3xN or BxNx3
+    :return
+        neighbor_points Bx3xMxnsample (if NCHW) or BxMxnsamplex3 (otherwise)
+        index_batch     BxMxnsample int32
+    The gather is differentiable with respect to `points` (torch.gather); indices carry no gradient."""
+    if NCHW:
+        points_trans = points.transpose(2, 1).contiguous()
+        query_trans = query.transpose(2, 1).contiguous()
+    else:
+        points_trans = points.contiguous()
+        query_trans = query.contiguous()
+    assert(points_trans.size(2) == 3 and query_trans.size(2) == 3), "ball query is implemented for 3D points"
+    with torch.no_grad():
+        idx = BACKEND.ball_query(query_trans.detach(), points_trans.detach(), radius, nsample)
+    grouped = torch.gather(points_trans.unsqueeze(1).expand(-1, query_trans.size(1), -1, -1), 2,
+                           idx.long().unsqueeze(-1).expand(-1, -1, -1, points_trans.size(-1)))
+    if NCHW:
+        grouped = grouped.permute(0, 3, 1, 2)
+    return grouped, idx
 
 
 class GatherFunction(torch.autograd.Function):

@@ -1,6 +1,5 @@
 """Progressive patch upsampler of 3PU for PyTorch-ROCm -- counterpart of the reference's
-network/upsampler.py (Net :9-189, Level :192-374; the never-instantiated AdaptiveLevel is out of
-scope).  Same constructor arguments, module names and parameter shapes (reference checkpoints
+network/upsampler.py (Net :9-189, Level :192-374, and the never-instantiated AdaptiveLevel :377-512).  Same constructor arguments, module names and parameter shapes (reference checkpoints
 load unchanged), same numerical definition of every step; the execution is re-designed:
 
   * `Net.forward` in eval mode accepts ANY batch of input patches (the reference asserts
@@ -428,3 +427,87 @@ class Level(torch.nn.Module):
         x, feat = self.forward_cl(xyz.transpose(2, 1).contiguous(),
                                   xyz_normalized.transpose(2, 1).contiguous(), previous)
         return x.transpose(2, 1).contiguous(), feat.transpose(2, 1).contiguous()
+
+
+class AdaptiveLevel(Level):
+    """Upsampling unit with a free target point number (reference :377-512).  Nothing in the reference
+    instantiates it; it is mirrored for completeness of the module API: layer1 is a DenseEdgeConv on
+    all points, layers 2-4 are SampledDenseEdgeConvs on 48 / 16 / 1 sampled points, each followed by
+    an interpolation of the previous features onto the sampled points; the single global feature is
+    expanded over a round(sqrt(target))^2 grid code and regressed to coordinates.
+
+    As in the reference, layer4 asks for knn + 1 neighbours among the 16 points layer3 kept, so the
+    module only runs for knn <= 15 (the reference's torch.topk raises for more; so does the kNN here).
+    FPS, gathers and every kNN run on the HIP kernels through `operations`; the small dense layers
+    are ordinary convolutions."""
+
+    def __init__(self, dense_n=3, growth_rate=12, knn=16, fm_knn=5):
+        super(Level, self).__init__()
+        self.dense_n = dense_n
+        self.fm_knn = fm_knn
+        self.layer0 = layers.Conv2d(3, 24, [1, 1], activation=None)
+        self.layer1 = layers.DenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 84
+        self.layer2_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer2 = layers.SampledDenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 144
+        self.layer3_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer3 = layers.SampledDenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 204
+        self.layer4_prep = layers.Conv1d(in_channels, 24, 1, activation="relu")
+        self.layer4 = layers.SampledDenseEdgeConv(24, growth_rate=growth_rate, n=dense_n, k=knn)
+        in_channels = 264
+        self.up_layer = torch.nn.Sequential(OrderedDict([
+            ("up_layer1", layers.Conv2d(in_channels + 2, 128, 1, activation="relu")),
+            ("up_layer2", layers.Conv2d(128, 128, 1, activation="relu")), ]))
+        self.fc_layer1 = layers.Conv2d(128, 64, 1, activation="relu")
+        self.fc_layer2 = layers.Conv2d(64, 3, 1, activation=None)
+
+    def exponential_distance(self, points, knnIdx_points):
+        """points (B,C,N[,1]), knnIdx_points (B,C,N,K) -> distance, weight (B,1,N,K)   (:409-427;
+        unlike Level's, the bandwidth carries + 1e-5)"""
+        if points.dim() == 3:
+            points = points.unsqueeze(dim=-1)
+        distance = torch.sum((points - knnIdx_points) ** 2, dim=1, keepdim=True).detach()
+        h = torch.mean(torch.min(distance, dim=-1, keepdim=True)[0], dim=-2, keepdim=True) + 1e-5
+        weight = torch.exp(-distance / (h / 2)).detach()
+        return distance, weight
+
+    def gen_grid(self, grid_size):
+        """output [2, grid_size x grid_size] over [-1, 1]^2   (:429-439)"""
+        x = torch.linspace(-1.0, 1.0, grid_size, dtype=torch.float32)
+        x, y = torch.meshgrid(x, x, indexing="ij")
+        return torch.stack([x, y], dim=0).view([2, grid_size * grid_size])
+
+    def interpolate(self, previous_xyz, xyz, previous_feat):
+        """previous_feat (B,C,M) at previous_xyz (B,3,M) -> (B,C,N') at xyz (B,3,N'): weighted mean over
+        the fm_knn nearest previous points (:441-465).  The reference repeats previous_feat N' times
+        before its gather; here the neighbours' rows are gathered directly."""
+        knn_points, knn_idx, _ = operations.group_knn(self.fm_knn, xyz, previous_xyz, unique=True, NCHW=True)
+        B, C, _ = previous_feat.shape
+        Np, K = knn_idx.size(1), knn_idx.size(2)
+        feats = torch.gather(previous_feat, 2, knn_idx.reshape(B, 1, Np * K).expand(-1, C, -1)).view(B, C, Np, K)
+        _, weight = self.exponential_distance(xyz, knn_points)
+        weight = weight / torch.sum(weight + 1e-5, dim=-1, keepdim=True)
+        return torch.sum(weight * feats, dim=-1)
+
+    def forward(self, xyz, target_n_point):
+        """xyz (B,3,N) -> xyz (B,3,round(sqrt(target_n_point))^2), global feature (B,264,1)   (:467-512)"""
+        code = self.gen_grid(round(sqrt(target_n_point))).to(device=xyz.device)
+        code = code.expand(xyz.size(0), -1, -1)
+        xyz_normalized, centroid, radius = operations.normalize_point_batch(xyz, NCHW=True)
+        x = self.layer0(xyz_normalized.unsqueeze(dim=-1)).squeeze(dim=-1)
+        y, _ = self.layer1(x)
+        x = torch.cat([y, x], dim=1)
+        sampled_xyz = xyz_normalized
+        for prep, layer, nsample in ((self.layer2_prep, self.layer2, 48), (self.layer3_prep, self.layer3, 16),
+                                     (self.layer4_prep, self.layer4, 1)):
+            y, new_xyz, _ = layer(prep(x), nsample, sampled_xyz)
+            x = torch.cat([y, self.interpolate(sampled_xyz, new_xyz, x)], dim=1)
+            sampled_xyz = new_xyz
+        global_features = x
+        x = x.expand(-1, -1, code.size(-1))
+        x = torch.cat([x, code], dim=1).unsqueeze(-1)
+        x = self.fc_layer2(self.fc_layer1(self.up_layer(x))).squeeze(-1)
+        x = (x * radius.detach()) + centroid.detach()
+        return x, global_features

@@ -102,6 +102,9 @@ class OracleBackend(object):
     def gather_backward(self, grad_out, idx, c, n):
         return torch.from_numpy(orc.gather_bwd(_np(grad_out), _np(idx), n)).to(grad_out.device)
 
+    def ball_query(self, query, xyz, radius, nsample):
+        return torch.from_numpy(orc.ball_query(_np(query), _np(xyz), radius, nsample)).to(query.device)
+
     def normalize(self, pc, n_arr=None):
         assert n_arr is None
         o, c, r = orc.normalize_point_batch(_np(pc), NCHW=True)

@@ -437,3 +437,52 @@ def test_data_path_on_device_matches_reference_items(dev):
         assert a.is_cuda and r == int(g["item%d_ratio" % i])
         np.testing.assert_allclose(a.cpu().numpy(), g["item%d_input" % i], atol=1e-6, rtol=0)
         np.testing.assert_allclose(b.cpu().numpy(), g["item%d_label" % i], atol=1e-6, rtol=0)
+
+
+# ---- the unused variants of the reference on the device -------------------------
+def _load_prefixed(module, g, prefix, dev):
+    module.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)},
+                           strict=True)
+    return module.to(dev).eval()
+
+
+@pytest.mark.parametrize("nsample", [48, 1])
+def test_sampled_dense_edge_conv_on_device(dev, nsample):
+    layers = pkg("network.layers")
+    g = golden("adaptive_level.npz")
+    conv = _load_prefixed(layers.SampledDenseEdgeConv(24, growth_rate=12, n=3, k=8), g, "sdec_state_", dev)
+    with torch.no_grad():
+        y, sxyz, sidx = conv(torch.from_numpy(g["sdec_x"]).to(dev), nsample, torch.from_numpy(g["sdec_xyz"]).to(dev))
+    np.testing.assert_array_equal(sidx.cpu().numpy().astype(np.int32), g["sdec_sidx_%d" % nsample])
+    np.testing.assert_array_equal(sxyz.cpu().numpy(), g["sdec_sxyz_%d" % nsample])
+    np.testing.assert_allclose(y.cpu().numpy(), g["sdec_y_%d" % nsample], rtol=0, atol=1e-5)
+
+
+def test_adaptive_level_on_device(dev):
+    ups = pkg("network.upsampler")
+    g = golden("adaptive_level.npz")
+    lvl = _load_prefixed(ups.AdaptiveLevel(dense_n=3, growth_rate=12, knn=8, fm_knn=5), g, "alevel_state_", dev)
+    with torch.no_grad():
+        x, glob = lvl(torch.from_numpy(g["alevel_in"]).to(dev), int(g["alevel_target"]))
+    np.testing.assert_allclose(glob.cpu().numpy(), g["alevel_global"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.cpu().numpy(), g["alevel_xyz"], rtol=0, atol=1e-5)
+    with torch.no_grad(), pytest.raises((AssertionError, RuntimeError)):
+        ups.AdaptiveLevel(knn=16).to(dev).eval()(torch.from_numpy(g["alevel_in"]).to(dev), 100)
+
+
+def test_group_ball_on_device(orc, dev):
+    ops = pkg("network.operations")
+    pts = sphere(31, 5000, 4)
+    q = np.ascontiguousarray(pts[:, ::16][:, :312])
+    grouped, idx = ops.group_ball(0.1, 32, torch.from_numpy(q).to(dev), torch.from_numpy(pts).to(dev), NCHW=False)
+    ref = orc.ball_query(q, pts, 0.1, 32)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(grouped.cpu().numpy(), np.stack([pts[b][ref[b]] for b in range(4)]))
+    # differentiable with respect to the points: every slot passes its gradient to the point it holds
+    p = torch.from_numpy(pts).to(dev).requires_grad_(True)
+    gr, ix = ops.group_ball(0.1, 32, torch.from_numpy(q).to(dev), p, NCHW=False)
+    gr.sum().backward()
+    counts = np.zeros((4, 5000), np.float32)
+    for b in range(4):
+        np.add.at(counts[b], ref[b].reshape(-1), 1.0)
+    np.testing.assert_array_equal(p.grad.cpu().numpy(), np.repeat(counts[:, :, None], 3, axis=2))

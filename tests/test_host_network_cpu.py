@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, pkg
+from conftest import golden, pkg, sphere
 from oracle.backend import OracleBackend
 
 
@@ -183,3 +183,62 @@ def test_net_train_backward_reaches_every_level(net_modules):
             assert p.grad.abs().sum() > 0 or name.endswith("bias"), name
         else:
             assert p.grad is None
+
+
+# ---- the unused variants of the reference ---------------------------------------
+def _load_prefixed(module, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    res = module.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return module.eval()
+
+
+@pytest.mark.parametrize("nsample", [48, 1])
+def test_sampled_dense_edge_conv_matches_reference(net_modules, nsample):
+    """layers.py:67-112: FPS (or closest-to-centroid) subset, kNN of the subset in the full feature
+    set, dense layers, max over k."""
+    layers = pkg("network.layers")
+    g = golden("adaptive_level.npz")
+    conv = _load_prefixed(layers.SampledDenseEdgeConv(24, growth_rate=12, n=3, k=8), g, "sdec_state_")
+    with torch.no_grad():
+        y, sxyz, sidx = conv(torch.from_numpy(g["sdec_x"]), nsample, torch.from_numpy(g["sdec_xyz"]))
+    np.testing.assert_array_equal(sidx.numpy().astype(np.int32), g["sdec_sidx_%d" % nsample])
+    np.testing.assert_array_equal(sxyz.numpy(), g["sdec_sxyz_%d" % nsample])
+    np.testing.assert_allclose(y.numpy(), g["sdec_y_%d" % nsample], rtol=0, atol=1e-5)
+
+
+def test_adaptive_level_matches_reference(net_modules):
+    """upsampler.py:377-512 with knn=8: same parameter names / shapes, same output."""
+    _, ups = net_modules
+    g = golden("adaptive_level.npz")
+    lvl = ups.AdaptiveLevel(dense_n=3, growth_rate=12, knn=8, fm_knn=5)
+    ref_keys = sorted(k[len("alevel_state_"):] for k in g.files if k.startswith("alevel_state_"))
+    assert sorted(lvl.state_dict().keys()) == ref_keys
+    _load_prefixed(lvl, g, "alevel_state_")
+    with torch.no_grad():
+        x, glob = lvl(torch.from_numpy(g["alevel_in"]), int(g["alevel_target"]))
+    assert x.shape == g["alevel_xyz"].shape and glob.shape == g["alevel_global"].shape
+    np.testing.assert_allclose(glob.numpy(), g["alevel_global"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.numpy(), g["alevel_xyz"], rtol=0, atol=1e-5)
+
+
+def test_adaptive_level_refuses_knn_above_15(net_modules):
+    """its last sampled layer asks for knn+1 of 16 points: the reference's topk raises, so does this"""
+    _, ups = net_modules
+    lvl = ups.AdaptiveLevel(knn=16).eval()
+    with torch.no_grad(), pytest.raises((AssertionError, RuntimeError)):
+        lvl(torch.from_numpy(np.ascontiguousarray(sphere(3, 312).transpose(0, 2, 1))), 100)
+
+
+def test_group_ball_against_oracle(net_modules, orc):
+    """operations.group_ball: consumer of the ball_query export (sampling_cuda.cu:269-317)."""
+    ops, _ = net_modules
+    pts = sphere(31, 700, 2)
+    q = np.ascontiguousarray(pts[:, ::7][:, :60])
+    grouped, idx = ops.group_ball(0.25, 16, torch.from_numpy(q), torch.from_numpy(pts), NCHW=False)
+    ref = orc.ball_query(q, pts, 0.25, 16)
+    np.testing.assert_array_equal(idx.numpy(), ref)
+    np.testing.assert_array_equal(grouped.numpy(), np.stack([pts[b][ref[b]] for b in range(2)]))
+    g2, idx2 = ops.group_ball(0.25, 16, torch.from_numpy(q).transpose(2, 1), torch.from_numpy(pts).transpose(2, 1))
+    assert tuple(g2.shape) == (2, 3, 60, 16)
+    np.testing.assert_array_equal(g2.permute(0, 2, 3, 1).numpy(), grouped.numpy())
