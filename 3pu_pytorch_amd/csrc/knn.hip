@@ -60,9 +60,18 @@ template <int C>
 __device__ __forceinline__ void stage_row(float4 *row, const float *__restrict__ src, int c, float add)
 {
     float v[C];
+    if (C % 4 == 0 && c == C && ((uintptr_t)src & 15) == 0) {
+        // full rows, 16-byte aligned: C/4 vector loads instead of C guarded scalar ones
 #pragma unroll
-    for (int i = 0; i < C; ++i)
-        v[i] = i < c ? src[i] : 0.f;
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 t = ((const float4 *)src)[i];
+            v[4 * i] = t.x, v[4 * i + 1] = t.y, v[4 * i + 2] = t.z, v[4 * i + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            v[i] = i < c ? src[i] : 0.f;
+    }
     float r = 0.f;
 #pragma unroll
     for (int i = 0; i < C; ++i)
@@ -105,9 +114,18 @@ __device__ __forceinline__ float row_dist(const float4 *row, const float (&q)[C]
 template <int C>
 __device__ __forceinline__ void load_query(float (&q)[C], float &rq, const float *__restrict__ src, int c, bool live)
 {
+    if (C % 4 == 0 && c == C && ((uintptr_t)src & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < C; ++i)
-        q[i] = (live && i < c) ? src[i] : 0.f;
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 t = ((const float4 *)src)[i];      // src is a valid row also when !live
+            q[4 * i] = live ? t.x : 0.f, q[4 * i + 1] = live ? t.y : 0.f;
+            q[4 * i + 2] = live ? t.z : 0.f, q[4 * i + 3] = live ? t.w : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            q[i] = (live && i < c) ? src[i] : 0.f;
+    }
     rq = 0.f;
 #pragma unroll
     for (int i = 0; i < C; ++i)
@@ -242,6 +260,24 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     }   // work items
 }
 
+// v = v + (lane's bit of mask);  w = 2 w + (lane's bit of mask): one v_addc_co_u32 each, the lane mask
+// (a v_cmp result) is the carry-in
+__device__ __forceinline__ int kg_add_bit(int v, uint64_t mask)
+{
+    int r;
+    uint64_t co;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=&s"(co) : "v"(v), "s"(mask));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t kg_push_bit(uint32_t w, uint64_t mask)
+{
+    uint32_t r;
+    uint64_t co;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(co) : "v"(w), "s"(mask));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kNN *graph* for the fused DenseEdgeConv: the k nearest as a SET, nearest first
 // ---------------------------------------------------------------------------------------------
@@ -284,21 +320,22 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
 #pragma unroll
     for (int i = 0; i < K; ++i)
         ds[i] = __builtin_inff();
+    // Both passes run on every lane of the block (lanes beyond m carry a zero query), so the loops
+    // are wave-uniform: scalar trip counts, no exec juggling; only the stores are guarded.
     // ---- pass 1: the k smallest distances ---------------------------------------------------------
     for (int j0 = 0; j0 < n; j0 += TILE) {
-        const int len = min(TILE, n - j0);
+        const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
         __syncthreads();
         for (int i = threadIdx.x; i < len; i += blockDim.x)
             stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
         __syncthreads();
-        if (live)
-            for (int j = 0; j < len; ++j) {
-                const float d = row_dist<C>(tile + j * F4, q, rq);
+        for (int j = 0; j < len; ++j) {
+            const float d = row_dist<C>(tile + j * F4, q, rq);
 #pragma unroll
-                for (int i = K - 1; i > 0; --i)
-                    ds[i] = __builtin_amdgcn_fmed3f(ds[i - 1], d, ds[i]);
-                ds[0] = fminf(ds[0], d);
-            }
+            for (int i = K - 1; i > 0; --i)
+                ds[i] = __builtin_amdgcn_fmed3f(ds[i - 1], d, ds[i]);
+            ds[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), d, ds[0]);
+        }
     }
     const float t1 = ds[0], tk = ds[K - 1];
     if (self_check && live) {
@@ -317,32 +354,48 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
     for (int i = 0; i < K; ++i)
         quota += ds[i] == tk ? 1 : 0;
     // ---- pass 2: the indices ---------------------------------------------------------------------------
+    // Branch-free per candidate: the three comparisons land in lane masks (SGPR pairs), the mask logic
+    // is scalar, and one v_addc per mask shifts the lane's bit into a 32-candidate word (w = 2w + bit).
+    // After every 32 candidates the words are expanded into indices (about 3.4 bits per lane and word).
     int32_t *out = (int32_t *)a.idx + ((size_t)b * a.m + (live ? qi : 0)) * K;
     int cnt = 1, used = 0;
     bool found = false;
     for (int j0 = 0; j0 < n; j0 += TILE) {
-        const int len = min(TILE, n - j0);
+        const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
         if (n > TILE) {         // the tile still holds the whole set when it fits (the 312-point case)
             __syncthreads();
             for (int i = threadIdx.x; i < len; i += blockDim.x)
                 stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
             __syncthreads();
         }
-        if (live)
-            for (int j = 0; j < len; ++j) {
-                const float d = row_dist<C>(tile + j * F4, q, rq);
-                const bool at = d == tk;
-                const bool sel = d < tk || (at && used < quota);
-                if (sel) {
-                    used += at ? 1 : 0;
-                    if (!found && d == t1) {
-                        out[0] = j0 + j;
-                        found = true;
-                    } else if (cnt < K) {
-                        out[cnt++] = j0 + j;
-                    }
-                }
+        for (int g0 = 0; g0 < len; g0 += 32) {
+            const int gl = __builtin_amdgcn_readfirstlane(min(32, len - g0));
+            uint32_t w = 0, mw = 0;
+            for (int t = 0; t < gl; ++t) {
+                const float d = row_dist<C>(tile + (g0 + t) * F4, q, rq);
+                const uint64_t lt = __builtin_amdgcn_ballot_w64(d < tk);
+                const uint64_t eq = __builtin_amdgcn_ballot_w64(d == tk);
+                const uint64_t room = __builtin_amdgcn_ballot_w64(used < quota);
+                const uint64_t tie = eq & room;
+                used = kg_add_bit(used, tie);
+                w = kg_push_bit(w, lt | tie);
+                mw = kg_push_bit(mw, __builtin_amdgcn_ballot_w64(d == t1));
             }
+            if (!live)
+                w = 0;
+            const int last = j0 + g0 + gl - 1;      // candidate of bit 0
+            while (w) {
+                const int hb = 31 - __clz(w);
+                const uint32_t bit = 1u << hb;
+                if (!found && (mw & bit)) {
+                    out[0] = last - hb;
+                    found = true;
+                } else if (cnt < K) {
+                    out[cnt++] = last - hb;
+                }
+                w &= ~bit;
+            }
+        }
     }
 }
 
