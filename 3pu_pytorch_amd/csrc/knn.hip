@@ -18,6 +18,7 @@
 //                      (order-preserving distance bits << 32 | index) are bitonic-sorted in
 //                      LDS, in chunks when n exceeds the LDS tile (the best k ride along).
 #include "tpu3_dev.h"
+#include "knn_sortnet.h"
 
 namespace {
 
@@ -260,6 +261,138 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     }   // work items
 }
 
+typedef float kg_v4f __attribute__((ext_vector_type(4)));
+#ifndef KG_USE_MFMA
+#define KG_USE_MFMA 1
+#endif
+
+// Distances of this lane's query to the candidates j .. j+3 of the staged tile.
+// C % 4 == 0: the dot products run on v_mfma_f32_4x4x1_16b_f32 -- 16 blocks of (4 candidates x 1
+// channel) x (1 channel x 4 queries): operand A of lane l is a channel of candidate j + l%4 (its
+// 16-byte row reads are shared by the lanes of equal l%4), operand B is the lane's own query channel,
+// and the four results of lane l are <q_l, p_j..j+3>.  One instruction is a single fused multiply-add
+// per output, so 24 of them in ascending channel order are the oracle's fmaf chain bit for bit, at
+// twice the rate of v_fma_f32 (an fp32 MFMA retires 256 FMAs per 8 cycles).
+template <int C, int G>
+__device__ __forceinline__ void kg_dist(const float4 *tile, const float *rps, int j, const float (&q)[C], float rq,
+                                        float *d)
+{
+    // distances to the candidates j .. j+4G-1: G accumulators (4 candidates each) advance together, so
+    // consecutive MFMAs never wait for each other's result
+    constexpr int F4 = Row<C>::F4;
+    if constexpr (C % 4 == 0 && KG_USE_MFMA) {
+        const float4 *row = tile + (j + (int)(threadIdx.x & 3)) * F4;
+        kg_v4f acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            acc[g] = kg_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            float4 p[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                p[g] = row[g * 4 * F4 + i];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].x, q[4 * i + 0], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].y, q[4 * i + 1], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].z, q[4 * i + 2], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].w, q[4 * i + 3], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 rp = *(const float4 *)(rps + j + 4 * g);
+            d[4 * g + 0] = __builtin_fmaf(-2.f, acc[g][0], rq) + rp.x;
+            d[4 * g + 1] = __builtin_fmaf(-2.f, acc[g][1], rq) + rp.y;
+            d[4 * g + 2] = __builtin_fmaf(-2.f, acc[g][2], rq) + rp.z;
+            d[4 * g + 3] = __builtin_fmaf(-2.f, acc[g][3], rq) + rp.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4 * G; ++t)
+            d[t] = row_dist<C>(tile + (j + t) * F4, q, rq);
+    }
+}
+
+// stage candidates [j0, j0+len) of P into the tile, padded to a multiple of 32 rows with |p|^2 = +inf
+// (distance +inf: never among the k smallest, never selected)
+template <int C>
+__device__ __forceinline__ void kg_stage(float4 *tile, float *rps, const float *__restrict__ P, int j0, int len, int c)
+{
+    constexpr int F4 = Row<C>::F4;
+    const int len32 = (len + 31) & ~31;
+    for (int i = threadIdx.x; i < len32; i += blockDim.x) {
+        if (i < len) {
+            stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * c, c, 0.f);
+            rps[i] = C == 3 ? tile[i * F4].w : tile[i * F4 + C / 4].x;
+        } else {
+#pragma unroll
+            for (int t = 0; t < F4; ++t)
+                tile[i * F4 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (C == 3)
+                tile[i * F4].w = __builtin_inff();
+            else
+                tile[i * F4 + C / 4].x = __builtin_inff();
+            rps[i] = __builtin_inff();
+        }
+    }
+}
+
+// compare-exchange on two registers: plain v_min_f32 / v_max_f32 (2-source VALU, full rate).  The
+// insertion chain this replaces spent one v_med3_f32 per list slot and candidate, and a 3-source
+// VALU instruction issues at half the rate of a 2-source one on gfx950 (tools/valu_probe.hip:
+// 4.5 vs 2.3 cycles per wave-instruction).
+__device__ __forceinline__ void kg_cx(float &a, float &b)
+{
+    float lo, hi;
+    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo;
+    b = hi;
+}
+
+__device__ __forceinline__ float kg_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Fold L new distances into the running selection: `lst` = the L smallest so far (ascending), `e` = the
+// next one (the (L+1)-th smallest).  The new values are sorted by a Batcher network, the L smallest of
+// the 2L come out of one min(lst[i], nw[L-1-i]) layer as a bitonic sequence (log2 L clean-up layers sort
+// it), and the smallest value that layer discards is the new candidate for `e`.
+// About 20 2-source operations per candidate against 33 half-rate ones for the insertion chain.
+template <int L>
+__device__ __forceinline__ void kg_fold(float (&lst)[L], float &e, float (&nw)[L])
+{
+    static_assert(L == 16 || L == 32, "list length");
+    if constexpr (L == 32) {
+        KG_SORT32(nw, kg_cx)
+    } else {
+        KG_SORT16(nw, kg_cx)
+    }
+    float dm[4] = {e, __builtin_inff(), __builtin_inff(), __builtin_inff()};
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        kg_cx(lst[i], nw[L - 1 - i]);                   // lst[i] = min, nw[L-1-i] = max (discarded)
+        dm[i & 3] = kg_min(dm[i & 3], nw[L - 1 - i]);
+    }
+    e = kg_min(kg_min(dm[0], dm[1]), kg_min(dm[2], dm[3]));
+#pragma unroll
+    for (int st = L / 2; st >= 1; st >>= 1)
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            if ((i & st) == 0)
+                kg_cx(lst[i], lst[i + st]);
+}
+
 // v = v + (lane's bit of mask);  w = 2 w + (lane's bit of mask): one v_addc_co_u32 each, the lane mask
 // (a v_cmp result) is the carry-in
 __device__ __forceinline__ int kg_add_bit(int v, uint64_t mask)
@@ -293,11 +426,12 @@ __device__ __forceinline__ uint32_t kg_push_bit(uint32_t w, uint64_t mask)
 // order.  Runs only when the point sets hold no duplicated rows (uws[0] == 0); otherwise the exact
 // sorted kernels above run instead (gated the other way).
 template <int C, int K>
-__global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
+__global__ __launch_bounds__(512, 4) void knn_graph_kernel(KnnArgs a)
 {
     constexpr int TILE = tile_rows(C);
     constexpr int F4 = Row<C>::F4;
     __shared__ float4 tile[TILE * F4];
+    __shared__ __attribute__((aligned(16))) float rps[TILE];     // |p|^2 of the tile's rows, contiguous
     if (a.uws && a.uws[0] != 0)
         return;
     // a.mode == 2: self query (query set == point set) without a de-duplication pre-pass.  Identical
@@ -316,43 +450,43 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
     load_query<C>(q, rq, a.query + ((size_t)b * a.m + (live ? qi : 0)) * a.c, a.c, live);
     const float *P = a.points + (size_t)pb * a.n * a.c;
 
-    float ds[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i)
-        ds[i] = __builtin_inff();
     // Both passes run on every lane of the block (lanes beyond m carry a zero query), so the loops
     // are wave-uniform: scalar trip counts, no exec juggling; only the stores are guarded.
     // ---- pass 1: the k smallest distances ---------------------------------------------------------
+    constexpr int L = K - 1;
+    float lst[L], kth = __builtin_inff();
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+        lst[i] = __builtin_inff();
     for (int j0 = 0; j0 < n; j0 += TILE) {
         const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
         __syncthreads();
-        for (int i = threadIdx.x; i < len; i += blockDim.x)
-            stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
+        kg_stage<C>(tile, rps, P, j0, len, a.c);
         __syncthreads();
-        for (int j = 0; j < len; ++j) {
-            const float d = row_dist<C>(tile + j * F4, q, rq);
+        for (int j = 0; j < len; j += L) {
+            float nw[L];
 #pragma unroll
-            for (int i = K - 1; i > 0; --i)
-                ds[i] = __builtin_amdgcn_fmed3f(ds[i - 1], d, ds[i]);
-            ds[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), d, ds[0]);
+            for (int t = 0; t < L; t += 16)
+                kg_dist<C, 4>(tile, rps, j + t, q, rq, nw + t);
+            kg_fold<L>(lst, kth, nw);
         }
     }
-    const float t1 = ds[0], tk = ds[K - 1];
+    const float t1 = lst[0], tk = kth;
+    int quota = 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+        quota += lst[i] == tk ? 1 : 0;
     if (self_check && live) {
         // the query's own row is one zero; a second one (or a list so degenerate that zeros could
         // have been pushed out of it) asks for the exact path
-        int zeros = 0;
+        int zeros = tk == 0.f ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < K; ++i)
-            zeros += ds[i] == 0.f ? 1 : 0;
+        for (int i = 0; i < L; ++i)
+            zeros += lst[i] == 0.f ? 1 : 0;
         saw_zero = zeros >= 2 || !(tk > 0.f);
     }
     if (saw_zero)
         a.uws[2] = 1u;
-    int quota = 0;
-#pragma unroll
-    for (int i = 0; i < K; ++i)
-        quota += ds[i] == tk ? 1 : 0;
     // ---- pass 2: the indices ---------------------------------------------------------------------------
     // Branch-free per candidate: the three comparisons land in lane masks (SGPR pairs), the mask logic
     // is scalar, and one v_addc per mask shifts the lane's bit into a 32-candidate word (w = 2w + bit).
@@ -364,22 +498,25 @@ __global__ __launch_bounds__(512) void knn_graph_kernel(KnnArgs a)
         const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
         if (n > TILE) {         // the tile still holds the whole set when it fits (the 312-point case)
             __syncthreads();
-            for (int i = threadIdx.x; i < len; i += blockDim.x)
-                stage_row<C>(tile + i * F4, P + (size_t)(j0 + i) * a.c, a.c, 0.f);
+            kg_stage<C>(tile, rps, P, j0, len, a.c);
             __syncthreads();
         }
         for (int g0 = 0; g0 < len; g0 += 32) {
-            const int gl = __builtin_amdgcn_readfirstlane(min(32, len - g0));
+            constexpr int gl = 32;      // incl. pad rows (never selected)
             uint32_t w = 0, mw = 0;
-            for (int t = 0; t < gl; ++t) {
-                const float d = row_dist<C>(tile + (g0 + t) * F4, q, rq);
-                const uint64_t lt = __builtin_amdgcn_ballot_w64(d < tk);
-                const uint64_t eq = __builtin_amdgcn_ballot_w64(d == tk);
-                const uint64_t room = __builtin_amdgcn_ballot_w64(used < quota);
-                const uint64_t tie = eq & room;
-                used = kg_add_bit(used, tie);
-                w = kg_push_bit(w, lt | tie);
-                mw = kg_push_bit(mw, __builtin_amdgcn_ballot_w64(d == t1));
+            for (int t0 = 0; t0 < gl; t0 += 16) {
+                float d[16];
+                kg_dist<C, 4>(tile, rps, g0 + t0, q, rq, d);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const uint64_t lt = __builtin_amdgcn_ballot_w64(d[t] < tk);
+                    const uint64_t eq = __builtin_amdgcn_ballot_w64(d[t] == tk);
+                    const uint64_t room = __builtin_amdgcn_ballot_w64(used < quota);
+                    const uint64_t tie = eq & room;
+                    used = kg_add_bit(used, tie);
+                    w = kg_push_bit(w, lt | tie);
+                    mw = kg_push_bit(mw, __builtin_amdgcn_ballot_w64(d[t] == t1));
+                }
             }
             if (!live)
                 w = 0;
