@@ -281,30 +281,49 @@ __device__ __forceinline__ void kg_dist(const float4 *tile, const float *rps, in
     // consecutive MFMAs never wait for each other's result
     constexpr int F4 = Row<C>::F4;
     if constexpr (C % 4 == 0 && KG_USE_MFMA) {
+        // The MFMAs are volatile asm in round-robin order over the G accumulators (the compiler's own
+        // schedule ran each accumulator's chain back to back, with a wait on every LDS read); the
+        // rows of channel quad i+1 are in flight while quad i is consumed.
         const float4 *row = tile + (j + (int)(threadIdx.x & 3)) * F4;
         kg_v4f acc[G];
+        float4 p[G], pn[G];
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            acc[g] = kg_v4f{0.f, 0.f, 0.f, 0.f};
+            p[g] = row[g * 4 * F4];
 #pragma unroll
         for (int i = 0; i < C / 4; ++i) {
-            float4 p[G];
+            if (i + 1 < C / 4) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    pn[g] = row[g * 4 * F4 + i + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (i == 0)
+                    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(p[g].x), "v"(q[0]));
+                else
+                    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(p[g].x), "v"(q[4 * i]));
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                p[g] = row[g * 4 * F4 + i];
+                asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(p[g].y), "v"(q[4 * i + 1]));
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].x, q[4 * i + 0], acc[g], 0, 0, 0);
+                asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(p[g].z), "v"(q[4 * i + 2]));
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].y, q[4 * i + 1], acc[g], 0, 0, 0);
+                asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(p[g].w), "v"(q[4 * i + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < C / 4) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].z, q[4 * i + 2], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[g].w, q[4 * i + 3], acc[g], 0, 0, 0);
+                for (int g = 0; g < G; ++g)
+                    p[g] = pn[g];
+            }
         }
+        // MFMA results are not interlocked against VALU reads: 8 wait states before the epilogue
+        asm volatile("s_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float4 rp = *(const float4 *)(rps + j + 4 * g);
