@@ -15,11 +15,11 @@
 // lives only in MFMA accumulators, and HBM sees x once, the neighbour indices once and y once.
 //
 // MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32 fma chains): rows = output channels (12 of 16),
-// columns = 16 edges of one point, K = input channels 4 at a time.
+// columns = 16 POINTS (one neighbour slot of each at a time), K = input channels 4 at a time.
 //   * A operand = weights: lane (m = l&15, g = l>>4) keeps W[m][chan(step,g)] in VGPRs for the
 //     whole kernel (38 registers);
-//   * B operand = inputs: lane (edge = l&15, g) supplies channel chan(step,g) of its edge;
-//   * D = 4 consecutive channels (4g..4g+3) of the lane's edge -- exactly what the next layer's B
+//   * B operand = inputs: lane (point = l&15, g) supplies channel chan(step,g) of its point's neighbour;
+//   * D = 4 consecutive channels (4g..4g+3) of the lane's edge (point, slot) -- exactly what the next layer's B
 //     operand needs when its step r uses channel 4g+r, so h0/h1 feed the next MFMA straight from
 //     the accumulator registers, no shuffles, no LDS;
 //   * everything that depends on ONE point only is hoisted out of the edge loop:
@@ -28,7 +28,9 @@
 //     accumulators' initial values, and z_j = W0b x_j is a per-POINT table (12 floats per point in
 //     LDS, computed once per patch): the first layer of an edge is a gather of z_j, an add and a
 //     ReLU -- 12 MFMAs per 16-edge tile instead of 33, and 12 instead of 24 gathered floats per edge;
-//   * max over the k edges = elementwise max over the tiles, then one 16-lane DPP row reduction.
+//   * max over the k edges = a running per-lane v_max over the slots (v_max is a half-rate VALU
+//     instruction on gfx950 and fp32 MFMA shares the VALU datapath: with 16 edges of one point along the
+//     columns, the 16-lane DPP row reduction per point cost 18 % of the kernel).
 // Summation order differs from a BLAS GEMM (documented tolerance 1e-5 on the network outputs).
 #include "tpu3_dev.h"
 
@@ -41,7 +43,7 @@ constexpr int DEC_G = 12;        // growth rate
 constexpr int DEC_S = 26;        // LDS row stride of the patch features (floats)
 constexpr int DEC_NW = 8;        // waves per workgroup
 constexpr int DEC_ZS = 12;       // floats per point in the z table
-constexpr int DEC_TS = 52;       // floats per point in the per-wave T buffer (3 x 16 + pad)
+constexpr int DEC_TS = 64;       // words per point-slot row of the per-wave neighbour tile (k <= 64)
 
 struct DecArgs {
     int n;                       // points per patch
@@ -61,47 +63,13 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float row_max_f32(float v)
+// max(v, 0) as ONE v_max_f32: fmaxf() on an MFMA result costs a second (canonicalising) v_max, and
+// v_max is a half-rate instruction on gfx950
+__device__ __forceinline__ float dec_relu(float v)
 {
-    // max over the 16 lanes of a DPP row; every lane of the row gets the result
-    v = fmaxf(v, __int_as_float(tpu3_dpp<0xB1>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(tpu3_dpp<0x4E>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(tpu3_dpp<0x141>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(tpu3_dpp<0x140>(__float_as_int(v))));
-    return v;
-}
-
-// One DPP step of the 16-lane row max for twelve values at once: the modifier is fused into
-// v_max_f32 (hipcc emits v_mov_dpp + v_max + wait states per step and value), and the twelve
-// independent chains fill each other's DPP wait states.
-#define DEC_DPP_MAX12(CTRL)                                                                              \
-    asm volatile("s_nop 1\n\t"                                                                           \
-                 "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %8, %8, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %9, %9, %9 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
-                 "v_max_f32_dpp %10, %10, %10 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
-                 "v_max_f32_dpp %11, %11, %11 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                    \
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8),  \
-                   "+v"(v9), "+v"(v10), "+v"(v11))
-
-__device__ __forceinline__ void row_max12(f32x4 &a, f32x4 &b, f32x4 &c)
-{
-    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
-    float v8 = c[0], v9 = c[1], v10 = c[2], v11 = c[3];
-    DEC_DPP_MAX12("quad_perm:[1,0,3,2]");
-    DEC_DPP_MAX12("quad_perm:[2,3,0,1]");
-    DEC_DPP_MAX12("row_half_mirror");
-    DEC_DPP_MAX12("row_mirror");
-    a = (f32x4){v0, v1, v2, v3};
-    b = (f32x4){v4, v5, v6, v7};
-    c = (f32x4){v8, v9, v10, v11};
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // ZTAB: the per-point table z = W0b x fits LDS next to the features (patches up to ~700 points);
@@ -174,118 +142,112 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
     __syncthreads();
     const int zoff = g < 3 ? 4 * g : 0;     // lanes of the padding channel group read finite values (x 0 weights)
 
-    float *T = tb + wave * 16 * DEC_TS;
+    // ---- 16 points per wave step: columns = POINTS, one neighbour slot at a time ---------------------
+    // Everything a lane holds belongs to its own point pb + e: the centre terms stay in the registers
+    // the MFMA left them in, the max over the k neighbours is a running per-lane v_max (no cross-lane
+    // reduction), and lane (e, g) gathers rows 4g..4g+3 of ITS point's neighbour.
+    constexpr int K = 16 * TILES;
+    constexpr int U = 2;                        // neighbour slots in flight (independent MFMA chains)
+    int *IT = (int *)(tb + wave * 16 * DEC_TS);  // per-wave tile [slot][16 points]: byte offset of the neighbour's row
+    const char *gbase = ZTAB ? (const char *)(zt + zoff) : (const char *)(xs + 6 * g);
     for (int pb = wave * 16; pb < n; pb += DEC_NW * 16) {
-        // ---- centre terms of 16 points (columns = points) -> T[p][0..15 | 16..31 | 32..47] --------
+        // neighbour indices of the 16 points, clamped and scaled once, read coalesced (k contiguous per point)
+        for (int t = lane; t < 16 * K; t += 64) {
+            const int pt = t / K, sl = t - pt * K;
+            const int i = min(pb + pt, n - 1);
+            const size_t io = ((size_t)blockIdx.x * n + i) * a.idx_stride + a.idx_off + sl;
+            int j = a.idx64 ? (int)((const long long *)a.idx)[io] : ((const int *)a.idx)[io];
+            j = min(max(j, 0), n - 1);
+            IT[sl * 16 + pt] = j * (int)((ZTAB ? DEC_ZS : DEC_S) * sizeof(float));
+        }
+        // centre terms of the lane's point (+ bias): the initial values of the three accumulators
+        f32x4 c0 = bias0, c1 = bias1, c2 = bias2;
         {
-            const int p = min(pb + e, n - 1);
-            const float *xp = xs + p * DEC_S + 6 * g;
-            f32x4 t0 = bias0, t1 = bias1, t2 = bias2;
+            const float *xp = xs + min(pb + e, n - 1) * DEC_S + 6 * g;
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const float xv = xp[s];
-                t0 = mfma4(wt0[s], xv, t0);
-                t1 = mfma4(wt1[s], xv, t1);
-                t2 = mfma4(wt2[s], xv, t2);
+                c0 = mfma4(wt0[s], xv, c0);
+                c1 = mfma4(wt1[s], xv, c1);
+                c2 = mfma4(wt2[s], xv, c2);
             }
-            *(f32x4 *)(T + e * DEC_TS + 4 * g) = t0;
-            *(f32x4 *)(T + e * DEC_TS + 16 + 4 * g) = t1;
-            *(f32x4 *)(T + e * DEC_TS + 32 + 4 * g) = t2;
         }
-        const int pend = min(16, n - pb);
-        // neighbour indices of the point about to be processed (one register per tile); the next
-        // point's are requested while the current one computes, so the global-load latency is hidden
-        auto load_idx = [&](int i, int (&j)[TILES]) {
+        __builtin_amdgcn_wave_barrier();
+        const float ninf = -__builtin_inff();
+        f32x4 m0 = {ninf, ninf, ninf, ninf}, m1 = m0, m2 = m0;
+#pragma unroll 1
+        for (int kk = 0; kk < K; kk += U) {
+            f32x4 h0[U], h1[U], h2[U];
+            int off[U];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const size_t io = ((size_t)blockIdx.x * n + i) * a.idx_stride + a.idx_off + 16 * t + e;
-                j[t] = a.idx64 ? (int)((const long long *)a.idx)[io] : ((const int *)a.idx)[io];
-            }
-        };
-        int jn[TILES];
-        load_idx(pb, jn);
-        for (int p = 0; p < pend; ++p) {
-            const int i = pb + p;
-            const float *zj[TILES];
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const int j = min(max(jn[t], 0), n - 1);
-                zj[t] = ZTAB ? zt + j * DEC_ZS + zoff : xs + j * DEC_S + 6 * g;
-            }
-            if (p + 1 < pend)
-                load_idx(i + 1, jn);
-            const f32x4 c0 = *(const f32x4 *)(T + p * DEC_TS + 4 * g);
-            const f32x4 c1 = *(const f32x4 *)(T + p * DEC_TS + 16 + 4 * g);
-            const f32x4 c2 = *(const f32x4 *)(T + p * DEC_TS + 32 + 4 * g);
-            // the TILES edge tiles of the point are independent accumulator chains: issuing their
-            // MFMAs alternately hides the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
-            f32x4 h0[TILES], h1[TILES], h2[TILES];
+            for (int u = 0; u < U; ++u)
+                off[u] = IT[(kk + u) * 16 + e];
             if (ZTAB) {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    const f32x4 z = *(const f32x4 *)zj[t];
+                for (int u = 0; u < U; ++u) {
+                    const f32x4 z = *(const f32x4 *)(gbase + off[u]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h0[t][r] = fmaxf(c0[r] + z[r], 0.f);
+                        h0[u][r] = fmaxf(c0[r] + z[r], 0.f);
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
-                    h0[t] = c0;
+                for (int u = 0; u < U; ++u)
+                    h0[u] = c0;
 #pragma unroll
                 for (int s = 0; s < 6; ++s)
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t)
-                        h0[t] = mfma4(w0b[s], zj[t][s], h0[t]);
+                    for (int u = 0; u < U; ++u)
+                        h0[u] = mfma4(w0b[s], ((const float *)(gbase + off[u]))[s], h0[u]);
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h0[t][r] = fmaxf(h0[t][r], 0.f);
+                        h0[u][r] = dec_relu(h0[u][r]);
             }
+            // the U slots are independent accumulator chains: issuing their MFMAs alternately hides the
+            // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
 #pragma unroll
-            for (int t = 0; t < TILES; ++t)
-                h1[t] = c1;
+            for (int u = 0; u < U; ++u)
+                h1[u] = c1;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
-                    h1[t] = mfma4(w1a[r], h0[t][r], h1[t]);
+                for (int u = 0; u < U; ++u)
+                    h1[u] = mfma4(w1a[r], h0[u][r], h1[u]);
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    h1[t][r] = fmaxf(h1[t][r], 0.f);
-                h2[t] = c2;
+                    h1[u][r] = dec_relu(h1[u][r]);
+                h2[u] = c2;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
-                    h2[t] = mfma4(w2a[r], h1[t][r], h2[t]);
+                for (int u = 0; u < U; ++u)
+                    h2[u] = mfma4(w2a[r], h1[u][r], h2[u]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
-                    h2[t] = mfma4(w2b[r], h0[t][r], h2[t]);
-            f32x4 m0 = h0[0], m1 = h1[0], m2 = h2[0];
+                for (int u = 0; u < U; ++u)
+                    h2[u] = mfma4(w2b[r], h0[u][r], h2[u]);
 #pragma unroll
-            for (int t = 1; t < TILES; ++t)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    m0[r] = fmaxf(m0[r], h0[t][r]);
-                    m1[r] = fmaxf(m1[r], h1[t][r]);
-                    m2[r] = fmaxf(m2[r], h2[t][r]);
+                    m0[r] = fmaxf(m0[r], h0[u][r]);
+                    m1[r] = fmaxf(m1[r], h1[u][r]);
+                    m2[r] = fmaxf(m2[r], h2[u][r]);
                 }
-            // ---- max over the 16 edges of the row; one lane per channel group writes ----------------
-            row_max12(m0, m1, m2);
-            if (e == 0 && g < 3) {
-                float *o = O + (size_t)i * a.out_stride + 4 * g;
-                *(f32x4 *)(o) = m2;                  // [0,12)  max h2
-                *(f32x4 *)(o + DEC_G) = m1;          // [12,24) max h1
-                *(f32x4 *)(o + 2 * DEC_G) = m0;      // [24,36) max h0
-            }
         }
+        if (g < 3 && pb + e < n) {
+            float *o = O + (size_t)(pb + e) * a.out_stride + 4 * g;
+            *(f32x4 *)(o) = m2;                  // [0,12)  max h2
+            *(f32x4 *)(o + DEC_G) = m1;          // [12,24) max h1
+            *(f32x4 *)(o + 2 * DEC_G) = m0;      // [24,36) max h0
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
