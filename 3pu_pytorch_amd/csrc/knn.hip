@@ -136,6 +136,16 @@ __device__ __forceinline__ void load_query(float (&q)[C], float &rq, const float
 // C = 24: 320 rows so that a whole 312-point patch is one tile (36 KiB of LDS)
 constexpr int tile_rows(int C) { return C == 3 ? 1024 : (C <= 8 ? 512 : (C == 24 ? 320 : (C <= 32 ? 256 : 128))); }
 
+typedef float kg_v4f __attribute__((ext_vector_type(4)));
+
+// plain v_min_f32 (fminf() adds a canonicalising v_max; both are half-rate VALU instructions on gfx950)
+__device__ __forceinline__ float kg_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // small k: lane-per-query register insertion
 // ---------------------------------------------------------------------------------------------
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     constexpr int TILE = tile_rows(C);
     constexpr int F4 = Row<C>::F4;
     __shared__ float4 tile[TILE * F4];
-    __shared__ float addend[C == 3 ? TILE : 1];
+    __shared__ __attribute__((aligned(16))) float addend[C == 3 ? TILE : 1];
     if (a.gate && a.uws[a.gate < 0 ? 0 : a.gate] == 0)
         return;
     // work item = (batch element, block of queries); gated launches use a small grid and stride over
@@ -204,14 +214,69 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
                                       : (use_dup ? (optimistic ? (float)DUP[src] : dmax * (float)DUP[src]) : 0.f);
             stage_row<C>(tile + i * F4, P + (size_t)src * a.c, a.c, add);
             if (C == 3)
-                addend[i] = add;
+                addend[i] = compact ? tile[i * F4].w : add;    // compact lists: |p|^2, contiguous (add is 0)
         }
         __syncthreads();
+        int jstart = 0;
+        if constexpr (C == 3) {
+            if (compact) {
+                // first-occurrence lists (the inter-level kNN): four candidates per step.  Lane l reads the
+                // row of candidate j + l%4 (one 16-byte LDS read instead of four broadcasts), the three
+                // products run as v_mfma_f32_4x4x1 (one fused multiply-add per output: the oracle's chain),
+                // and ONE comparison on the minimum of the four decides whether any of them can enter the
+                // list; the running maximum for the verification is two v_max3.  Runs on every lane of the
+                // block (lanes beyond m carry a zero query): the MFMA wants the whole wave.
+                const int len4 = len & ~3;
+                for (int j = 0; j < len4; j += 4) {
+                    const float4 p = tile[j + (int)(threadIdx.x & 3)];
+                    kg_v4f acc;
+                    // one accumulator: a dependent MFMA needs two wait states after its producer, and the
+                    // result is not interlocked against VALU reads -- the compiler does not see inside the asm
+                    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %4, 0\n\ts_nop 1\n\t"
+                                 "v_mfma_f32_4x4x1_16b_f32 %0, %2, %5, %0\n\ts_nop 1\n\t"
+                                 "v_mfma_f32_4x4x1_16b_f32 %0, %3, %6, %0\n\ts_nop 7"
+                                 : "=&v"(acc)
+                                 : "v"(p.x), "v"(p.y), "v"(p.z), "v"(q[0]), "v"(q[1]), "v"(q[2]));
+                    const float4 rp = *(const float4 *)(addend + j);
+                    const float d0 = __builtin_fmaf(-2.f, acc[0], rq) + rp.x;
+                    const float d1 = __builtin_fmaf(-2.f, acc[1], rq) + rp.y;
+                    const float d2 = __builtin_fmaf(-2.f, acc[2], rq) + rp.z;
+                    const float d3 = __builtin_fmaf(-2.f, acc[3], rq) + rp.w;
+                    float lo;
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(dqmax) : "v"(d0), "v"(d1));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(dqmax) : "v"(d2), "v"(d3));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(d0), "v"(d1), "v"(d2));
+                    lo = kg_min(lo, d3);
+                    if (lo < bd[KMAX - 1]) {
+                        const float dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float d = dd[t];
+                            if (d < bd[KMAX - 1]) {
+                                const int id = j0 + j + t;
+#pragma unroll
+                                for (int i = KMAX - 1; i > 0; --i) {
+                                    const bool up = bd[i - 1] > d;
+                                    const bool here = bd[i] > d;
+                                    bi[i] = up ? bi[i - 1] : (here ? id : bi[i]);
+                                    bd[i] = up ? bd[i - 1] : (here ? d : bd[i]);
+                                }
+                                if (bd[0] > d) {
+                                    bd[0] = d;
+                                    bi[0] = id;
+                                }
+                            }
+                        }
+                    }
+                }
+                jstart = len4;
+            }
+        }
         if (live) {
-            for (int j = 0; j < len; ++j) {
+            for (int j = jstart; j < len; ++j) {
                 float d = row_dist<C>(tile + j * F4, q, rq);
                 if (use_dup) {
-                    const float ad = C == 3 ? addend[j] : tile[j * F4 + C / 4].y;
+                    const float ad = compact ? 0.f : (C == 3 ? addend[j] : tile[j * F4 + C / 4].y);
                     if (optimistic) {
                         dqmax = fmaxf(dqmax, d);
                         if (ad != 0.f) {
@@ -261,7 +326,6 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
     }   // work items
 }
 
-typedef float kg_v4f __attribute__((ext_vector_type(4)));
 #ifndef KG_USE_MFMA
 #define KG_USE_MFMA 1
 #endif
@@ -271,8 +335,9 @@ typedef float kg_v4f __attribute__((ext_vector_type(4)));
 // channel) x (1 channel x 4 queries): operand A of lane l is a channel of candidate j + l%4 (its
 // 16-byte row reads are shared by the lanes of equal l%4), operand B is the lane's own query channel,
 // and the four results of lane l are <q_l, p_j..j+3>.  One instruction is a single fused multiply-add
-// per output, so 24 of them in ascending channel order are the oracle's fmaf chain bit for bit, at
-// twice the rate of v_fma_f32 (an fp32 MFMA retires 256 FMAs per 8 cycles).
+// per output, so 24 of them in ascending channel order are the oracle's fmaf chain bit for bit.  An fp32
+// MFMA runs on the VALU datapath at the rate of v_fma_f32 (256 FMAs per 8 cycles, no overlap with other
+// VALU work: tools/mfma_overlap_probe.hip); what it saves is LDS traffic and instruction issue.
 template <int C, int G>
 __device__ __forceinline__ void kg_dist(const float4 *tile, const float *rps, int j, const float (&q)[C], float rq,
                                         float *d)
@@ -374,13 +439,6 @@ __device__ __forceinline__ void kg_cx(float &a, float &b)
     asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     a = lo;
     b = hi;
-}
-
-__device__ __forceinline__ float kg_min(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
 }
 
 // Fold L new distances into the running selection: `lst` = the L smallest so far (ascending), `e` = the
