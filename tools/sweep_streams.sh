@@ -1,7 +1,4 @@
-#!/bin/bash
-# development sweep: final-FPS side streams / hardware queues
-for fs in 1 2 3 4; do
-  python bench.py --steps 8 --warmup 3 --no_cpu_baseline --fps_streams $fs 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams $fs', round(d['value']), round(d['ms_per_step'],1), round(d['roofline']['launch_ms'],1))"
+cd /root/repo
+for cfg in "--net_streams 8 --sub_batch 4" "--net_streams 8 --sub_batch 2" "--net_streams 16 --sub_batch 2" "--net_streams 4 --sub_batch 4" "--clouds 48 --net_streams 12 --sub_batch 4" "--fps_streams 2"; do
+  echo -n "$cfg: "; timeout 120 python bench.py --no_cpu_baseline --steps 10 $cfg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f M  %.1f ms/step  fps launch %.0f ms' % (d['value']/1e6, d['ms_per_step'], d['roofline']['launch_ms']))" || echo failed
 done
-GPU_MAX_HW_QUEUES=8 python bench.py --steps 8 --warmup 3 --no_cpu_baseline --fps_streams 4 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('hwq8 streams 4', round(d['value']), round(d['ms_per_step'],1), round(d['roofline']['launch_ms'],1))"
-python bench.py --steps 8 --warmup 3 --no_cpu_baseline --fps_streams 4 --clouds 16 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('clouds16 streams 4', round(d['value']), round(d['ms_per_step'],1), round(d['roofline']['launch_ms'],1))"
