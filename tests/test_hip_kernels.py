@@ -383,7 +383,12 @@ def test_knn_unique_with_duplicate_rows(orc, dev, k, c, n):
 
 
 @pytest.mark.parametrize("b,n,c,k,dups", [(6, 312, 24, 33, False), (3, 312, 24, 17, False), (2, 700, 3, 33, False),
-                                          (4, 312, 24, 33, True), (2, 40, 24, 33, False)])
+                                          (4, 312, 24, 33, True), (2, 40, 24, 33, False),
+                                          # several LDS tiles per patch; the other channel templates (MFMA
+                                          # distances for c = 8, 16, 32; plain FMAs for c = 3, 5 -> template 8)
+                                          (2, 700, 24, 33, False), (2, 1100, 3, 17, False), (2, 400, 16, 17, False),
+                                          (2, 300, 8, 33, False), (2, 333, 5, 33, False), (2, 520, 32, 33, False),
+                                          (2, 700, 24, 17, True)])
 def test_knn_graph_is_the_exact_topk_set(orc, dev, b, n, c, k, dups):
     """tpu3_knn_graph_f32: slot 0 = the oracle's nearest neighbour, slots 1.. = the oracle's other
     k-1 neighbours as a set (ascending index order).  With duplicated rows the gated exact kernels
@@ -395,8 +400,9 @@ def test_knn_graph_is_the_exact_topk_set(orc, dev, b, n, c, k, dups):
         x[:, n // 2:] = x[:, :n - n // 2]
         x[1] = rng.standard_normal((n, c)).astype(np.float32)
     # exact ties without duplicate rows: points on a lattice line
-    if not dups and c == 3:
-        x[0, :50] = np.stack([np.arange(50), np.zeros(50), np.zeros(50)], 1).astype(np.float32)
+    if not dups:
+        x[0, :min(50, n // 2)] = 0
+        x[0, :min(50, n // 2), 0] = np.arange(min(50, n // 2), dtype=np.float32)
     idx = ops.BACKEND.knn_graph(k, _t(x, dev)).cpu().numpy()
     ri, _ = orc.knn(k, x, x, True)
     np.testing.assert_array_equal(idx[:, :, 0], ri[:, :, 0])

@@ -263,7 +263,7 @@ def test_config_c5_shapes_large_patches(orc, dev):
     assert ((fused - plain.detach()).abs().amax(dim=1) <= 1e-5).float().mean() > 0.99
 
 
-@pytest.mark.parametrize("P,N,k", [(3, 312, 32), (5, 100, 16), (2, 312, 48), (1, 17, 16)])
+@pytest.mark.parametrize("P,N,k", [(3, 312, 32), (5, 100, 16), (2, 312, 48), (1, 17, 16), (2, 1024, 32), (1, 200, 64)])
 def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
     """The MFMA kernel against the plain torch formulation of the same block (fp32 reference of the
     same op, same neighbour indices): 1e-5 absolute on O(1) activations.  Also checks writing into a
