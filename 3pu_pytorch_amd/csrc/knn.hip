@@ -214,13 +214,14 @@ __global__ __launch_bounds__(512, (KMAX <= 33 ? 4 : 2)) void knn_insert_kernel(K
                                       : (use_dup ? (optimistic ? (float)DUP[src] : dmax * (float)DUP[src]) : 0.f);
             stage_row<C>(tile + i * F4, P + (size_t)src * a.c, a.c, add);
             if (C == 3)
-                addend[i] = compact ? tile[i * F4].w : add;    // compact lists: |p|^2, contiguous (add is 0)
+                addend[i] = (compact || !use_dup) ? tile[i * F4].w : add;    // four-at-a-time loop: |p|^2, contiguous
         }
         __syncthreads();
         int jstart = 0;
         if constexpr (C == 3) {
-            if (compact) {
-                // first-occurrence lists (the inter-level kNN): four candidates per step.  Lane l reads the
+            if (compact || !use_dup) {
+                // first-occurrence lists (the inter-level kNN) and plain searches without duplicate handling
+                // (the outlier filter): four candidates per step.  Lane l reads the
                 // row of candidate j + l%4 (one 16-byte LDS read instead of four broadcasts), the three
                 // products run as v_mfma_f32_4x4x1 (one fused multiply-add per output: the oracle's chain),
                 // and ONE comparison on the minimum of the four decides whether any of them can enter the
