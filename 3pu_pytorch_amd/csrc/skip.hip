@@ -247,15 +247,23 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
 #pragma unroll
         for (int kk = 0; kk < K; ++kk)
             nbr[kk] = min(max(nbr[kk], 0), a.m - 1);
-        // weights (reference :340-342): w = ws*wf;  w /= sum_k (w + 1e-5)
+        // weights (reference :340-342): w = ws*wf;  w /= sum_k (w + 1e-5).  Lane kk evaluates neighbour kk
+        // (two divisions, two exponentials, then one more division) and the results are broadcast -- the
+        // same operations on the same values as evaluating all K in every lane, a fifth of the VALU work
+        // (IEEE divisions and expf are ~10 instructions each and this loop is not memory-bound).
+        {
+            const int lk = min(lane, K - 1);
+            const float mine = expf(-DS[(size_t)i * 2 * K + lk] / hs2) * expf(-DS[(size_t)i * 2 * K + K + lk] / hf2);
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-            w[kk] = expf(-DS[(size_t)i * 2 * K + kk] / hs2) * expf(-DS[(size_t)i * 2 * K + K + kk] / hf2);
-            tot += w[kk] + 1e-5f;
+            for (int kk = 0; kk < K; ++kk) {
+                w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), kk));
+                tot += w[kk] + 1e-5f;
+            }
+            const float mine_w = mine / tot;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk)
+                w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_w), kk));
         }
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk)
-            w[kk] = w[kk] / tot;
         if (VEC) {
             sk_f4 *X4 = (sk_f4 *)(F + (size_t)i * a.feat_stride);
             sk_f4 r[K][NS];
