@@ -81,12 +81,21 @@ class DenseEdgeConv(nn.Module):
         The first of the k+1 neighbours is dropped as in the reference (:33-35)."""
         need_grad = x.requires_grad and torch.is_grad_enabled()
         if idx is None:
-            with torch.no_grad():
-                idx, _, knn_point = operations.knn_query(
-                    k + 1, x.detach(), x.detach(), unique=True, layout=layout,
-                    want_dist=False, want_grouped=not need_grad)
+            full = None
+            if need_grad and x.is_cuda and x.dtype == torch.float32 and hasattr(operations.BACKEND, "knn_graph"):
+                # training: only the neighbour SET matters (the nearest is dropped, the rest is max-pooled),
+                # so the graph kernel serves here too; None = configuration it does not cover
+                with torch.no_grad():
+                    full = operations.BACKEND.knn_graph(k + 1, x.detach().contiguous(), layout)
+            if full is not None:
+                idx, knn_point = full.long(), None
+            else:
+                with torch.no_grad():
+                    idx, _, knn_point = operations.knn_query(
+                        k + 1, x.detach(), x.detach(), unique=True, layout=layout,
+                        want_dist=False, want_grouped=not need_grad)
             idx = idx[:, :, 1:]
-            if not need_grad:
+            if knn_point is not None and not need_grad:
                 knn_point = knn_point[:, :, 1:, :]
         else:
             knn_point = None
