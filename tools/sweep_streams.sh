@@ -1,4 +1,4 @@
 cd /root/repo
-for cfg in "--steps 20" "--steps 20 --fps_per_sub_batch --fps_streams 8" "--steps 5" "--steps 5 --fps_per_sub_batch --fps_streams 8" "--steps 20 --fps_per_sub_batch --fps_streams 16"; do
-  echo -n "$cfg: "; timeout 150 python bench.py --no_cpu_baseline $cfg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f M  %.1f ms/step  fps launch %.0f ms' % (d['value']/1e6, d['ms_per_step'], d['roofline']['launch_ms']))" || echo failed
+for cfg in "--clouds 32" "--clouds 64 --net_streams 8 --sub_batch 4" "--clouds 64 --net_streams 16 --sub_batch 4" "--clouds 48 --net_streams 12 --sub_batch 4"; do
+  echo -n "$cfg: "; timeout 200 python bench.py --no_cpu_baseline --steps 12 $cfg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f M  %.1f ms/step  fps launch %.0f ms' % (d['value']/1e6, d['ms_per_step'], d['roofline']['launch_ms']))" || echo failed
 done
