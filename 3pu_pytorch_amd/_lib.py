@@ -32,6 +32,7 @@ SIGNATURES = {
     "tpu3_ball_query": (_i, [_vp, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
     "tpu3_nmdist_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_nmdist_bwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_chamfer_reduce_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "tpu3_knn_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp,
                           _vp, _i, _vp, _vp]),
     "tpu3_knn_unique_prepare_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "tpu3_knn_graph_self_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp, _vp, _sz]),
     "tpu3_knn_graph_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp]),
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),
+    "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i]),
 }

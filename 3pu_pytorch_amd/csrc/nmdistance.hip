@@ -187,6 +187,79 @@ __global__ __launch_bounds__(256) void nmdist_bwd_kernel(int n, int m,
     }
 }
 
+// ChamferLoss reduction (network/model_loss.py:64-84) in two launches instead of ~12 elementwise /
+// reduction launches: one workgroup per batch element sums its dist1 / dist2 rows (fixed order:
+// strided per-lane partials, butterfly per wave, waves in index order -- deterministic), applies the
+// outlier rule `d < threshold * mean(d)` (values beyond it count as 0, the divisor stays n) and
+// leaves (i) cd[e] = forward_weight * mean1 + mean2 and (ii) the derivative of the final loss with
+// respect to every distance, which is all the backward pass needs.
+constexpr int CR_THREADS = 256;
+
+__device__ __forceinline__ float cr_block_sum(float v, float *slots)
+{
+    v = tpu3_wave_sum_f32(v);
+    __syncthreads();                        // slots may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = slots[0];
+#pragma unroll
+    for (int w = 1; w < CR_THREADS / 64; ++w)
+        s += slots[w];
+    return s;
+}
+
+__device__ __forceinline__ float cr_direction(const float *__restrict__ d, float *__restrict__ gw, int n,
+                                              int use_thr, float thr, float gscale, float *slots)
+{
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += CR_THREADS)
+        acc += d[i];
+    float total = cr_block_sum(acc, slots);
+    if (use_thr) {
+        const float bound = (total / (float)n) * thr;     // torch.mean(d, dim=1) * threshold (:68-71)
+        acc = 0.f;
+        for (int i = threadIdx.x; i < n; i += CR_THREADS) {
+            const float v = d[i];
+            const bool keep = v < bound;
+            acc += keep ? v : 0.f;
+            if (gw) gw[i] = keep ? gscale : 0.f;
+        }
+        total = cr_block_sum(acc, slots);
+    } else if (gw) {
+        for (int i = threadIdx.x; i < n; i += CR_THREADS)
+            gw[i] = gscale;
+    }
+    return total / (float)n;
+}
+
+__global__ __launch_bounds__(CR_THREADS) void chamfer_reduce_kernel(int b, int n, int m,
+                                                                   const float *__restrict__ dist1,
+                                                                   const float *__restrict__ dist2,
+                                                                   int use_thr, float thr, float fw,
+                                                                   float *__restrict__ cd,
+                                                                   float *__restrict__ gw1,
+                                                                   float *__restrict__ gw2)
+{
+    __shared__ float slots[CR_THREADS / 64];
+    const int e = blockIdx.x;
+    const float m1 = cr_direction(dist1 + (size_t)e * n, gw1 ? gw1 + (size_t)e * n : nullptr, n, use_thr, thr,
+                                  fw / ((float)n * (float)b), slots);
+    const float m2 = cr_direction(dist2 + (size_t)e * m, gw2 ? gw2 + (size_t)e * m : nullptr, m, use_thr, thr,
+                                  1.0f / ((float)m * (float)b), slots);
+    if (threadIdx.x == 0) cd[e] = fw * m1 + m2;
+}
+
+// loss = mean over the batch of cd, summed in index order by one wave
+__global__ __launch_bounds__(64) void chamfer_final_kernel(int b, const float *__restrict__ cd,
+                                                          float *__restrict__ loss)
+{
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < b; i += 64)
+        acc += cd[i];
+    acc = tpu3_wave_sum_f32(acc);
+    if (threadIdx.x == 0) loss[0] = acc / (float)b;
+}
+
 int nm_dir(hipStream_t s, int b, int n, int m, const float *a, const float *bb, float *dist, int32_t *idx)
 {
     if (n == 0) return TPU3_OK;
@@ -266,5 +339,18 @@ extern "C" int tpu3_nmdist_bwd_f32(tpu3_stream_t stream, int b, int n, int m, co
         hipLaunchKernelGGL(nmdist_bwd_kernel, g, dim3(256), 0, s, m, n, xyz2, xyz1, graddist2, idx2,
                            gradxyz2, gradxyz1);
     }
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_chamfer_reduce_f32(tpu3_stream_t stream, int b, int n, int m, const float *dist1,
+                                       const float *dist2, int use_threshold, float threshold,
+                                       float forward_weight, float *loss, float *cd, float *gw1, float *gw2)
+{
+    if (b <= 0 || n <= 0 || m <= 0) return TPU3_EINVAL;
+    if (!dist1 || !dist2 || !loss || !cd) return TPU3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chamfer_reduce_kernel, dim3(b), dim3(CR_THREADS), 0, s, b, n, m, dist1, dist2,
+                       use_threshold ? 1 : 0, threshold, forward_weight, cd, gw1, gw2);
+    hipLaunchKernelGGL(chamfer_final_kernel, dim3(1), dim3(64), 0, s, b, (const float *)cd, loss);
     return tpu3_launch_status();
 }

@@ -70,7 +70,17 @@ class H5Dataset(data.Dataset):
         self.jitter_sigma = jitter_sigma
         self.drop_out = drop_out
         self.step_ratio = step_ratio
-        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        if device is None:
+            # the patch sampler (shape_to_patch -> operations.group_knn) runs on the HIP kernels only:
+            # unlike the reference's CPU sampler there is nothing to fall back to
+            if torch.cuda.is_available():
+                device = torch.device("cuda", torch.cuda.current_device())
+            elif getattr(operations.BACKEND, "name", "") == "hip-gfx950":
+                raise RuntimeError("H5Dataset needs a ROCm device (its kNN patch sampler runs on the gfx950 "
+                                   "kernels); pass device=... or make one visible")
+            else:
+                device = torch.device("cpu")          # a test stand-in backend is installed
+        self.device = torch.device(device)
         input_array, label_array = self.load_patch_data(h5_path, up_ratio, step_ratio, num_shape_point, store)
         self.input_array = torch.from_numpy(np.ascontiguousarray(input_array)).to(self.device)
         self.label_array = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device)

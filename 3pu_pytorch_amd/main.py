@@ -149,7 +149,7 @@ def train(flags, net, device, num_point, model_dir):
     model = Model(net, "train", flags)
     steps_per_epoch = int(os.environ.get("TPU3_STEPS_PER_EPOCH", "0"))
     if flags.h5_data != "synthetic":
-        from .data import H5Dataset
+        H5Dataset = importlib.import_module(_pkg.__name__ + ".data").H5Dataset
         dataset = H5Dataset(h5_path=flags.h5_data, num_shape_point=flags.num_shape_point, num_patch_point=num_point,
                             batch_size=flags.batch_size, up_ratio=flags.up_ratio, step_ratio=flags.step_ratio,
                             device=device)

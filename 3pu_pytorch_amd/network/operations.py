@@ -78,8 +78,12 @@ class HipBackend(object):
                 n_arr_t = layout.get("n_arr") if layout is not None else None
                 key = (points.data_ptr(), tuple(points.shape), 0 if n_arr_t is None else n_arr_t.data_ptr(), groups)
                 st = unique_cache.get("state") if unique_cache is not None else None
-                if st is not None and st["key"] == key:
-                    dup, uws, cand, cand_count = st["dup"], st["uws"], st["cand"], st["cand_count"]
+                if st is not None and st["key"] == key and st["points"] is points:
+                    # the first-occurrence mask and the candidate lists depend on `points` only; the
+                    # per-call words of uws ([1] "optimistic pass failed", [4+g] max(D) of the call's
+                    # groups) must start from the state tpu3_knn_unique_prepare_f32 left them in
+                    dup, cand, cand_count = st["dup"], st["cand"], st["cand_count"]
+                    uws = st["uws"].clone()
                 else:
                     dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
                     uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
@@ -97,7 +101,9 @@ class HipBackend(object):
                                                                 L.ptr(cand), L.ptr(cand_count)),
                                 "tpu3_knn_unique_compact_i32")
                     if unique_cache is not None:
-                        unique_cache["state"] = dict(key=key, dup=dup, uws=uws, cand=cand, cand_count=cand_count)
+                        # `points` itself is kept: the key holds its address, which must not be recycled
+                        unique_cache["state"] = dict(key=key, points=points, dup=dup, uws=uws.clone(), cand=cand,
+                                                     cand_count=cand_count)
                 if cand is not None:
                     if lay is None:
                         lay = L.KnnLayout()

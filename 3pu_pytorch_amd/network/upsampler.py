@@ -53,9 +53,9 @@ class Net(torch.nn.Module):
                                     torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
                     torch.nn.init.zeros_(m.bias)
                     torch.nn.init.ones_(m.weight)
-        # number of (outer patch, level) pairs whose filtered cloud was smaller than a patch
-        # (the batched eval path assumes it never is; checked by the pipeline at its one sync)
-        self.small_cloud_events = None
+        # per eval call and level: number of clouds whose outlier-filtered size was below one patch
+        # (0-d device tensors, appended without a synchronisation; see small_cloud_events)
+        self._small_cloud_counts = []
         # optional list: when set, the eval path appends one dict per level
         # (patch_xyz (P,3,k) un-normalised inputs, out_norm (P,3,k*r) level output, patch_num)
         self.trace = None
@@ -123,8 +123,7 @@ class Net(torch.nn.Module):
         # patch_num = int(num_point / k * 5) per cloud, in double like Python (:76)
         P = int(N / k * 5)
         patch_num = torch.floor(count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
-        small = (count < k).sum()
-        self.small_cloud_events = small if self.small_cloud_events is None else self.small_cloud_events + small
+        self._small_cloud_counts.append((count < k).sum())
         kk = min(k, N)
         seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
         slot = torch.minimum(_arange_like(P, xyz_cl).view(1, P), (patch_num - 1).view(B, 1).long())
@@ -134,12 +133,27 @@ class Net(torch.nn.Module):
                                              layout=dict(n_arr=count), want_dist=False)
         return patches, patch_num
 
+    @property
+    def small_cloud_events(self):
+        """Number of (cloud, level) pairs since the last reset whose filtered cloud had fewer points
+        than a patch.  The batched eval path keeps k = num_point there (the reference shrinks k to the
+        filtered size, :75-78), so such a cloud's result is NOT the reference's: callers that care
+        (pipeline.upsample(check_small=True), bench.py) read this after their synchronisation and
+        raise.  Reading synchronises the device (the counts live on whatever streams produced them)."""
+        if not self._small_cloud_counts:
+            return 0
+        if any(c.is_cuda for c in self._small_cloud_counts):
+            torch.cuda.synchronize()
+        return int(sum(int(c) for c in self._small_cloud_counts))
+
+    def reset_small_cloud_events(self):
+        self._small_cloud_counts = []
+
     def _forward_eval(self, xyz, ratio):
         B, _, num_point = xyz.size()
         dev = xyz.device
         num_levels = int(log(ratio, self.step_ratio))
         max_num_point = min(num_point, self.max_num_point)
-        self.small_cloud_events = None
         xyz_cl = xyz.transpose(2, 1).contiguous()                     # (B,N,3)
         for l in range(1, num_levels + 1):
             curr_ratio = self.step_ratio ** l
@@ -275,12 +289,14 @@ class Level(torch.nn.Module):
             bounds = list(range(0, B, self.max_patches)) + [B]
         else:
             # owner ids are non-decreasing (patches of one cloud are contiguous): cut between owners
+            # A chunk is always a whole number of owners: unique=True adds max(D) over one reference
+            # call = one owner's patches (operations.py:204), so an owner must never straddle chunks.
             per = B // groups if groups > 0 and B % groups == 0 else None
-            if per is None or per > self.max_patches:
-                bounds = list(range(0, B, self.max_patches)) + [B]
+            if per is None:
+                bounds = [0, B]
                 per_owner = 0
             else:
-                owners = self.max_patches // per
+                owners = max(1, self.max_patches // per)
                 if owners > 8:
                     owners -= owners % 8        # whole sets of 8 clouds: one per XCD (skip kernel)
                 step = owners * per

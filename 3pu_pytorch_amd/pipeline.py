@@ -88,7 +88,30 @@ def shard_range(total, rank, world):
 
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-             timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0):
+             timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, check_small=None):
+    """See _upsample.  check_small: after enqueueing, synchronise and raise if the outlier filter left
+    some cloud with fewer points than a patch at some level (the batched path does not reproduce the
+    reference's shrunken k there, network/upsampler.py:75-78).  Default: on for plain calls, off when
+    the caller overlaps work on side streams (fps_stream / net_streams) -- such callers (bench.py)
+    check `net.small_cloud_events` themselves at their own synchronisation point."""
+    if check_small is None:
+        check_small = fps_stream is None and not net_streams
+    if check_small and hasattr(net, "reset_small_cloud_events"):
+        net.reset_small_cloud_events()
+    out = _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
+                    net_streams, sub_batch, fps_offset)
+    if check_small and hasattr(net, "small_cloud_events"):
+        bad = net.small_cloud_events
+        if bad:
+            raise RuntimeError("%d cloud/level pairs were smaller than num_point=%d after the outlier filter; "
+                               "the batched pipeline does not cover that case (use a smaller --num_point)"
+                               % (bad, num_point))
+    return out
+
+
+@torch.no_grad()
+def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
+              timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0):
     """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
     the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
     Every rank passes the same `clouds` and receives the full result.
@@ -163,9 +186,9 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     elif shard == "clouds":
         ids, per = shard_range(C, rank, world)
         mine = clouds[ids]
-        local = upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
-                         timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch,
-                         fps_offset=fps_offset)
+        local = _upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
+                          timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch,
+                          fps_offset=fps_offset)
         for f in (fps_stream if isinstance(fps_stream, (list, tuple)) else [fps_stream]):
             if f is not None:
                 torch.cuda.current_stream().wait_stream(f)

@@ -100,6 +100,18 @@ int tpu3_nmdist_bwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *
                         const float *graddist1, const float *graddist2, const int32_t *idx1,
                         const int32_t *idx2);
 
+/* ChamferLoss reduction (network/model_loss.py:64-84) next to the nm-distance call: from the two
+ * distance rows of every batch element e
+ *   cd[e] = forward_weight * mean_i(keep1 * dist1[e,i]) + mean_j(keep2 * dist2[e,j]),
+ *   keep = 1, or with use_threshold != 0: dist < threshold * mean(dist row)   (:67-77),
+ *   loss[0] = mean_e cd[e]                                                    (:80-84),
+ * and, when gw1 (b,n) / gw2 (b,m) are not NULL, the derivative of loss with respect to every
+ * distance (forward_weight * keep1 / (n b), keep2 / (m b)) -- what the backward pass multiplies into
+ * tpu3_nmdist_bwd_f32.  Fixed summation order (deterministic); cd (b) f32 is scratch/out. */
+int tpu3_chamfer_reduce_f32(tpu3_stream_t stream, int b, int n, int m, const float *dist1,
+                            const float *dist2, int use_threshold, float threshold,
+                            float forward_weight, float *loss, float *cd, float *gw1, float *gw2);
+
 /* Optional batch layout of a kNN call (host struct, pointers inside are DEVICE pointers).
  * NULL layout = the reference's dense call: b query sets, b point sets, one group.
  *   n_arr   (bp)  live points of each point set inside its padded n-slab, or NULL
@@ -256,6 +268,18 @@ size_t tpu3_linear_wgrad_workspace_bytes(long m);
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
                        float *out, float *centroid, float *radius);
+
+/* ---- measurement hooks (bench.py and tools/ only; a caller of the path never needs them) ------------
+ * tpu3_debug_fps_bucket_events: the NEXT bucketed-FPS call (n beyond the register-resident limit)
+ * records `start` / `stop` (hipEvent_t created by the caller) on ITS stream immediately before / after
+ * its main round-loop kernel, so that exactly that kernel can be timed on whatever stream it runs on.
+ * One-shot, host-side state only.
+ * tpu3_debug_fps_bucket_profile: one cloud through the same kernel with per-phase cycle counters;
+ * prof (device) = waves x 8 u64. */
+int tpu3_debug_fps_bucket_events(void *start, void *stop);
+int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,
+                                  int32_t *idx, void *workspace, size_t workspace_bytes,
+                                  unsigned long long *prof);
 
 #ifdef __cplusplus
 }

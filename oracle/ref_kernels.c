@@ -102,19 +102,29 @@ void orc_fps_f32(int b, int n, int m, const float *xyz, float *temp, int32_t *id
                 dists[th] = -1.0f;
                 dists_i[th] = 0;
             }
-            for (int k = 0; k < n; ++k) {
-                const int th = k & (bs - 1); /* bs is a power of two */
-                const float td = t[k];
-                const float d = sqdist3_f(p[k * 3 + 0] - x1, p[k * 3 + 1] - y1,
-                                          p[k * 3 + 2] - z1, fma_on);
-                const float d2 = fminf(d, td);
-                if (d2 != td)
-                    t[k] = d2;
-                if (d2 > dists[th]) {
-                    dists[th] = d2;
-                    dists_i[th] = k;
+            /* The emulated threads are independent of each other, so ranges of them may run on
+             * different host cores (OpenMP) without changing any result: chunk c owns the
+             * emulated threads [c*cw, (c+1)*cw) and walks their k in ascending order. */
+            const int nchunk = (n >= 8192 && bs >= 64) ? 16 : 1;
+            const int cw = bs / nchunk;
+#pragma omp parallel for schedule(static) if (nchunk > 1)
+            for (int c = 0; c < nchunk; ++c)
+                for (int kb = 0; kb < n; kb += bs) {
+                    const int hi = (kb + (c + 1) * cw < n) ? kb + (c + 1) * cw : n;
+                    for (int k = kb + c * cw; k < hi; ++k) {
+                        const int th = k & (bs - 1); /* bs is a power of two */
+                        const float td = t[k];
+                        const float d = sqdist3_f(p[k * 3 + 0] - x1, p[k * 3 + 1] - y1,
+                                                  p[k * 3 + 2] - z1, fma_on);
+                        const float d2 = fminf(d, td);
+                        if (d2 != td)
+                            t[k] = d2;
+                        if (d2 > dists[th]) {
+                            dists[th] = d2;
+                            dists_i[th] = k;
+                        }
+                    }
                 }
-            }
             for (int u = 0; (1 << u) < bs; ++u) {
                 for (int th = 0; th < (bs >> (u + 1)); ++th) {
                     const int i1 = (th * 2) << u, i2 = (th * 2 + 1) << u;
@@ -245,6 +255,8 @@ static void nm_one_direction(int b, int n, const float *xyz, int m, const float 
         for (int k2 = 0; k2 < m; k2 += TILE) {
             const int end_k = (m < k2 + TILE ? m : k2 + TILE) - k2;
             const float *buf = xyz2 + ((size_t)i * m + k2) * 3;
+            /* every query j is independent (its own result slot): host cores share the j loop */
+#pragma omp parallel for schedule(static) if ((long long)n * end_k >= 1000000)
             for (int j = 0; j < n; ++j) {
                 const float x1 = xyz[((size_t)i * n + j) * 3 + 0];
                 const float y1 = xyz[((size_t)i * n + j) * 3 + 1];
@@ -339,6 +351,7 @@ void orc_first_occurrence_dup(int b, int n, int c, const float *points, uint8_t 
 {
     for (int bi = 0; bi < b; ++bi) {
         const float *P = points + (size_t)bi * n * c;
+#pragma omp parallel for schedule(dynamic, 64) if (n >= 1024)
         for (int i = 0; i < n; ++i) {
             uint8_t d = 0;
             for (int j = 0; j < i && !d; ++j) {
@@ -370,12 +383,17 @@ static int knn_pair_cmp(const void *a, const void *b)
     return (x->i > y->i) - (x->i < y->i);
 }
 
+/* (d, i) lexicographic "less": ascending distance, ties to the lowest index */
+static int knn_less(float d, int32_t i, const knn_pair *y)
+{
+    return d < y->d || (d == y->d && i < y->i);
+}
+
 void orc_knn_f32(int b, int m, int n, int c, int k, const float *query, const float *points,
                  int unique, int32_t *idx, float *dist)
 {
     float *rp = (float *)malloc(sizeof(float) * (size_t)b * n);
     uint8_t *dup = (uint8_t *)calloc((size_t)b * n, 1);
-    knn_pair *row = (knn_pair *)malloc(sizeof(knn_pair) * (size_t)n);
     for (size_t t = 0; t < (size_t)b * n; ++t)
         rp[t] = sqnorm_chain(points + t * c, c);
     float dmax = 0.f;
@@ -384,43 +402,64 @@ void orc_knn_f32(int b, int m, int n, int c, int k, const float *query, const fl
         orc_first_occurrence_dup(b, n, c, points, dup);
         for (size_t t = 0; t < (size_t)b * n; ++t)
             any_dup |= dup[t];
-        /* torch.max(D) over the whole tensor (:204); needed only if something is added */
+        /* torch.max(D) over the whole tensor (:204); needed only if something is added.
+         * (max is associative and exact: the partition over host cores does not matter) */
         if (any_dup) {
-            int first = 1;
-            for (int bi = 0; bi < b; ++bi)
-                for (int j = 0; j < m; ++j) {
-                    const float *q = query + ((size_t)bi * m + j) * c;
-                    const float rq = sqnorm_chain(q, c);
-                    for (int t = 0; t < n; ++t) {
-                        const float d = knn_dist(q, rq, points + ((size_t)bi * n + t) * c,
-                                                 rp[(size_t)bi * n + t], c);
-                        if (first || d > dmax) {
-                            dmax = d;
-                            first = 0;
-                        }
-                    }
+            dmax = -INFINITY;
+#pragma omp parallel for schedule(static) reduction(max : dmax)
+            for (long long qi = 0; qi < (long long)b * m; ++qi) {
+                const int bi = (int)(qi / m);
+                const float *q = query + (size_t)qi * c;
+                const float rq = sqnorm_chain(q, c);
+                for (int t = 0; t < n; ++t) {
+                    const float d = knn_dist(q, rq, points + ((size_t)bi * n + t) * c,
+                                             rp[(size_t)bi * n + t], c);
+                    if (d > dmax)
+                        dmax = d;
                 }
+            }
         }
     }
-    for (int bi = 0; bi < b; ++bi)
-        for (int j = 0; j < m; ++j) {
-            const float *q = query + ((size_t)bi * m + j) * c;
+    /* every query row is independent.  k <= 64: bounded insertion into the sorted list of the k
+     * best (d, i) pairs; larger k: full sort of the row.  Same total order either way. */
+#pragma omp parallel
+    {
+        knn_pair *row = (knn_pair *)malloc(sizeof(knn_pair) * (size_t)(k <= 64 ? k : n));
+#pragma omp for schedule(static)
+        for (long long qi = 0; qi < (long long)b * m; ++qi) {
+            const int bi = (int)(qi / m);
+            const float *q = query + (size_t)qi * c;
             const float rq = sqnorm_chain(q, c);
+            int have = 0;
             for (int t = 0; t < n; ++t) {
                 float d = knn_dist(q, rq, points + ((size_t)bi * n + t) * c,
                                    rp[(size_t)bi * n + t], c);
                 if (any_dup)
                     d = d + dmax * (float)dup[(size_t)bi * n + t];
-                row[t].d = d;
-                row[t].i = t;
+                if (k > 64) {
+                    row[t].d = d;
+                    row[t].i = t;
+                    continue;
+                }
+                if (have == k && !knn_less(d, t, &row[k - 1]))
+                    continue;
+                int pos = have < k ? have++ : k - 1;
+                while (pos > 0 && knn_less(d, t, &row[pos - 1])) {
+                    row[pos] = row[pos - 1];
+                    --pos;
+                }
+                row[pos].d = d;
+                row[pos].i = t;
             }
-            qsort(row, (size_t)n, sizeof(knn_pair), knn_pair_cmp);
+            if (k > 64)
+                qsort(row, (size_t)n, sizeof(knn_pair), knn_pair_cmp);
             for (int t = 0; t < k; ++t) {
-                idx[((size_t)bi * m + j) * k + t] = row[t].i;
-                dist[((size_t)bi * m + j) * k + t] = row[t].d;
+                idx[(size_t)qi * k + t] = row[t].i;
+                dist[(size_t)qi * k + t] = row[t].d;
             }
         }
+        free(row);
+    }
     free(rp);
     free(dup);
-    free(row);
 }

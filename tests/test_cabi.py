@@ -27,6 +27,17 @@ def test_header_functions_are_exported_and_bound():
     assert sorted(L.SIGNATURES.keys()) == names            # the Python binding covers the header
 
 
+def test_every_exported_symbol_is_declared():
+    """The converse: nothing with C linkage leaves the library that include/tpu3.h does not declare."""
+    import subprocess
+    L = pkg("_lib")
+    pkg("build").build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" T tpu3_[a-z0-9_]+$", ln)})
+    assert exported, "no tpu3_* symbols found"
+    assert set(exported) <= set(_declared()), sorted(set(exported) - set(_declared()))
+
+
 def test_version_and_strerror():
     L = pkg("_lib")
     assert L.lib().tpu3_version().decode().startswith("3pu-hip")

@@ -34,6 +34,9 @@ def test_fps_bit_exact(orc, dev, b, n, m):
 
 @pytest.mark.parametrize("b,n,m,dups", [(1, 30000, 3000, False), (2, 70000, 1500, False),
                                           (1, 239616, 2500, False), (1, 40000, 4000, True),
+                                          # a quarter of the metric's final resampling (239 616 -> 80 000):
+                                          # 4.8 G point-rounds of the oracle, multi-core C
+                                          (1, 239616, 20000, False),
                                           (1, 26000, 26000, False), (3, 25601, 300, False)])
 def test_fps_bucketed_kernel_bit_exact(orc, dev, b, n, m, dups):
     """Point sets beyond the register-resident limit take the Morton-bucket kernel with exact
@@ -242,7 +245,9 @@ def test_ball_query(orc, dev, dtype):
 
 # ---- nm-distance (a5, a6) --------------------------------------------------------------------
 @pytest.mark.parametrize("b,n,m", [(32, 624, 624), (2, 1000, 513), (1, 5000, 4992), (3, 1, 7),
-                                   (1, 20000, 20000)])
+                                   (1, 20000, 20000),
+                                   # the metric's Chamfer: one 80 000-point cloud against another
+                                   (1, 80000, 80000)])
 def test_nmdistance_forward_bit_exact(orc, dev, b, n, m):
     losses = pkg("losses")
     x1 = sphere(5, n, b)
