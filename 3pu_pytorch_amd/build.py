@@ -47,8 +47,11 @@ def _compile_one(args):
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> objs/*.o (only the translation units whose source or any header is
     newer than their object, in parallel) and link lib3pu_hip.so."""
-    os.makedirs(OBJ, exist_ok=True)
     hdr_time = max(os.path.getmtime(h) for h in _headers())
+    if not force and os.path.exists(LIB) and \
+            os.path.getmtime(LIB) >= max([hdr_time] + [os.path.getmtime(f) for f in sources()]):
+        return LIB                           # up to date (the objects need not exist, e.g. on the GPU box)
+    os.makedirs(OBJ, exist_ok=True)
     todo, objs = [], []
     for src in sources():
         obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
@@ -72,6 +75,60 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- compiled drop-in extension modules (`import sampling`, `import losses`) ---------------------------
+EXT_SRC = os.path.join(CSRC, "ext")
+DROPIN = os.path.join(HERE, "dropin")       # put THIS directory on sys.path to get the bare module names
+
+
+def _dropin_path(name):
+    import sysconfig
+    return os.path.join(DROPIN, name + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_dropin(force=False, verbose=False):
+    """g++ -> dropin/sampling.*.so and dropin/losses.*.so: pybind11 modules over torch tensors (host
+    code only) that call the C ABI of lib3pu_hip.so; what the reference builds with
+    sampling/setup.py and losses/setup.py."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    build()
+    os.makedirs(DROPIN, exist_ok=True)
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    incs = cpp_extension.include_paths() + ["/opt/rocm/include", sysconfig.get_paths()["include"]]
+    deps = [os.path.join(EXT_SRC, "ext_common.h"), os.path.join(HERE, "..", "include", "tpu3.h"),
+            os.path.abspath(__file__)]
+    outs = []
+    jobs = []
+    for name in ("sampling", "losses"):
+        src = os.path.join(EXT_SRC, name + "_module.cpp")
+        out = _dropin_path(name)
+        outs.append(out)
+        newest = max(os.path.getmtime(f) for f in [src] + deps)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+            continue
+        cmd = (["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+                "-DTORCH_EXTENSION_NAME=" + name, "-DTORCH_API_INCLUDE_EXTENSION_H",
+                "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-deprecated-declarations"]
+               + ["-I" + i for i in incs] + [src, "-o", out + ".tmp", "-L" + tlib, "-L" + HERE,
+                                              "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_python",
+                                              "-l:lib3pu_hip.so", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + tlib])
+        jobs.append((cmd, out))
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(job):
+            cmd, out = job
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(out + ".tmp", out)
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    return outs
+
+
 if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_dropin(force="--force" in sys.argv, verbose=True))
