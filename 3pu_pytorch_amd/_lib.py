@@ -52,8 +52,10 @@ SIGNATURES = {
     "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),
     "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _i]),
+                                      _vp, _i, _i]),
 }
+
+MFMA_F32, MFMA_F16 = 0, 1        # TPU3_MFMA_* of include/tpu3.h
 
 _lib = None
 

@@ -11,8 +11,10 @@
 //
 // The reference materialises (B,48..60,N,k) tensors between six ATen kernels (1x1 convolutions with
 // 12 output channels, concatenations, max): ~4.6 GB per tensor at the level-4 batch, memory bound.
-// Here a workgroup owns one patch: its (N,24) features sit in LDS, every edge's 60-channel vector
-// lives only in MFMA accumulators, and HBM sees x once, the neighbour indices once and y once.
+// Here a workgroup owns one patch (or, for patches beyond ~2700 points, a 512-point slice of it): what
+// an edge needs of its neighbour is a 12-float row of a per-point table (below) kept in LDS (in global
+// memory / L2 for the large patches), every edge's 60-channel vector lives only in MFMA accumulators,
+// and HBM sees x once, the neighbour indices once and y once -- y as one contiguous 240-byte run per point.
 //
 // MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32 fma chains): rows = output channels (12 of 16),
 // columns = 16 POINTS (one neighbour slot of each at a time), K = input channels 4 at a time.
@@ -37,13 +39,16 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int DEC_C = 24;        // input channels
 constexpr int DEC_G = 12;        // growth rate
-constexpr int DEC_S = 26;        // LDS row stride of the patch features (floats)
 constexpr int DEC_NW = 8;        // waves per workgroup
 constexpr int DEC_ZS = 12;       // floats per point in the z table
 constexpr int DEC_TS = 64;       // words per point-slot row of the per-wave neighbour tile (k <= 64)
+constexpr int DEC_SLICE = 512;   // points per workgroup when a patch is split (global z table)
 
 struct DecArgs {
     int n;                       // points per patch
@@ -56,6 +61,7 @@ struct DecArgs {
     const float *w2, *b2;        // (12,48), (12)
     float *out;                  // (P, n, out_stride): y written at channels [0,60)
     int out_stride;
+    float *zg;                   // (P, n, 12) z table in global memory (patches too large for LDS), else null
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -72,52 +78,227 @@ __device__ __forceinline__ float dec_relu(float v)
     return r;
 }
 
-// ZTAB: the per-point table z = W0b x fits LDS next to the features (patches up to ~700 points);
-// otherwise the first layer's W0b x_j is evaluated per edge (6 more MFMAs per tile).
-template <int TILES, bool ZTAB>     // TILES = k / 16
+__device__ __forceinline__ f16x4 to_h4(f32x4 v)
+{
+    f16x4 r;
+    r[0] = (_Float16)v[0]; r[1] = (_Float16)v[1]; r[2] = (_Float16)v[2]; r[3] = (_Float16)v[3];
+    return r;
+}
+
+// ---- operand sets of the two arithmetic flavours -----------------------------------------------------------
+// fp32: v_mfma_f32_16x16x4_f32, exact fp32 fma chains.  Lane (m = e, g) keeps the A operands of every step:
+//   centre terms (W0a-W0b), W1b, W2c and W0b over the 24 input channels: channel 6g+s at step s (6 steps);
+//   W1a, W2a, W2b over the 12 hidden channels: channel 4g+r at step r (4 steps, g = 3 is padding).
+struct DecW32 {
+    float wt0[6], wt1[6], wt2[6], w0b[6], w1a[4], w2a[4], w2b[4];
+    __device__ __forceinline__ void load(const DecArgs &a, int m, int g)
+    {
+        const bool live = m < DEC_G;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int c = 6 * g + s;
+            const float wa = live ? a.w0[m * 48 + c] : 0.f, wb = live ? a.w0[m * 48 + 24 + c] : 0.f;
+            wt0[s] = wa - wb;
+            w0b[s] = wb;
+            wt1[s] = live ? a.w1[m * 36 + 12 + c] : 0.f;
+            wt2[s] = live ? a.w2[m * 48 + 24 + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * g + r;
+            const bool ok = live && c < DEC_G;
+            w1a[r] = ok ? a.w1[m * 36 + c] : 0.f;
+            w2a[r] = ok ? a.w2[m * 48 + c] : 0.f;
+            w2b[r] = ok ? a.w2[m * 48 + 12 + c] : 0.f;
+        }
+    }
+    // x6 = channels 6g .. 6g+5 of the lane's point
+    __device__ __forceinline__ void centre(const float *x6, f32x4 &c0, f32x4 &c1, f32x4 &c2) const
+    {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            c0 = mfma4(wt0[s], x6[s], c0);
+            c1 = mfma4(wt1[s], x6[s], c1);
+            c2 = mfma4(wt2[s], x6[s], c2);
+        }
+    }
+    __device__ __forceinline__ f32x4 ztab(const float *x6) const
+    {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            z = mfma4(w0b[s], x6[s], z);
+        return z;
+    }
+    template <int U>
+    __device__ __forceinline__ void layers(const f32x4 (&h0)[U], f32x4 (&h1)[U], f32x4 (&h2)[U], f32x4 c1, f32x4 c2) const
+    {
+        // the U slots are independent accumulator chains: issuing their MFMAs alternately hides the
+        // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            h1[u] = c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                h1[u] = mfma4(w1a[r], h0[u][r], h1[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h1[u][r] = dec_relu(h1[u][r]);
+            h2[u] = c2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                h2[u] = mfma4(w2a[r], h1[u][r], h2[u]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                h2[u] = mfma4(w2b[r], h0[u][r], h2[u]);
+    }
+};
+
+// fp16 inputs on the matrix cores, fp32 accumulate (config C5, "fp16 feature MLPs on MFMA"): the weights and
+// the activations entering an MFMA are rounded to fp16, everything between them (bias, ReLU, max, the z table)
+// stays fp32.  v_mfma_f32_16x16x32_f16 takes eight k values per lane: lane (point e, g) supplies channels
+// 8g .. 8g+7 of the 24 inputs (g = 3: zeros) -- ONE instruction per 24-channel product -- and for the last
+// layer [h1 (4g..4g+3) | h0 (4g..4g+3)], i.e. W2a h1 + W2b h0 in ONE instruction; W1a h0 is one
+// v_mfma_f32_16x16x16_f16.  2 MFMAs per 16-edge tile instead of 12.
+struct DecW16 {
+    f16x8 wt0, wt1, wt2, w0b, w2ab;
+    f16x4 w1a;
+    __device__ __forceinline__ void load(const DecArgs &a, int m, int g)
+    {
+        const bool live = m < DEC_G;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j;
+            const bool ok = live && c < DEC_C;
+            const float wa = ok ? a.w0[m * 48 + c] : 0.f, wb = ok ? a.w0[m * 48 + 24 + c] : 0.f;
+            wt0[j] = (_Float16)(wa - wb);
+            w0b[j] = (_Float16)wb;
+            wt1[j] = (_Float16)(ok ? a.w1[m * 36 + 12 + c] : 0.f);
+            wt2[j] = (_Float16)(ok ? a.w2[m * 48 + 24 + c] : 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * g + r;
+            const bool ok = live && c < DEC_G;
+            w1a[r] = (_Float16)(ok ? a.w1[m * 36 + c] : 0.f);
+            w2ab[r] = (_Float16)(ok ? a.w2[m * 48 + c] : 0.f);
+            w2ab[4 + r] = (_Float16)(ok ? a.w2[m * 48 + 12 + c] : 0.f);
+        }
+    }
+    // x8 = channels 8g .. 8g+7 of the lane's point (zeros for g = 3)
+    __device__ __forceinline__ void centre(f16x8 x8, f32x4 &c0, f32x4 &c1, f32x4 &c2) const
+    {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt0, x8, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt1, x8, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt2, x8, c2, 0, 0, 0);
+    }
+    __device__ __forceinline__ f32x4 ztab(f16x8 x8) const
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, x8, z, 0, 0, 0);
+    }
+    template <int U>
+    __device__ __forceinline__ void layers(const f32x4 (&h0)[U], f32x4 (&h1)[U], f32x4 (&h2)[U], f32x4 c1, f32x4 c2) const
+    {
+        f16x4 h0h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            h0h[u] = to_h4(h0[u]);
+            h1[u] = __builtin_amdgcn_mfma_f32_16x16x16f16(w1a, h0h[u], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h1[u][r] = dec_relu(h1[u][r]);
+            const f16x4 h1h = to_h4(h1[u]);
+            f16x8 b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                b[r] = h1h[r];
+                b[4 + r] = h0h[u][r];
+            }
+            h2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2ab, b, c2, 0, 0, 0);
+        }
+    }
+};
+
+// x row fragments of the lane's point, straight from global memory (read once per point)
+__device__ __forceinline__ void dec_load_x6(const float *xrow, int g, float *x6)
+{
+    const f32x2 *p = (const f32x2 *)(xrow + 6 * g);           // 24 g bytes: 8-byte aligned
+    const f32x2 a = p[0], b = p[1], c = p[2];
+    x6[0] = a[0]; x6[1] = a[1]; x6[2] = b[0]; x6[3] = b[1]; x6[4] = c[0]; x6[5] = c[1];
+}
+__device__ __forceinline__ f16x8 dec_load_x8(const float *xrow, int g)
+{
+    const int gg = g < 3 ? g : 0;
+    const f32x4 a = *(const f32x4 *)(xrow + 8 * gg), b = *(const f32x4 *)(xrow + 8 * gg + 4);
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = g < 3 ? (_Float16)a[j] : (_Float16)0.f;
+        r[4 + j] = g < 3 ? (_Float16)b[j] : (_Float16)0.f;
+    }
+    return r;
+}
+
+// z_p = W0b x_p for a block of 16 points (columns = points) -> table rows (LDS or global)
+template <bool F16, typename W>
+__device__ __forceinline__ void dec_ztab_block(const W &w, const float *X, int n, int pb, int e, int g, float *zt)
+{
+    const float *xrow = X + (size_t)min(pb + e, n - 1) * DEC_C;
+    f32x4 z;
+    if constexpr (F16) {
+        z = w.ztab(dec_load_x8(xrow, g));
+    } else {
+        float x6[6];
+        dec_load_x6(xrow, g, x6);
+        z = w.ztab(x6);
+    }
+    if (g < 3 && pb + e < n)
+        *(f32x4 *)(zt + (size_t)(pb + e) * DEC_ZS + 4 * g) = z;
+}
+
+// z table of patches too large for LDS: one wave per 16 points, whole GPU
+template <bool F16>
+__global__ __launch_bounds__(256) void dec_ztab_kernel(DecArgs a)
+{
+    const int lane = threadIdx.x & 63, e = lane & 15, g = lane >> 4;
+    std::conditional_t<F16, DecW16, DecW32> w;
+    w.load(a, e, g);
+    const int pb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (pb >= a.n)
+        return;
+    dec_ztab_block<F16>(w, a.x + (size_t)blockIdx.y * a.n * DEC_C, a.n, pb, e, g,
+                        a.zg + (size_t)blockIdx.y * a.n * DEC_ZS);
+}
+
+// TILES = k / 16.  ZG: the z table lives in global memory (a.zg) and blockIdx.y selects a DEC_SLICE-point
+// slice of the patch; otherwise the table is built in LDS and the workgroup owns the whole patch.
+template <int TILES, bool F16, bool ZG>
 __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xs = lds;                                   // n * DEC_S
-    float *tb = lds + ((a.n * DEC_S + 3) & ~3);        // DEC_NW * 16 * DEC_TS
-    float *zt = tb + DEC_NW * 16 * DEC_TS;             // n * DEC_ZS (+ 4 floats of slack)
+    float *tb = lds;                                   // DEC_NW * 16 * DEC_TS
+    float *zl = lds + DEC_NW * 16 * DEC_TS;            // n * DEC_ZS (+ 4 floats of slack), !ZG only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 15, g = lane >> 4;
     const int n = a.n;
     const float *X = a.x + (size_t)blockIdx.x * n * DEC_C;
     float *O = a.out + (size_t)blockIdx.x * n * a.out_stride;
 
-    // ---- the patch's features -> LDS; x_i also goes straight to the output (channels 36..59) ------
-    for (int t = tid; t < n * DEC_C; t += DEC_NW * 64) {
-        const int i = t / DEC_C, c = t - i * DEC_C;
-        const float v = X[t];
-        xs[i * DEC_S + c] = v;
-        O[(size_t)i * a.out_stride + 3 * DEC_G + c] = v;
-    }
-
-    // ---- weights: lane (m = e, g) holds the A operands of every step -----------------------------
-    const int m = e;
-    const bool live = m < DEC_G;
-    float wt0[6], wt1[6], wt2[6];    // centre terms: (W0a-W0b), W1b, W2c   channel 6g+s
-    float w0b[6];                    // W0b                                 channel 6g+s
-    float w1a[4], w2a[4], w2b[4];    // W1a, W2a (h1), W2b (h0)             channel 4g+r  (g = 3: padding)
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int c = 6 * g + s;
-        const float wa = live ? a.w0[m * 48 + c] : 0.f, wb = live ? a.w0[m * 48 + 24 + c] : 0.f;
-        wt0[s] = wa - wb;
-        w0b[s] = wb;
-        wt1[s] = live ? a.w1[m * 36 + 12 + c] : 0.f;
-        wt2[s] = live ? a.w2[m * 48 + 24 + c] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = 4 * g + r;
-        const bool ok = live && c < DEC_G;
-        w1a[r] = ok ? a.w1[m * 36 + c] : 0.f;
-        w2a[r] = ok ? a.w2[m * 48 + c] : 0.f;
-        w2b[r] = ok ? a.w2[m * 48 + 12 + c] : 0.f;
-    }
+    std::conditional_t<F16, DecW16, DecW32> w;
+    w.load(a, e, g);
     // bias of the 4 channels this lane's accumulator rows hold (rows 4g..4g+3)
     f32x4 bias0, bias1, bias2;
 #pragma unroll
@@ -127,19 +308,20 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
         bias1[r] = c < DEC_G ? a.b1[c] : 0.f;
         bias2[r] = c < DEC_G ? a.b2[c] : 0.f;
     }
-    __syncthreads();
 
-    // ---- z_p = W0b x_p for every point of the patch (columns = points) ------------------------------
-    for (int pb = wave * 16; ZTAB && pb < n; pb += DEC_NW * 16) {
-        const float *xp = xs + min(pb + e, n - 1) * DEC_S + 6 * g;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-            z = mfma4(w0b[s], xp[s], z);
-        if (g < 3 && pb + e < n)
-            *(f32x4 *)(zt + (pb + e) * DEC_ZS + 4 * g) = z;
+    const float *ztab;
+    int p_lo = 0, p_hi = n;
+    if constexpr (ZG) {
+        ztab = a.zg + (size_t)blockIdx.x * n * DEC_ZS;
+        p_lo = blockIdx.y * DEC_SLICE;
+        p_hi = min(n, p_lo + DEC_SLICE);
+    } else {
+        // ---- z_p = W0b x_p for every point of the patch, once, into LDS ------------------------------
+        for (int pb = wave * 16; pb < n; pb += DEC_NW * 16)
+            dec_ztab_block<F16>(w, X, n, pb, e, g, zl);
+        __syncthreads();
+        ztab = zl;
     }
-    __syncthreads();
     const int zoff = g < 3 ? 4 * g : 0;     // lanes of the padding channel group read finite values (x 0 weights)
 
     // ---- 16 points per wave step: columns = POINTS, one neighbour slot at a time ---------------------
@@ -148,9 +330,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
     // reduction), and lane (e, g) gathers rows 4g..4g+3 of ITS point's neighbour.
     constexpr int K = 16 * TILES;
     constexpr int U = 2;                        // neighbour slots in flight (independent MFMA chains)
-    int *IT = (int *)(tb + wave * 16 * DEC_TS);  // per-wave tile [slot][16 points]: byte offset of the neighbour's row
-    const char *gbase = ZTAB ? (const char *)(zt + zoff) : (const char *)(xs + 6 * g);
-    for (int pb = wave * 16; pb < n; pb += DEC_NW * 16) {
+    int *IT = (int *)(tb + wave * 16 * DEC_TS);  // per-wave tile [slot][16 points]: byte offset of the neighbour's z row
+    float *ST = (float *)IT;                     // ... re-used as the output staging area [16 points][36]
+    const char *gbase = (const char *)(ztab + zoff);
+    for (int pb = p_lo + wave * 16; pb < p_hi; pb += DEC_NW * 16) {
         // neighbour indices of the 16 points, clamped and scaled once, read coalesced (k contiguous per point)
         for (int t = lane; t < 16 * K; t += 64) {
             const int pt = t / K, sl = t - pt * K;
@@ -158,18 +341,18 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
             const size_t io = ((size_t)blockIdx.x * n + i) * a.idx_stride + a.idx_off + sl;
             int j = a.idx64 ? (int)((const long long *)a.idx)[io] : ((const int *)a.idx)[io];
             j = min(max(j, 0), n - 1);
-            IT[sl * 16 + pt] = j * (int)((ZTAB ? DEC_ZS : DEC_S) * sizeof(float));
+            IT[sl * 16 + pt] = j * (int)(DEC_ZS * sizeof(float));
         }
         // centre terms of the lane's point (+ bias): the initial values of the three accumulators
         f32x4 c0 = bias0, c1 = bias1, c2 = bias2;
         {
-            const float *xp = xs + min(pb + e, n - 1) * DEC_S + 6 * g;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const float xv = xp[s];
-                c0 = mfma4(wt0[s], xv, c0);
-                c1 = mfma4(wt1[s], xv, c1);
-                c2 = mfma4(wt2[s], xv, c2);
+            const float *xrow = X + (size_t)min(pb + e, n - 1) * DEC_C;
+            if constexpr (F16) {
+                w.centre(dec_load_x8(xrow, g), c0, c1, c2);
+            } else {
+                float x6[6];
+                dec_load_x6(xrow, g, x6);
+                w.centre(x6, c0, c1, c2);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -182,56 +365,14 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 off[u] = IT[(kk + u) * 16 + e];
-            if (ZTAB) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const f32x4 z = *(const f32x4 *)(gbase + off[u]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h0[u][r] = fmaxf(c0[r] + z[r], 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    h0[u] = c0;
-#pragma unroll
-                for (int s = 0; s < 6; ++s)
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        h0[u] = mfma4(w0b[s], ((const float *)(gbase + off[u]))[s], h0[u]);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h0[u][r] = dec_relu(h0[u][r]);
-            }
-            // the U slots are independent accumulator chains: issuing their MFMAs alternately hides the
-            // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                h1[u] = c1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    h1[u] = mfma4(w1a[r], h0[u][r], h1[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                const f32x4 z = *(const f32x4 *)(gbase + off[u]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    h1[u][r] = dec_relu(h1[u][r]);
-                h2[u] = c2;
+                    h0[u][r] = fmaxf(c0[r] + z[r], 0.f);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    h2[u] = mfma4(w2a[r], h1[u][r], h2[u]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    h2[u] = mfma4(w2b[r], h0[u][r], h2[u]);
+            w.template layers<U>(h0, h1, h2, c1, c2);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -241,46 +382,53 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
                     m2[r] = fmaxf(m2[r], h2[u][r]);
                 }
         }
-        if (g < 3 && pb + e < n) {
-            float *o = O + (size_t)(pb + e) * a.out_stride + 4 * g;
-            *(f32x4 *)(o) = m2;                  // [0,12)  max h2
-            *(f32x4 *)(o + DEC_G) = m1;          // [12,24) max h1
-            *(f32x4 *)(o + 2 * DEC_G) = m0;      // [24,36) max h0
+        // ---- write-out: the 60-float row [max h2 | max h1 | max h0 | x_i] of every point leaves as whole
+        // 16-byte pieces of ONE contiguous 240-byte run per point (staged through the wave's tile, the x_i part
+        // straight from the input row) instead of three scattered 16-byte stores per lane
+        __builtin_amdgcn_wave_barrier();
+        if (g < 3) {
+            float *st = ST + e * 36 + 4 * g;
+            *(f32x4 *)(st) = m2;                  // [0,12)  max h2
+            *(f32x4 *)(st + DEC_G) = m1;          // [12,24) max h1
+            *(f32x4 *)(st + 2 * DEC_G) = m0;      // [24,36) max h0
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1      // (unrolled, the four row pieces in flight cost 33 VGPRs and a wave of occupancy)
+        for (int t0 = 0; t0 < 16 * 15; t0 += 64) {
+            const int t = t0 + lane;
+            const int pt = t / 15, q4 = t - pt * 15;
+            if (t < 16 * 15 && pb + pt < n) {
+                const f32x4 v = q4 < 9 ? *(const f32x4 *)(ST + pt * 36 + 4 * q4)
+                                       : *(const f32x4 *)(X + (size_t)(pb + pt) * DEC_C + 4 * (q4 - 9));
+                *(f32x4 *)(O + (size_t)(pb + pt) * a.out_stride + 4 * q4) = v;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-} // namespace
+constexpr size_t DEC_LDS_TILE_BYTES = (size_t)DEC_NW * 16 * DEC_TS * sizeof(float);
 
-// Internal entry (declared in include/tpu3.h as tpu3_dense_edge_conv_f32).
-extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
-                                        const void *idx, int idx_elem_size, int idx_stride, int idx_off,
-                                        const float *w0, const float *b0, const float *w1, const float *b1,
-                                        const float *w2, const float *b2, float *out, int out_stride)
+template <bool F16>
+int dec_launch(hipStream_t s, int patches, DecArgs &a)
 {
-    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
-    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
-    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
-    if (patches == 0) return TPU3_OK;
-    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return TPU3_EINVAL;
-    if (((uintptr_t)out % 16) != 0) return TPU3_EINVAL;
-    const size_t base = (size_t)((n * DEC_S + 3) & ~3) + (size_t)DEC_NW * 16 * DEC_TS;
-    const size_t with_z = (base + (size_t)n * DEC_ZS + 4) * sizeof(float);
-    const bool ztab = with_z <= 160 * 1024;
-    const size_t lds = ztab ? with_z : base * sizeof(float);
-    if (lds > 160 * 1024) return TPU3_ELIMIT;
-    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride};
-    hipStream_t s = (hipStream_t)stream;
+    const size_t with_z = DEC_LDS_TILE_BYTES + ((size_t)a.n * DEC_ZS + 4) * sizeof(float);
+    const bool zg = with_z > 160 * 1024;
     hipError_t e = hipSuccess;
-#define DEC_LAUNCH1(T, Z)                                                                                \
-    e = hipFuncSetAttribute((const void *)dec_fused_kernel<T, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                   \
-    if (e != hipSuccess) return (int)e;                                                                  \
-    hipLaunchKernelGGL((dec_fused_kernel<T, Z>), dim3(patches), dim3(DEC_NW * 64), lds, s, a)
-#define DEC_LAUNCH(T)                                                                                    \
-    if (ztab) { DEC_LAUNCH1(T, true); } else { DEC_LAUNCH1(T, false); }
-    switch (k / 16) {
+    if (zg) {
+        e = hipMallocAsync((void **)&a.zg, (size_t)patches * a.n * DEC_ZS * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(dec_ztab_kernel<F16>, dim3((a.n + 63) / 64, patches), dim3(256), 0, s, a);
+    }
+    const size_t lds = zg ? DEC_LDS_TILE_BYTES : with_z;
+    const dim3 grid(patches, zg ? (a.n + DEC_SLICE - 1) / DEC_SLICE : 1);
+#define DEC_LAUNCH1(T, Z)                                                                                   \
+    e = hipFuncSetAttribute((const void *)dec_fused_kernel<T, F16, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                      \
+    if (e == hipSuccess) hipLaunchKernelGGL((dec_fused_kernel<T, F16, Z>), grid, dim3(DEC_NW * 64), lds, s, a)
+#define DEC_LAUNCH(T)                                                                                       \
+    if (zg) { DEC_LAUNCH1(T, true); } else { DEC_LAUNCH1(T, false); }
+    switch (a.k / 16) {
     case 1: DEC_LAUNCH(1); break;
     case 2: DEC_LAUNCH(2); break;
     case 3: DEC_LAUNCH(3); break;
@@ -288,5 +436,30 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     }
 #undef DEC_LAUNCH1
 #undef DEC_LAUNCH
-    return tpu3_launch_status();
+    int r = e != hipSuccess ? (int)e : tpu3_launch_status();
+    if (zg) {
+        const hipError_t fe = hipFreeAsync(a.zg, s);
+        if (!r) r = (int)fe;
+    }
+    return r;
+}
+
+} // namespace
+
+extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                        const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                        const float *w0, const float *b0, const float *w1, const float *b1,
+                                        const float *w2, const float *b2, float *out, int out_stride, int mfma)
+{
+    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
+    if (mfma != TPU3_MFMA_F32 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
+    if (patches == 0) return TPU3_OK;
+    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return TPU3_EINVAL;
+    if (((uintptr_t)out % 16) != 0 || ((uintptr_t)x % 16) != 0) return TPU3_EINVAL;
+    if (patches > 65535 * 0 + 2147483647 / (n > 0 ? n : 1)) return TPU3_ELIMIT;       // patches * n must fit an int
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    return mfma == TPU3_MFMA_F16 ? dec_launch<true>(s, patches, a) : dec_launch<false>(s, patches, a);
 }

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import operations
+from .. import _lib as L
 
 
 class _SkinnyLinear(torch.autograd.Function):
@@ -105,11 +106,24 @@ class DenseEdgeConv(nn.Module):
         center = x.unsqueeze(2).expand_as(knn_point)
         return torch.cat([center, knn_point - center], dim=-1), idx
 
-    def fused_ok(self, x):
-        """The hand-written MFMA kernel covers the configuration every Level uses."""
-        return (hasattr(operations.BACKEND, "dense_edge_conv") and not torch.is_grad_enabled()
-                and x.is_cuda and x.dtype == torch.float32 and self.in_channels == 24
-                and self.growth_rate == 12 and self.n == 3 and self.k % 16 == 0 and self.k <= 64)
+    # arithmetic of the fused block's matrix instructions: "f32" (default: exact fp32 chains) or "f16"
+    # (fp16 operands, fp32 accumulate -- config C5); set through Net.set_mlp_precision
+    mlp_precision = "f32"
+
+    def fused_reason(self, x):
+        """None when the hand-written MFMA kernel covers this call, else why it does not."""
+        if not hasattr(operations.BACKEND, "dense_edge_conv"):
+            return "stand-in backend"
+        if torch.is_grad_enabled():
+            return "training (autograd formulation)"
+        if not x.is_cuda or x.dtype != torch.float32:
+            return "DenseEdgeConv input is %s on %s" % (x.dtype, x.device.type)
+        if (self.in_channels, self.growth_rate, self.n) != (24, 12, 3):
+            return "DenseEdgeConv(in_channels=%d, growth_rate=%d, n=%d): the fused kernel covers (24, 12, 3)" % (
+                self.in_channels, self.growth_rate, self.n)
+        if self.k % 16 or self.k > 64:
+            return "DenseEdgeConv k=%d: the fused kernel covers k in {16, 32, 48, 64}" % self.k
+        return None
 
     def forward_cl(self, x, idx=None, layout=None, out=None):
         """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k).
@@ -117,7 +131,8 @@ class DenseEdgeConv(nn.Module):
         Level passes a slice of its concatenated feature buffer so that no copy is needed."""
         B, N, C = x.shape
         g, n, k = self.growth_rate, self.n, self.k
-        if idx is None and self.fused_ok(x):
+        why = self.fused_reason(x) if idx is None else "caller-supplied neighbour indices"
+        if why is None:
             # kNN graph + gather + 3 dense layers + max in two launches, no (B,N,k,C) tensors
             x = x.contiguous()
             full_idx = operations.BACKEND.knn_graph(k + 1, x, layout) \
@@ -127,8 +142,14 @@ class DenseEdgeConv(nn.Module):
                                                       want_dist=False, want_grouped=False)
             if out is None:
                 out = x.new_empty((B, N, C + n * g))
-            operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out)
+            operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out,
+                                               mfma=L.MFMA_F16 if self.mlp_precision == "f16" else L.MFMA_F32)
             return out, full_idx[:, :, 1:]
+        if self.mlp_precision != "f32":
+            raise RuntimeError("mlp_precision=%r needs the fused DenseEdgeConv kernel, which does not cover this "
+                               "call: %s" % (self.mlp_precision, why))
+        if not torch.is_grad_enabled():
+            operations.note_generic_path(why)
         edge, idx = self.get_local_graph_cl(x, k, idx, layout)
         if torch.is_grad_enabled():
             # training: autograd-friendly concatenations, exactly the reference's dataflow (:53-61)

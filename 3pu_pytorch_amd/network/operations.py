@@ -19,8 +19,25 @@ from .. import _lib as L
 from .. import sampling
 
 
+import collections
 import os
+import warnings
 _DEBUG_UWS = bool(os.environ.get("TPU3_DEBUG_UWS"))
+
+# Every place where the network leaves a hand-written kernel for the generic PyTorch-ROCm formulation
+# (a shape the fused kernel does not cover: k not a multiple of 16, other channel counts, r > 4 ...)
+# reports here: counted, and warned about once per reason, so that a slow configuration is never
+# silent.  bench.py asserts that the measured configuration produced no such event.
+GENERIC_PATH_EVENTS = collections.Counter()
+
+
+def note_generic_path(reason):
+    if getattr(BACKEND, "name", "") != "hip-gfx950":
+        return                                   # a test stand-in backend is installed
+    if not GENERIC_PATH_EVENTS[reason]:
+        warnings.warn("3pu_pytorch_amd: generic (unfused) PyTorch path taken: " + reason, RuntimeWarning,
+                      stacklevel=3)
+    GENERIC_PATH_EVENTS[reason] += 1
 
 
 class HipBackend(object):
@@ -201,10 +218,11 @@ class HipBackend(object):
         grad = torch.zeros((b, c, n), dtype=grad_out.dtype, device=grad_out.device)
         return sampling.gather_backward(b, c, n, npoint, grad_out, idx, grad)
 
-    def dense_edge_conv(self, x, idx, idx_off, k, mlps, out):
+    def dense_edge_conv(self, x, idx, idx_off, k, mlps, out, mfma=L.MFMA_F32):
         """Fused DenseEdgeConv (inference): x (P,N,24) contiguous, idx (P,N,idx_stride) int64/int32,
         the k neighbours start at column idx_off; mlps = the block's three nn.Conv2d; `out` is a
-        (P,N,>=60) view with unit channel stride whose channels [0,60) receive y."""
+        (P,N,>=60) view with unit channel stride whose channels [0,60) receive y.
+        mfma: L.MFMA_F32 (exact fp32 chains) or L.MFMA_F16 (fp16 operands, fp32 accumulate)."""
         L.require_device(x, "x")
         L.require_dtype(x, torch.float32, "x")
         L.require_device(idx, "idx")
@@ -219,7 +237,7 @@ class HipBackend(object):
             L.check(L.lib().tpu3_dense_edge_conv_f32(
                 L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
                 L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
-                L.ptr(out), out.stride(1)), "tpu3_dense_edge_conv_f32")
+                L.ptr(out), out.stride(1), int(mfma)), "tpu3_dense_edge_conv_f32")
         return out
 
     def interlevel_skip(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2, per_cloud=0):

@@ -149,6 +149,18 @@ class Net(torch.nn.Module):
     def reset_small_cloud_events(self):
         self._small_cloud_counts = []
 
+    def set_mlp_precision(self, precision):
+        """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):
+        "f32" -- fp32 operands (default; what the parity tests pin), or "f16" -- operands rounded to fp16,
+        fp32 accumulate (BASELINE config C5: "fp16 feature MLPs on MFMA").  FPS, every kNN and the Chamfer
+        distance stay fp32 either way.  Explicit: a layer shape the f16 kernels do not cover raises."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("mlp precision must be 'f32' or 'f16'")
+        for m in self.modules():
+            if isinstance(m, (layers.DenseEdgeConv, Level)):
+                m.mlp_precision = precision
+        return self
+
     def _forward_eval(self, xyz, ratio):
         B, _, num_point = xyz.size()
         dev = xyz.device
@@ -367,6 +379,9 @@ class Level(torch.nn.Module):
                 pts_of = None
             fused = (not torch.is_grad_enabled() and hasattr(operations.BACKEND, "interlevel_skip")
                      and x.is_cuda and x.is_contiguous() and self.fm_knn <= 8 and x.size(-1) <= 320)
+            if not fused and not torch.is_grad_enabled():
+                operations.note_generic_path("inter-level skip with fm_knn=%d, %d channels (fused kernel: "
+                                             "fm_knn <= 8, <= 320 channels)" % (self.fm_knn, x.size(-1)))
             with torch.no_grad():
                 knn_idx, _, knn_points = operations.knn_query(
                     self.fm_knn, xyz.detach(), prev_xyz.detach(), unique=True, layout=layout,
@@ -412,6 +427,9 @@ class Level(torch.nn.Module):
                                       fc1.conv.bias, flat(fc2), fc2.conv.bias,
                                       xyz_normalized.reshape(B * N, 3))
                 return out.view(B, N * ratio, 3), point_features
+            operations.note_generic_path("regressor tail with step ratio %d / widths %s (fused kernel: ratio <= 4, "
+                                         "128 -> 128 -> 64 -> 3)" % (ratio, (a.size(-1), up2.conv.out_channels,
+                                                                            fc1.conv.out_channels, fc2.conv.out_channels)))
             x = torch.relu_(a.unsqueeze(2) + c.view(1, 1, ratio, -1)).reshape(B, N * ratio, -1)
         else:
             code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)

@@ -37,6 +37,11 @@ extern "C" {
 
 typedef void *tpu3_stream_t; /* hipStream_t */
 
+/* arithmetic of the matrix-core (MFMA) kernels of the per-patch MLP stacks: an explicit argument of
+ * every such entry point, never chosen silently */
+#define TPU3_MFMA_F32 0    /* fp32 inputs, fp32 accumulate (v_mfma_f32_16x16x4_f32): the default path   */
+#define TPU3_MFMA_F16 1    /* inputs rounded to fp16, fp32 accumulate (v_mfma_f32_16x16x{16,32}_f16)    */
+
 /* Library identification: "3pu-hip <version> gfx950". */
 const char *tpu3_version(void);
 
@@ -209,11 +214,16 @@ int tpu3_knn_unique_compact_i32(tpu3_stream_t stream, int bp, int n, const int32
  *   out (patches, n, out_stride) f32: channels [0,60) of every row are written (out_stride >= 60,
  *       multiple of 4, base 16-byte aligned) -- lets the caller place y inside the level's
  *       concatenated feature buffer without a copy.  k must be a multiple of 16, at most 64.
- * fp32 MFMA (exact fp32 fma chains); the summation order differs from a BLAS GEMM. */
+ * Any n: the per-point table the kernel gathers from lives in LDS up to ~2700 points per patch and
+ * in global memory beyond (the patch is then split over several workgroups).
+ * mfma = TPU3_MFMA_F32: fp32 MFMA (exact fp32 fma chains; the summation order differs from a BLAS GEMM).
+ * mfma = TPU3_MFMA_F16: weights and the activations entering a matrix instruction rounded to fp16, fp32
+ * accumulate, everything else (bias, ReLU, max, tensors in memory) fp32 -- config C5's "fp16 feature MLPs
+ * on MFMA"; results agree with the fp32 flavour to ~1e-2 relative (tests state the bound). */
 int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
                              const void *idx, int idx_elem_size, int idx_stride, int idx_off,
                              const float *w0, const float *b0, const float *w1, const float *b1,
-                             const float *w2, const float *b2, float *out, int out_stride);
+                             const float *w2, const float *b2, float *out, int out_stride, int mfma);
 
 /* Fused inter-level skip connection of a Level, inference (network/upsampler.py:317-347):
  *   w_k = exp(-|p_i - q_k|^2 / (h_s/2)) * exp(-|x_i - f_k|^2 / (h_f/2)),  h = mean_i min_k (dist),

@@ -487,30 +487,77 @@ def test_config_c5_shapes_large_patches(orc, dev):
     assert ((fused - plain.detach()).abs().amax(dim=1) <= 1e-5).float().mean() > 0.99
 
 
-@pytest.mark.parametrize("P,N,k", [(3, 312, 32), (5, 100, 16), (2, 312, 48), (1, 17, 16), (2, 1024, 32), (1, 200, 64)])
-def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
-    """The MFMA kernel against the plain torch formulation of the same block (fp32 reference of the
-    same op, same neighbour indices): 1e-5 absolute on O(1) activations.  Also checks writing into a
-    channel slice of a wider buffer (how the Level uses it)."""
-    layers = pkg("network.layers")
-    torch.manual_seed(P * 100 + N)
+def _dec_block(layers, dev, k, seed):
+    torch.manual_seed(seed)
     blk = layers.DenseEdgeConv(24, growth_rate=12, n=3, k=k).to(dev)
     for mconv in blk.mlps:
         torch.nn.init.xavier_uniform_(mconv.weight)
         torch.nn.init.uniform_(mconv.bias, -0.5, 0.5)
+    return blk
+
+
+# 312 / 1024: the path's patch sizes (C2 / C5); 2048: `--num_point 2048` of the CLI help (table still in LDS);
+# 2731 / 5000: beyond the LDS table -- global z table, patch split over several workgroups ("pWhole" mode)
+@pytest.mark.parametrize("P,N,k", [(3, 312, 32), (5, 100, 16), (2, 312, 48), (1, 17, 16), (2, 1024, 32), (1, 200, 64),
+                                   (2, 2048, 32), (1, 2731, 16), (2, 5000, 32)])
+def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
+    """The MFMA kernel against the plain torch formulation of the same block (fp32 reference of the
+    same op, same neighbour indices): 1e-5 absolute on O(1) activations.  Also checks writing into a
+    channel slice of a wider buffer (how the Level uses it)."""
+    layers, ops = pkg("network.layers"), pkg("network.operations")
+    blk = _dec_block(layers, dev, k, P * 100 + N)
     x = torch.randn(P, N, 24, device=dev)
     with torch.no_grad():
-        assert blk.fused_ok(x)
+        assert blk.fused_reason(x) is None
         wide = torch.full((P, N, 84), 7.0, device=dev)
         y_f, idx_f = blk.forward_cl(x, out=wide[..., 12:72])      # 16-byte aligned channel slice
         assert y_f.data_ptr() == wide[..., 12:72].data_ptr()
         assert (wide[..., :12] == 7.0).all() and (wide[..., 72:] == 7.0).all()
-        monkeypatch.setattr(layers.DenseEdgeConv, "fused_ok", lambda self, t: False)
-        y_u, idx_u = blk.forward_cl(x)
-    # the fused path returns the neighbour SET (index order), the plain path the sorted list
-    assert torch.equal(idx_f.long().sort(-1)[0], idx_u.sort(-1)[0])
+        # the plain torch formulation on the SAME neighbour rows (a caller-supplied idx takes the generic path)
+        y_u, idx_u = blk.forward_cl(x, idx=idx_f.long())
+    assert torch.equal(idx_f.long(), idx_u)
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
     assert torch.equal(y_f[..., 36:], x)                      # the x_i pass-through channels
+    # and the neighbour SET is the exact kNN's (the fused path returns index order, the kNN sorted by distance)
+    if N <= 2048:
+        idx_k, _, _ = ops.knn_query(k + 1, x, x, unique=True, want_dist=False, want_grouped=False)
+        assert torch.equal(idx_f.long().sort(-1)[0], idx_k[:, :, 1:].sort(-1)[0])
+
+
+@pytest.mark.parametrize("P,N,k", [(4, 312, 32), (3, 1024, 32), (1, 3000, 16)])
+def test_dense_edge_conv_fp16_mfma_close_to_fp32(dev, P, N, k):
+    """mlp_precision = "f16" (config C5: fp16 operands on the matrix cores, fp32 accumulate) against the
+    fp32 flavour on the same neighbour rows.  Stated bound: operands carry 2^-11 relative rounding, three
+    layers deep on O(1) activations -> |diff| <= 2e-2 everywhere, <= 4e-3 on average; the pass-through
+    channels are bit-identical.  No silent fallback: a shape the fused kernel does not cover raises."""
+    layers = pkg("network.layers")
+    blk = _dec_block(layers, dev, k, 7 * N + k)
+    x = torch.randn(P, N, 24, device=dev)
+    with torch.no_grad():
+        y32, idx = blk.forward_cl(x)
+        blk.mlp_precision = "f16"
+        y16, idx16 = blk.forward_cl(x)
+        assert torch.equal(idx, idx16)                            # the kNN graph stays fp32
+        diff = (y16 - y32).abs()
+        assert float(diff.max()) <= 2e-2 and float(diff.mean()) <= 4e-3, (float(diff.max()), float(diff.mean()))
+        assert float(diff[..., :36].max()) > 0                    # it really is another arithmetic
+        assert torch.equal(y16[..., 36:], x)
+        odd = layers.DenseEdgeConv(24, growth_rate=12, n=3, k=20).to(dev)
+        odd.mlp_precision = "f16"
+        with pytest.raises(RuntimeError, match="does not cover"):
+            odd.forward_cl(x)
+
+
+def test_generic_path_is_reported_not_silent(dev):
+    """A DenseEdgeConv shape outside the fused kernel (k = 20) runs through the generic PyTorch
+    formulation -- with a RuntimeWarning and a counted event, never silently."""
+    layers, ops = pkg("network.layers"), pkg("network.operations")
+    blk = _dec_block(layers, dev, 20, 5)
+    x = torch.randn(2, 100, 24, device=dev)
+    ops.GENERIC_PATH_EVENTS.clear()
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match="generic"):
+        y, idx = blk.forward_cl(x)
+    assert tuple(y.shape) == (2, 100, 60) and sum(ops.GENERIC_PATH_EVENTS.values()) == 1
 
 
 def test_interlevel_skip_fused_matches_unfused(dev, monkeypatch):
