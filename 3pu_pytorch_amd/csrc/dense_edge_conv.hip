@@ -232,39 +232,63 @@ struct DecW16 {
     }
 };
 
-// x row fragments of the lane's point, straight from global memory (read once per point)
-__device__ __forceinline__ void dec_load_x6(const float *xrow, int g, float *x6)
-{
-    const f32x2 *p = (const f32x2 *)(xrow + 6 * g);           // 24 g bytes: 8-byte aligned
-    const f32x2 a = p[0], b = p[1], c = p[2];
-    x6[0] = a[0]; x6[1] = a[1]; x6[2] = b[0]; x6[3] = b[1]; x6[4] = c[0]; x6[5] = c[1];
-}
-__device__ __forceinline__ f16x8 dec_load_x8(const float *xrow, int g)
-{
-    const int gg = g < 3 ? g : 0;
-    const f32x4 a = *(const f32x4 *)(xrow + 8 * gg), b = *(const f32x4 *)(xrow + 8 * gg + 4);
-    f16x8 r;
+// The lane's fragment of its point's input row, straight from global memory (read once per point):
+// fp32 flavour channels 6g .. 6g+5 (all four lane groups), fp16 flavour channels 8g .. 8g+7 (g < 3).
+// Kept in registers across the neighbour loop: it is also the x_i pass-through part of the output row.
+template <bool F16>
+struct DecX {
+    static constexpr int NV = F16 ? 8 : 6;
+    float v[NV];
+    __device__ __forceinline__ void load(const float *xrow, int g)
+    {
+        if constexpr (F16) {
+            const int gg = g < 3 ? g : 0;
+            const f32x4 a = *(const f32x4 *)(xrow + 8 * gg), b = *(const f32x4 *)(xrow + 8 * gg + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[j] = g < 3 ? (_Float16)a[j] : (_Float16)0.f;
-        r[4 + j] = g < 3 ? (_Float16)b[j] : (_Float16)0.f;
+            for (int j = 0; j < 4; ++j) {
+                v[j] = a[j];
+                v[4 + j] = b[j];
+            }
+        } else {
+            const f32x2 *p = (const f32x2 *)(xrow + 6 * g);           // 24 g bytes: 8-byte aligned
+            const f32x2 a = p[0], b = p[1], c = p[2];
+            v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1];
+        }
     }
-    return r;
-}
+    __device__ __forceinline__ f16x8 half8(int g) const        // F16 only: zeros for the padding lane group
+    {
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            r[j] = g < 3 ? (_Float16)v[j < NV ? j : 0] : (_Float16)0.f;
+        return r;
+    }
+    // into the staged output row (floats [36, 60) of the point's 60)
+    __device__ __forceinline__ void stage(float *row, int g) const
+    {
+        if constexpr (F16) {
+            if (g < 3) {
+                *(f32x4 *)(row + 36 + 8 * g) = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4 *)(row + 36 + 8 * g + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+        } else {
+            f32x2 *p = (f32x2 *)(row + 36 + 6 * g);
+            p[0] = (f32x2){v[0], v[1]}; p[1] = (f32x2){v[2], v[3]}; p[2] = (f32x2){v[4], v[5]};
+        }
+    }
+};
 
 // z_p = W0b x_p for a block of 16 points (columns = points) -> table rows (LDS or global)
 template <bool F16, typename W>
 __device__ __forceinline__ void dec_ztab_block(const W &w, const float *X, int n, int pb, int e, int g, float *zt)
 {
-    const float *xrow = X + (size_t)min(pb + e, n - 1) * DEC_C;
+    DecX<F16> xf;
+    xf.load(X + (size_t)min(pb + e, n - 1) * DEC_C, g);
     f32x4 z;
-    if constexpr (F16) {
-        z = w.ztab(dec_load_x8(xrow, g));
-    } else {
-        float x6[6];
-        dec_load_x6(xrow, g, x6);
-        z = w.ztab(x6);
-    }
+    if constexpr (F16)
+        z = w.ztab(xf.half8(g));
+    else
+        z = w.ztab(xf.v);
     if (g < 3 && pb + e < n)
         *(f32x4 *)(zt + (size_t)(pb + e) * DEC_ZS + 4 * g) = z;
 }
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *tb = lds;                                   // DEC_NW * 16 * DEC_TS
-    float *zl = lds + DEC_NW * 16 * DEC_TS;            // n * DEC_ZS (+ 4 floats of slack), !ZG only
+    float *zl = lds + DEC_NW * 16 * DEC_TS + 48;       // n * DEC_ZS (+ 4 floats of slack), !ZG only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 15, g = lane >> 4;
     const int n = a.n;
@@ -299,15 +323,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 
     std::conditional_t<F16, DecW16, DecW32> w;
     w.load(a, e, g);
-    // bias of the 4 channels this lane's accumulator rows hold (rows 4g..4g+3)
-    f32x4 bias0, bias1, bias2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = 4 * g + r;
-        bias0[r] = c < DEC_G ? a.b0[c] : 0.f;
-        bias1[r] = c < DEC_G ? a.b1[c] : 0.f;
-        bias2[r] = c < DEC_G ? a.b2[c] : 0.f;
-    }
+    // bias of the 4 channels this lane's accumulator rows hold (rows 4g..4g+3): re-read from LDS per block
+    // of 16 points rather than held in 12 registers, which would cost a wave of occupancy
+    float *bl = lds + DEC_NW * 16 * DEC_TS;            // [3][16]: b0 | b1 | b2, rows 12..15 zero
+    if (tid < 48)
+        bl[tid] = (tid & 15) < DEC_G ? (tid < 16 ? a.b0 : tid < 32 ? a.b1 : a.b2)[tid & 15] : 0.f;
 
     const float *ztab;
     int p_lo = 0, p_hi = n;
@@ -315,6 +335,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
         ztab = a.zg + (size_t)blockIdx.x * n * DEC_ZS;
         p_lo = blockIdx.y * DEC_SLICE;
         p_hi = min(n, p_lo + DEC_SLICE);
+        __syncthreads();
     } else {
         // ---- z_p = W0b x_p for every point of the patch, once, into LDS ------------------------------
         for (int pb = wave * 16; pb < n; pb += DEC_NW * 16)
@@ -331,8 +352,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
     constexpr int K = 16 * TILES;
     constexpr int U = 2;                        // neighbour slots in flight (independent MFMA chains)
     int *IT = (int *)(tb + wave * 16 * DEC_TS);  // per-wave tile [slot][16 points]: byte offset of the neighbour's z row
-    float *ST = (float *)IT;                     // ... re-used as the output staging area [16 points][36]
+    float *ST = (float *)IT;                     // ... re-used as the output staging area [16 points][60]
     const char *gbase = (const char *)(ztab + zoff);
+    DecX<F16> xf, xnext;
+    if (p_lo + wave * 16 < p_hi)
+        xnext.load(X + (size_t)min(p_lo + wave * 16 + e, n - 1) * DEC_C, g);
     for (int pb = p_lo + wave * 16; pb < p_hi; pb += DEC_NW * 16) {
         // neighbour indices of the 16 points, clamped and scaled once, read coalesced (k contiguous per point)
         for (int t = lane; t < 16 * K; t += 64) {
@@ -344,17 +368,16 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
             IT[sl * 16 + pt] = j * (int)(DEC_ZS * sizeof(float));
         }
         // centre terms of the lane's point (+ bias): the initial values of the three accumulators
-        f32x4 c0 = bias0, c1 = bias1, c2 = bias2;
-        {
-            const float *xrow = X + (size_t)min(pb + e, n - 1) * DEC_C;
-            if constexpr (F16) {
-                w.centre(dec_load_x8(xrow, g), c0, c1, c2);
-            } else {
-                float x6[6];
-                dec_load_x6(xrow, g, x6);
-                w.centre(x6, c0, c1, c2);
-            }
-        }
+        xf = xnext;
+        f32x4 c0 = *(const f32x4 *)(bl + 4 * g), c1 = *(const f32x4 *)(bl + 16 + 4 * g),
+              c2 = *(const f32x4 *)(bl + 32 + 4 * g);
+        if constexpr (F16)
+            w.centre(xf.half8(g), c0, c1, c2);
+        else
+            w.centre(xf.v, c0, c1, c2);
+        // the next block's row fragment arrives while this block's neighbours are processed
+        if (pb + DEC_NW * 16 < p_hi)
+            xnext.load(X + (size_t)min(pb + DEC_NW * 16 + e, n - 1) * DEC_C, g);
         __builtin_amdgcn_wave_barrier();
         const float ninf = -__builtin_inff();
         f32x4 m0 = {ninf, ninf, ninf, ninf}, m1 = m0, m2 = m0;
@@ -382,32 +405,32 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
                     m2[r] = fmaxf(m2[r], h2[u][r]);
                 }
         }
-        // ---- write-out: the 60-float row [max h2 | max h1 | max h0 | x_i] of every point leaves as whole
-        // 16-byte pieces of ONE contiguous 240-byte run per point (staged through the wave's tile, the x_i part
-        // straight from the input row) instead of three scattered 16-byte stores per lane
+        // ---- write-out: the 60-float row [max h2 | max h1 | max h0 | x_i] of every point is assembled in the
+        // wave's tile and leaves as the 15 aligned 16-byte pieces of ONE contiguous 240-byte run per point
+        // (three scattered 16-byte stores per lane + a separate x_i copy cost 4x the payload in fabric writes)
         __builtin_amdgcn_wave_barrier();
-        if (g < 3) {
-            float *st = ST + e * 36 + 4 * g;
-            *(f32x4 *)(st) = m2;                  // [0,12)  max h2
-            *(f32x4 *)(st + DEC_G) = m1;          // [12,24) max h1
-            *(f32x4 *)(st + 2 * DEC_G) = m0;      // [24,36) max h0
+        {
+            float *st = ST + e * 60;
+            if (g < 3) {
+                *(f32x4 *)(st + 4 * g) = m2;                  // [0,12)  max h2
+                *(f32x4 *)(st + DEC_G + 4 * g) = m1;          // [12,24) max h1
+                *(f32x4 *)(st + 2 * DEC_G + 4 * g) = m0;      // [24,36) max h0
+            }
+            xf.stage(st, g);                                  // [36,60) x_i
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 1      // (unrolled, the four row pieces in flight cost 33 VGPRs and a wave of occupancy)
+#pragma unroll 2      // (fully unrolled the four pieces in flight cost a wave of occupancy: 129 VGPRs)
         for (int t0 = 0; t0 < 16 * 15; t0 += 64) {
             const int t = t0 + lane;
             const int pt = t / 15, q4 = t - pt * 15;
-            if (t < 16 * 15 && pb + pt < n) {
-                const f32x4 v = q4 < 9 ? *(const f32x4 *)(ST + pt * 36 + 4 * q4)
-                                       : *(const f32x4 *)(X + (size_t)(pb + pt) * DEC_C + 4 * (q4 - 9));
-                *(f32x4 *)(O + (size_t)(pb + pt) * a.out_stride + 4 * q4) = v;
-            }
+            if (t < 16 * 15 && pb + pt < n)
+                *(f32x4 *)(O + (size_t)(pb + pt) * a.out_stride + 4 * q4) = *(const f32x4 *)(ST + pt * 60 + 4 * q4);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-constexpr size_t DEC_LDS_TILE_BYTES = (size_t)DEC_NW * 16 * DEC_TS * sizeof(float);
+constexpr size_t DEC_LDS_TILE_BYTES = ((size_t)DEC_NW * 16 * DEC_TS + 48) * sizeof(float);    // tiles + bias table
 
 template <bool F16>
 int dec_launch(hipStream_t s, int patches, DecArgs &a)
