@@ -52,7 +52,7 @@ struct FbArgs {
     int32_t *idx;         // (m)
     float4 *sp;           // (npad) Morton order: x, y, z, running distance
     uint32_t *skey;       // (npad) tie key of the original index (0xFFFFFFFF = padding)
-    uint32_t *ib;         // (8, nbpad) initial bucket table: max, key, x, y, z, box0, box1, box2
+    uint32_t *ib;         // (9, nbpad) initial bucket table: max, key, x, y, z, box0, box1, box2, runner-up
     float *bbox;          // (8)
     size_t per_elem;
     size_t sort_stride;
@@ -188,6 +188,14 @@ struct FbCand {
     uint32_t key;
 };
 
+// Second-largest running distance of a bucket, given every lane's best `c` and lane-local runner-up
+// `second` (-2 when the lane holds a single point) and the winning lane: a wave max over the runners-up,
+// the winner contributing its second instead of its best.  Exact (equal to the maximum when it is tied).
+__device__ __forceinline__ int fb_runner_up(float best, float second, bool is_winner)
+{
+    return tpu3_wave_max_i32_fast(__float_as_int(is_winner ? second : best));
+}
+
 // The re-scan of a bucket is split into load / apply / store so that a caller can put the loads of
 // two buckets in flight together and issue the stores LAST: on gfx950 loads and stores share vmcnt
 // but complete out of order with each other, so a value loaded before a store can only be waited
@@ -229,6 +237,41 @@ __device__ __forceinline__ FbCand fb_apply(FbBucket<PPL> &b, float qx, float qy,
     return c;
 }
 
+// The same for SEVERAL samples at once: lane i of (px, py, pz) holds sample i, `pmask` (wave-uniform)
+// selects the samples to fold in.  Also returns the lane-local runner-up.
+template <int PPL>
+__device__ __forceinline__ FbCand fm_apply(FbBucket<PPL> &b, uint32_t pmask, float px, float py, float pz,
+                                           float &second)
+{
+    float t[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p)
+        t[p] = b.v[p].w;
+    while (pmask) {
+        const int i = __builtin_ctz(pmask);
+        pmask &= pmask - 1;
+        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), i));
+        const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), i));
+        const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), i));
+#pragma unroll
+        for (int p = 0; p < PPL; ++p)
+            t[p] = fminf(tpu3_sqdist3(b.v[p].x - qx, b.v[p].y - qy, b.v[p].z - qz), t[p]);
+    }
+    FbCand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
+    second = -2.0f;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        b.nt[p] = t[p];
+        if (t[p] > c.t || (t[p] == c.t && b.key[p] < c.key)) {
+            second = c.t;
+            c.t = t[p]; c.key = b.key[p]; c.x = b.v[p].x; c.y = b.v[p].y; c.z = b.v[p].z;
+        } else {
+            second = fmaxf(second, t[p]);
+        }
+    }
+    return c;
+}
+
 template <int PPL>
 __device__ __forceinline__ void fb_store(const FbBucket<PPL> &b, float4 *__restrict__ sp, int beta, int lane)
 {
@@ -256,14 +299,17 @@ __global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a0)
             ib[0 * S + beta] = 0x80000000u; ib[1 * S + beta] = 0xFFFFFFFFu;
             ib[2 * S + beta] = 0; ib[3 * S + beta] = 0; ib[4 * S + beta] = 0;
             ib[5 * S + beta] = pinf; ib[6 * S + beta] = pinf; ib[7 * S + beta] = pinf;
+            ib[8 * S + beta] = 0x80000000u;
         }
         return;
     }
     FbBucket<PPL> bk;
     fb_load<PPL>(bk, a.sp, a.skey, beta, lane);
-    const FbCand c = fb_apply<PPL>(bk, 0.f, 0.f, 0.f, false);
+    float second;
+    const FbCand c = fm_apply<PPL>(bk, 0u, 0.f, 0.f, 0.f, second);
     int wl;
     const int wmax = tpu3_wave_argmax(__float_as_int(c.t), c.key, wl);
+    const int runner = fb_runner_up(c.t, second, lane == wl);
     float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
@@ -284,6 +330,7 @@ __global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a0)
         ib[4 * S + beta] = __float_as_uint(c.z);
         ib[5 * S + beta] = h[0] | (h[1] << 16); ib[6 * S + beta] = h[2] | (h[3] << 16);
         ib[7 * S + beta] = h[4] | (h[5] << 16);
+        ib[8 * S + beta] = (uint32_t)runner;
     }
 }
 
@@ -562,6 +609,485 @@ __global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Several samples per round, exactly.
+//
+// The loop above spends a full round (prune -> re-scan -> refresh -> arg-max -> barrier -> broadcast,
+// ~2.8 us of dependent latency) per sample.  Most consecutive samples do not interact, though: late in
+// the sampling the leading candidates are scattered over the whole cloud, far outside each other's
+// update balls.  With ONE extra number per cell -- an upper bound R_c on the SECOND largest running
+// distance inside cell c (cells = groups of 16 buckets) -- a whole prefix of the sampling order can
+// be read off the group table at once:
+//
+//   let R* = max_c R_c.  Sort the cells with M_c > R* by (M_c descending, tie key): c_1, c_2, ...
+//   The next samples are the best points p_1, p_2, ..., p_J of c_1, c_2, ... for the longest prefix in which
+//   no p_j lies inside the update ball of an earlier member (|p_i - p_j|^2 >= M_j for i < j).
+//
+// Proof sketch: running distances only decrease, so a stale R_c stays an upper bound.  After c_1..c_{j-1}
+// have been sampled and applied, every point other than the members' own best points has a distance
+// <= max(M of an unsampled cell, R of a sampled cell) -- and R_c <= R* < M_j, M of the other unsampled
+// cells <= M_j by the sort; p_j itself is out of reach of the earlier members, so it still holds M_j (the
+// other points of its cell can only have fallen) and is the exact arg-max (ties: equal M are ordered by the reference's tie key, and strictness of M_j > R* keeps runner-ups
+// out).  J >= 1 always: c_1 is the plain arg-max.  If no cell beats R* (ties at the top) the round falls
+// back to the single arg-max sample.
+//
+// All J updates are applied in one pass: a touched bucket is re-scanned once with every sample that
+// reaches it folded in (min is commutative), and bucket / group entries now also carry their runner-up.
+// R* may be one round old (bounds only fall), so candidates, the waves' bests and the new R* travel through
+// ONE barrier per round; every wave enters at most FM_WCAP candidates, the best one it leaves out caps what
+// may be accepted.  The re-scans of a round are listed first and then run several buckets at a time with
+// all their loads in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int FM_WCAP = 8;          // candidates a wave may enter per round
+constexpr int FM_CAP = 32;          // = 4 waves x FM_WCAP: a 32-bit sample mask per bucket
+constexpr int FM_EW = 8;            // words per candidate entry (5 used)
+
+struct FmHeader {                   // one per wave and buffer
+    int best;                       // best group entry of the wave (distance bits) ...
+    uint32_t key;
+    float x, y, z;
+    int rmax;                       // largest runner-up bound among the wave's groups
+    int count;                      // candidates entered (<= FM_WCAP)
+    int drop;                       // best candidate NOT entered (INT_MIN if none)
+};
+
+struct FmShared {
+    FmHeader h[2][4];
+    uint32_t stat[8];               // PROF: rounds, samples, capped rounds, tie rounds, ...
+};
+
+constexpr size_t fm_lds_bytes(int nbpad, int nw)
+{
+    // 9 words per bucket; 12 per group-table entry, of which the 6 box words are setup only and are
+    // re-used for the candidate lists (2 x FM_CAP x FM_EW words) and the waves' re-scan work lists
+    // (nw x 64 x 2 words); the shared block
+    return (size_t)nbpad * 36 + (size_t)nw * 64 * 12 * 4 + sizeof(FmShared) + 64;
+}
+
+template <int NW, int PPL, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
+{
+    static_assert(NW == 4, "candidate slots are laid out for four waves");
+    constexpr int W = NW * 64;
+    constexpr int GT = W;                           // group-table entries (owner order), one per lane
+    static_assert(2 * FM_CAP * FM_EW + NW * 64 * 2 <= 6 * GT, "lists must fit the setup-only box area");
+    constexpr int CH = PPL <= 2 ? 4 : 2;            // buckets in flight per re-scan step (8: register arrays spill)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    const int nbpad = a.nbpad, ng = a.ng, lb = a.lb;
+    if (a.n <= 0 || a.m <= 0)
+        return;
+    // Group g = the 16 CONSECUTIVE Morton buckets [16 g, 16 g + 16) (a compact box); it belongs to wave g % NW,
+    // owner lane g / NW.  With several samples per round, scattered over the cloud, the waves' re-scan loads
+    // balance statistically, and a sample touches one or two groups in total instead of one per wave.
+    int *t_max = (int *)smem;
+    uint32_t *t_key = (uint32_t *)(t_max + nbpad);
+    float *t_x = (float *)(t_key + nbpad);
+    float *t_y = t_x + nbpad;
+    float *t_z = t_y + nbpad;
+    uint32_t *t_b0 = (uint32_t *)(t_z + nbpad);     // fp16 boxes: lo.x|lo.y, lo.z|hi.x, hi.y|hi.z
+    uint32_t *t_b1 = t_b0 + nbpad;
+    uint32_t *t_b2 = t_b1 + nbpad;
+    int *t_r = (int *)(t_b2 + nbpad);               // runner-up of the bucket
+    int *g_max = t_r + nbpad;
+    uint32_t *g_key = (uint32_t *)(g_max + GT);
+    float *g_x = (float *)(g_key + GT);
+    float *g_y = g_x + GT;
+    float *g_z = g_y + GT;
+    int *g_r = (int *)(g_z + GT);                   // runner-up bound of the group
+    float *g_box = (float *)(g_r + GT);             // 6 x GT, setup only ...
+    uint32_t *cand = (uint32_t *)g_box;             // ... then the candidate lists [2][FM_CAP][FM_EW]
+    uint32_t *work = cand + 2 * FM_CAP * FM_EW;     // ... and the re-scan work lists [NW][64][2]
+    FmShared &sh = *(FmShared *)(g_box + 6 * GT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane >> 4, col = lane & 15;
+    float4 *__restrict__ sp = a.sp;
+    const uint32_t *__restrict__ skey = a.skey;
+    uint32_t *wl = work + wave * 128;
+
+    // group g <-> wave g % NW, owner lane g / NW
+    auto refresh_groups = [&](int slot, bool with_box) {
+        const bool valid = slot >= 0 && slot * NW + wave < ng;
+        const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+        const int bits = valid ? t_max[beta] : (int)0x80000000;
+        const uint32_t key = valid ? t_key[beta] : 0xFFFFFFFFu;
+        const int rmax = tpu3_row_max_i32_fast(bits);
+        unsigned long long tie = __ballot(valid && bits == rmax);
+        const unsigned long long rows = __ballot(valid && col == 0);
+        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
+            const uint32_t k = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
+            tie = __ballot(valid && bits == rmax && key == k);
+        }
+        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
+        const bool winner = valid && ((tie >> lane) & 1ull) && (tie & below) == 0;
+        // runner-up bound of the group: the other children's maxima and the winning child's own runner-up
+        const int rr = tpu3_row_max_i32_fast(valid ? (winner ? t_r[beta] : bits) : (int)0x80000000);
+        if (winner) {
+            const int e = wave * 64 + slot;
+            g_max[e] = rmax; g_key[e] = key; g_r[e] = rr;
+            g_x[e] = t_x[beta]; g_y[e] = t_y[beta]; g_z[e] = t_z[beta];
+        }
+        if (with_box) {     // setup: group AABB = union of the children's (outward-rounded) boxes
+            const uint32_t w0 = valid ? t_b0[beta] : 0, w1 = valid ? t_b1[beta] : 0, w2 = valid ? t_b2[beta] : 0;
+            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
+                          fb_half_hi(w2)};
+            for (int c3 = 0; c3 < 6; ++c3) {
+                if (!valid)
+                    v[c3] = -__builtin_inff();
+                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
+                if (valid && col == 0)
+                    g_box[c3 * GT + wave * 64 + slot] = c3 < 3 ? -m : m;
+            }
+        }
+    };
+
+    // ---- setup ------------------------------------------------------------------------------------
+    for (int i = tid; i < nbpad; i += W) {
+        const int ti = i;                               // table slot = bucket id
+        t_max[ti] = (int)a.ib[0 * nbpad + i];
+        t_key[ti] = a.ib[1 * nbpad + i];
+        t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
+        t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
+        t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
+        t_b0[ti] = a.ib[5 * nbpad + i];
+        t_b1[ti] = a.ib[6 * nbpad + i];
+        t_b2[ti] = a.ib[7 * nbpad + i];
+        t_r[ti] = (int)a.ib[8 * nbpad + i];
+    }
+    for (int i = tid; i < GT; i += W) {
+        g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu; g_r[i] = (int)0x80000000;
+        g_x[i] = g_y[i] = g_z[i] = 0.f;
+        for (int c3 = 0; c3 < 6; ++c3)
+            g_box[c3 * GT + i] = __builtin_inff();          // lo = hi = +inf: infinitely far away
+    }
+    if (tid < 8)
+        sh.stat[tid] = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < 64; s0 += 4)
+        if ((s0 * NW + wave) < ng)
+            refresh_groups(s0 + row, true);
+    __syncthreads();
+    float gbox[6];
+    for (int c3 = 0; c3 < 6; ++c3)
+        gbox[c3] = g_box[c3 * GT + tid];
+    int gmax = g_max[tid];
+    __syncthreads();                                // the box area becomes the candidate / work lists
+
+    if (tid == 0)
+        a.idx[0] = 0;
+    if (a.m <= 1)
+        return;                                     // the reference's loop body never runs: temp untouched
+
+    // current samples: lane i < J holds sample i (coordinates); start with point 0
+    float px = a.xyz[0], py = a.xyz[1], pz = a.xyz[2];
+    int J = 1;
+    int r = 1;                                      // samples emitted so far
+    int rstar = 0x7FFFFFFF;                         // bound on every group's runner-up (from the previous round)
+
+    auto rl = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+
+    // ---- re-scan the first `nwork` buckets of the wave's work list, CH at a time with all their loads in
+    // flight together (a bucket's entry = table slot, set of samples that reach it) -------------------
+    // ---- re-scan the first `nwork` buckets of the wave's work list (entry = bucket, set of samples that
+    // reach it), CH at a time with all their loads in flight together.  (Fetching the next CH while the current
+    // ones are worked on was tried through a two-buffer struct: the compiler put it in scratch, 200 vs 103 ms.)
+    auto flush = [&](int nwork) {
+        for (int w0 = 0; w0 < nwork; w0 += CH) {
+            FbBucket<PPL> bk[CH];
+            int tb[CH];
+            uint32_t pmv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int e = w0 + u < nwork ? w0 + u : w0;         // a short tail repeats the first (idempotent)
+                tb[u] = __builtin_amdgcn_readfirstlane((int)wl[2 * e]);
+                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl[2 * e + 1]);
+                fb_load<PPL>(bk[u], sp, skey, tb[u], lane);
+            }
+            FbCand c[CH];
+            float sc[CH];
+            int mx[CH], rx[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                c[u] = fm_apply<PPL>(bk[u], pmv[u], px, py, pz, sc[u]);
+                mx[u] = __float_as_int(c[u].t);
+            }
+            if constexpr (CH >= 4) {
+#pragma unroll
+                for (int u = 0; u < CH; u += 4)
+                    tpu3_wave_max_i32_fast_x4(mx[u], mx[u + 1], mx[u + 2], mx[u + 3]);
+            } else {
+                tpu3_wave_max_i32_fast_x2(mx[0], mx[1]);
+            }
+            bool win[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                unsigned long long t0 = __ballot(__float_as_int(c[u].t) == mx[u]);
+                if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
+                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c[u].t) == mx[u] ? c[u].key : 0xFFFFFFFFu);
+                    t0 = __ballot(__float_as_int(c[u].t) == mx[u] && c[u].key == k);
+                }
+                win[u] = lane == (int)__builtin_ctzll(t0);
+                rx[u] = __float_as_int(win[u] ? sc[u] : c[u].t);
+            }
+            if constexpr (CH >= 4) {
+#pragma unroll
+                for (int u = 0; u < CH; u += 4)
+                    tpu3_wave_max_i32_fast_x4(rx[u], rx[u + 1], rx[u + 2], rx[u + 3]);
+            } else {
+                tpu3_wave_max_i32_fast_x2(rx[0], rx[1]);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (win[u] && (u == 0 || w0 + u < nwork)) {
+                    const int b = tb[u];
+                    t_max[b] = mx[u]; t_key[b] = c[u].key; t_x[b] = c[u].x; t_y[b] = c[u].y; t_z[b] = c[u].z;
+                    t_r[b] = rx[u];
+                }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (u == 0 || w0 + u < nwork)
+                    fb_store<PPL>(bk[u], sp, tb[u], lane);     // stores last
+        }
+    };
+
+    // ---- fold the first `nj` current samples into everything they reach -------------------------------
+    auto apply = [&](int nj) {
+        unsigned long long t0 = 0, t1 = 0;
+        if (PROF) t0 = now();
+        // 1. group prune: which samples reach this lane's group?
+        uint32_t gpm = 0;
+        for (int i = 0; i < nj; ++i)
+            gpm |= fb_dbox(rl(px, i), rl(py, i), rl(pz, i), gbox[0], gbox[1], gbox[2], gbox[3], gbox[4], gbox[5]) <
+                           __int_as_float(gmax) ? (1u << i) : 0u;
+        const unsigned long long gmask = __ballot(gpm != 0);
+        if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
+        if (!gmask)
+            return;
+        // 2. children tests, four touched groups (one per DPP row) at a time: every reached bucket goes on
+        //    the wave's work list together with the set of samples that reach it
+        int nwork = 0;
+        for (unsigned long long mask = gmask; mask;) {
+            int slot = -1;
+            uint32_t rem = 0;                       // the samples that reach this row's group
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)gpm, l);
+                    if (row == rr) {
+                        slot = l;
+                        rem = m;
+                    }
+                }
+            const bool valid = slot >= 0;
+            const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
+            const uint32_t w0 = t_b0[beta], w1 = t_b1[beta], w2 = t_b2[beta];
+            const float lx = fb_half_lo(w0), ly = fb_half_hi(w0), lz = fb_half_lo(w1);
+            const float hx = fb_half_hi(w1), hy = fb_half_lo(w2), hz = fb_half_hi(w2);
+            const float tm = __int_as_float(t_max[beta]);
+            uint32_t pm = 0;
+            while (__ballot(rem != 0)) {            // every row walks ITS group's samples (usually one)
+                const int i = rem ? __builtin_ctz(rem) : 0;
+                const float qx = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(px)));
+                const float qy = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(py)));
+                const float qz = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(pz)));
+                pm |= (rem != 0 && fb_dbox(qx, qy, qz, lx, ly, lz, hx, hy, hz) < tm) ? (1u << i) : 0u;
+                rem &= rem - 1;
+            }
+            const unsigned long long bt = __ballot(pm != 0);
+            const int cnt = __builtin_popcountll(bt);
+            if (nwork + cnt > 64) {                 // the list holds 64 entries: work it off first
+                flush(nwork);
+                nwork = 0;
+            }
+            if (PROF) pc[7] += cnt;
+            if (pm != 0) {
+                const int pos = nwork + __builtin_popcountll(bt & ((1ull << lane) - 1ull));
+                wl[2 * pos] = (uint32_t)beta;
+                wl[2 * pos + 1] = pm;
+            }
+            nwork += cnt;
+        }
+        if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
+        // 3. the re-scans
+        flush(nwork);
+        if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
+        // 4. rebuild the touched groups' entries
+        for (unsigned long long mask = gmask; mask;) {
+            int slot = -1;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    if (row == rr)
+                        slot = l;
+                }
+            refresh_groups(slot, false);
+        }
+        if (PROF) { t1 = now(); pc[3] += t1 - t0; }
+    };
+
+    for (int round = 0;; ++round) {
+        apply(J);
+        // ---- select the next samples ---------------------------------------------------------------
+        const int par = round & 1;                  // double-buffered hand-off areas
+        unsigned long long s0 = 0, s1 = 0;
+        if (PROF) s0 = now();
+        gmax = g_max[tid];
+        const uint32_t gk = g_key[tid];
+        const int gr = g_r[tid];
+        uint32_t *cl = cand + par * (FM_CAP * FM_EW);
+        {
+            int wlane;
+            const int wmax = tpu3_wave_argmax(gmax, gk, wlane);
+            const int wr = tpu3_wave_max_i32_fast(gr);
+            // candidates: groups whose best beats every runner-up bound (rstar is one round old: bounds only fall)
+            bool is_cand = gmax > rstar;
+            unsigned long long cm = __ballot(is_cand);
+            int drop = (int)0x80000000;
+            if (__builtin_popcountll(cm) > FM_WCAP) {
+                // keep the wave's FM_WCAP best; the best one left out limits what may be accepted this round
+                int lrank = 0;
+                for (unsigned long long mm = cm; mm;) {
+                    const int i = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const int mi = __builtin_amdgcn_readlane(gmax, i);
+                    const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)gk, i);
+                    lrank += (mi > gmax || (mi == gmax && ki < gk)) ? 1 : 0;
+                }
+                const bool keep = is_cand && lrank < FM_WCAP;
+                drop = tpu3_wave_max_i32_fast(is_cand && !keep ? gmax : (int)0x80000000);
+                is_cand = keep;
+                cm = __ballot(is_cand);
+            }
+            if (is_cand) {
+                const int pos = wave * FM_WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                uint32_t *e = cl + pos * FM_EW;
+                e[0] = (uint32_t)gmax; e[1] = gk;
+                e[2] = __float_as_uint(g_x[tid]); e[3] = __float_as_uint(g_y[tid]); e[4] = __float_as_uint(g_z[tid]);
+            }
+            if (lane == wlane) {
+                FmHeader &h = sh.h[par][wave];
+                h.best = wmax; h.key = gk; h.x = g_x[tid]; h.y = g_y[tid]; h.z = g_z[tid];
+                h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
+            }
+        }
+        if (PROF) { s1 = now(); pc[4] += s1 - s0; s0 = s1; }
+        __syncthreads();                                                    // the round's ONE barrier
+        if (PROF) { s1 = now(); pc[5] += s1 - s0; s0 = s1; }
+        const FmHeader &hh = sh.h[par][lane & (NW - 1)];
+        const int sd = lane < NW ? hh.best : (int)0x80000000;
+        const uint32_t sk = lane < NW ? hh.key : 0xFFFFFFFFu;
+        const int sr = lane < NW ? hh.rmax : (int)0x80000000;
+        const int sdrop = lane < NW ? hh.drop : (int)0x80000000;
+        const float sx = hh.x, sy = hh.y, sz = hh.z;
+        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+        rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+        const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
+        // candidate `lane` of the list: wave lane / FM_WCAP, entry lane % FM_WCAP
+        const int cw = (lane >> 3) & (NW - 1);
+        const bool live = lane < FM_CAP && (lane & (FM_WCAP - 1)) < sh.h[par][cw].count;
+        const unsigned long long lm = __ballot(live);
+        const int total = __builtin_popcountll(lm);
+        const int left = a.m - r;
+        uint32_t okey;                              // tie key of sample `lane` of this round (lanes < J)
+        bool multi = total >= 2;
+        int cM = (int)0x80000000;
+        uint32_t cK = 0xFFFFFFFFu;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        int rank = 0;
+        if (multi) {
+            // every wave ranks the candidate list on its own (no further synchronisation)
+            const uint32_t *e = cl + (lane & (FM_CAP - 1)) * FM_EW;
+            if (live) {
+                cM = (int)e[0]; cK = e[1];
+                cx = __uint_as_float(e[2]); cy = __uint_as_float(e[3]); cz = __uint_as_float(e[4]);
+            }
+            bool tie = false;
+            for (unsigned long long mm = lm; mm;) {
+                const int i = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const int mi = __builtin_amdgcn_readlane(cM, i);
+                rank += mi > cM ? 1 : 0;
+                tie |= (mi == cM && i != lane);
+            }
+            // equal maxima among candidates (rare): order them by the reference's tie key
+            if (__ballot(live && tie)) {
+                rank = 0;
+                for (unsigned long long mm = lm; mm;) {
+                    const int i = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const int mi = __builtin_amdgcn_readlane(cM, i);
+                    const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
+                    rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
+                }
+                if (PROF && tid == 0) sh.stat[3] += 1;
+            }
+        }
+        if (!multi) {
+            // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
+            unsigned long long who = __ballot(lane < NW && sd == gbest);
+            if (__builtin_popcountll(who) != 1) {
+                const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
+                const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
+                who = __ballot(lane < NW && sd == gbest && sk == win);
+            }
+            const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
+            px = rl(sx, ww); py = rl(sy, ww); pz = rl(sz, ww);
+            okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
+            J = 1;
+            if (PROF && tid == 0 && total >= 2) sh.stat[3] += 1;
+        } else {
+            // into rank order: lane `rank` receives this candidate (dead lanes keep to themselves, behind)
+            const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
+            const int dst = (live ? rank : deadpos) * 4;
+            auto perm = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(v))); };
+            px = perm(cx); py = perm(cy); pz = perm(cz);
+            okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
+            const int sM = __builtin_amdgcn_ds_permute(dst, cM);
+            // candidates below the best one a wave had to leave out cannot be accepted
+            int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
+            if (PROF && tid == 0 && jmax < total) sh.stat[2] += 1;
+            jmax = jmax < 1 ? 1 : jmax;
+            jmax = jmax < left ? jmax : left;
+            // longest prefix in which no member's best point lies inside the update ball of an earlier member
+            // (then that point keeps its distance, and every other point of its cell can only fall)
+            for (int i = 0; i + 1 < jmax; ++i) {
+                const float d = tpu3_sqdist3(px - rl(px, i), py - rl(py, i), pz - rl(pz, i));
+                const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
+                if (hit) {
+                    const int f = __builtin_ctzll(hit);
+                    jmax = f < jmax ? f : jmax;
+                }
+            }
+            J = jmax;
+        }
+        if (J > left)
+            J = left;
+        if (wave == 0 && lane < J)
+            a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
+        if (PROF && tid == 0) { sh.stat[0] += 1; sh.stat[1] += (uint32_t)J; sh.stat[4] += (uint32_t)total; }
+        if (PROF) { s1 = now(); pc[6] += s1 - s0; }
+        r += J;
+        if (r >= a.m) {
+            if (J > 1)
+                apply(J - 1);                           // every sample but the last one updates `temp`
+            break;
+        }
+    }
+    if (PROF && tid == 0 && a.prof)
+        for (int i = 0; i < 8; ++i)
+            a.prof[i] = sh.stat[i];
+    if (PROF && lane == 0 && a.prof)
+        for (int i = 0; i < 8; ++i)
+            a.prof[8 + wave * 8 + i] = pc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Point sets that fit the register file (n <= 25 600): the same exact pruning with the points held
 // in VGPRs.  One 16-wave workgroup per set; a ROW is 64 consecutive points of the Morton order (a
 // compact region, = one bucket of the init kernel) and row r belongs to wave r % 16, slot r / 16
@@ -794,7 +1320,7 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.ks = align256(sizeof(uint32_t) * (size_t)n);
     p.ps = align256(sizeof(float) * (size_t)p.npad);
     p.bs = align256(sizeof(uint32_t) * (size_t)p.nbpad);
-    p.per_elem = 5 * p.ps + 8 * p.bs + align256(8 * sizeof(float));
+    p.per_elem = 5 * p.ps + 9 * p.bs + align256(8 * sizeof(float));
     p.segmented = b >= 4 && n <= 65536 && (size_t)b * (p.ks / 4) < 0x7FFFFFFFu;
     p.global64 = !p.segmented && b >= 2;
     p.ebits = 1;
@@ -832,8 +1358,8 @@ int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
 {
     if (p.ngpt != 1)
         return TPU3_ELIMIT;
-    const size_t lds = fb_lds_bytes(p.nbpad, FB_NW, 1);
-    auto kern = fb_main_kernel<FB_NW, 1, PPL, PROF>;
+    const size_t lds = fm_lds_bytes(p.nbpad, FB_NW);
+    auto kern = fm_main_kernel<FB_NW, PPL, PROF>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
@@ -876,7 +1402,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     a0.sp = (float4 *)slabs;
     a0.skey = (uint32_t *)(slabs + 4 * p.ps);
     a0.ib = (uint32_t *)(slabs + 5 * p.ps);
-    a0.bbox = (float *)(slabs + 5 * p.ps + 8 * p.bs);
+    a0.bbox = (float *)(slabs + 5 * p.ps + 9 * p.bs);
     a0.per_elem = p.per_elem;
     a0.sort_stride = p.ks / 4;
 

@@ -142,6 +142,24 @@ __device__ __forceinline__ void tpu3_wave_max_i32_fast_x2(int &a, int &b)
     a = __builtin_amdgcn_readlane(a, 63);
     b = __builtin_amdgcn_readlane(b, 63);
 }
+// four independent chains: each chain's DPP read is three instructions behind its write, no wait states needed
+__device__ __forceinline__ void tpu3_wave_max_i32_fast_x4(int &a, int &b, int &c, int &d)
+{
+#define TPU3_X4(ctrl) TPU3_DPP_MAX_I32("%0", ctrl) TPU3_DPP_MAX_I32("%1", ctrl) TPU3_DPP_MAX_I32("%2", ctrl) TPU3_DPP_MAX_I32("%3", ctrl)
+    asm volatile("s_nop 1\n\t"
+                 TPU3_X4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 TPU3_X4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 TPU3_X4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 TPU3_X4("row_mirror row_mask:0xf bank_mask:0xf")
+                 TPU3_X4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 TPU3_X4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n\t"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef TPU3_X4
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63);
+    d = __builtin_amdgcn_readlane(d, 63);
+}
 // max over the 16 lanes of row 0 only (cross-wave slots); result valid in every lane of row 0
 __device__ __forceinline__ int tpu3_row_max_i32_fast(int v)
 {
