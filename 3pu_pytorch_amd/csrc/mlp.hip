@@ -39,6 +39,83 @@ struct LinArgs {
 
 constexpr int LS_CIN_MAX = 320;           // weights staged in LDS: 32 x (320 + 4) floats = 41 KB
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ h8 cat_h8(v4f lo, v4f hi)
+{
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (_Float16)lo[j];
+        r[4 + j] = (_Float16)hi[j];
+    }
+    return r;
+}
+
+// fp16-operand flavour (TPU3_MFMA_F16): two 16-channel slabs per v_mfma_f32_16x16x32_f16.  The eight k slots
+// of lane (pt, q) are the channels {16 s + 4 q + j} u {16 (s+1) + 4 q + j}, j < 4 -- the SAME two float4 pieces
+// the fp32 flavour fetches, converted in registers; weights likewise.  fp32 accumulate, fp32 rows in memory.
+template <int TOUT>
+__global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 * TOUT][cin + 4], zero padded (fp32)
+    const int S = a.cin + 4;
+    for (int i = threadIdx.x; i < 16 * TOUT * (a.cin >> 2); i += blockDim.x) {
+        const int o = i / (a.cin >> 2), c4 = i - o * (a.cin >> 2);
+        const v4f v = o < a.cout ? ld4(a.w + (size_t)o * a.cin + 4 * c4) : (v4f){0.f, 0.f, 0.f, 0.f};
+        *(v4f *)(wl + o * S + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const int nslab = (a.cin + 15) >> 4;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 16 + pt;
+        const float *xr = a.x + (row < a.m ? row : a.m - 1) * a.xs;
+        v4f acc[TOUT];
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t)
+            acc[t] = zero;
+        for (int s0 = 0; s0 < nslab; s0 += 8) {
+            v4f bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = 16 * (s0 + u) + 4 * q;
+                bv[u] = ld4(xr + (ch < a.cin ? ch : 0));        // cin % 4 == 0
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const int ch0 = 16 * (s0 + u) + 4 * q, ch1 = ch0 + 16;
+                const bool ok0 = ch0 < a.cin, ok1 = ch1 < a.cin;
+                const h8 b = cat_h8(ok0 ? bv[u] : zero, ok1 ? bv[u + 1] : zero);
+#pragma unroll
+                for (int t = 0; t < TOUT; ++t) {
+                    const float *wr = wl + (16 * t + pt) * S;
+                    const h8 av = cat_h8(ok0 ? *(const v4f *)(wr + ch0) : zero, ok1 ? *(const v4f *)(wr + ch1) : zero);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+            const int o = 16 * t + 4 * q;                       // cout % 4 == 0
+            if (o < a.cout && row < a.m) {
+                v4f v = acc[t];
+                if (a.b)
+                    v += ld4(a.b + o);
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(v4f *)(a.y + row * a.ys + o) = v;
+            }
+        }
+    }
+}
+
 template <int TOUT>
 __global__ __launch_bounds__(256) void linear_small_kernel(LinArgs a)
 {
@@ -244,12 +321,153 @@ __global__ __launch_bounds__(512) void regress_tail_kernel(TailArgs a)
     }
 }
 
+// fp16-operand flavour of the tail (TPU3_MFMA_F16): the same register-to-register dataflow with two
+// accumulator tiles of a layer forming the B operand of ONE v_mfma_f32_16x16x32_f16 of the next (k slots of
+// lane (pt, q): outputs 16 t + 4 q + j of tiles t = 2 S and 2 S + 1).  Weights in LDS as fp16 (50 KB instead
+// of 100): 32 + 16 + 2 MFMAs per 16 rows instead of 256 + 128 + 16.
+constexpr int RH_S = 136;                 // fp16 row stride of the 128-wide weight rows (16-byte aligned, skewed)
+constexpr int RH_S4 = 72;
+
+constexpr size_t rh_lds_bytes()
+{
+    return ((size_t)RT_C2 * RH_S + RT_C3 * RH_S + 16 * RH_S4) * 2 + (RT_C2 + RT_C3 + 16 + RT_RMAX * RT_C1) * 4;
+}
+
+// the eight weights of output row `m` a lane needs for slab pair S: channels 32 S + {4 q + j, 16 + 4 q + j}
+__device__ __forceinline__ h8 rh_w8(const _Float16 *w, int stride, int m, int S, int q)
+{
+    const h4 lo = *(const h4 *)(w + m * stride + 32 * S + 4 * q), hi = *(const h4 *)(w + m * stride + 32 * S + 16 + 4 * q);
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = lo[j];
+        r[4 + j] = hi[j];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    _Float16 *w2 = (_Float16 *)ldsb;              // [128][136]
+    _Float16 *w3 = w2 + RT_C2 * RH_S;             // [64][136]
+    _Float16 *w4 = w3 + RT_C3 * RH_S;             // [16][72], rows >= 3 zero
+    float *b2 = (float *)(w4 + 16 * RH_S4);       // [128]
+    float *b3 = b2 + RT_C2;                       // [64]
+    float *b4 = b3 + RT_C3;                       // [16]
+    float *cc = b4 + 16;                          // [r][128]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RT_C2 * RT_C1; i += blockDim.x)
+        w2[(i >> 7) * RH_S + (i & 127)] = (_Float16)a.w2[i];
+    for (int i = tid; i < RT_C3 * RT_C2; i += blockDim.x)
+        w3[(i >> 7) * RH_S + (i & 127)] = (_Float16)a.w3[i];
+    for (int i = tid; i < 16 * RT_C3; i += blockDim.x)
+        w4[(i >> 6) * RH_S4 + (i & 63)] = (_Float16)((i >> 6) < RT_C4 ? a.w4[i] : 0.f);
+    for (int i = tid; i < RT_C2; i += blockDim.x)
+        b2[i] = a.b2[i];
+    for (int i = tid; i < RT_C3; i += blockDim.x)
+        b3[i] = a.b3[i];
+    for (int i = tid; i < 16; i += blockDim.x)
+        b4[i] = i < RT_C4 ? a.b4[i] : 0.f;
+    for (int i = tid; i < a.r * RT_C1; i += blockDim.x)
+        cc[i] = a.c[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    for (long tile = (long)blockIdx.x * nw + wave; tile < ntiles; tile += (long)gridDim.x * nw) {
+        const long row = tile * 16 + pt;
+        const long rowc = row < a.m ? row : a.m - 1;
+        v4f av[RT_C1 / 16];
+#pragma unroll
+        for (int s = 0; s < RT_C1 / 16; ++s)
+            av[s] = ld4(a.a + rowc * RT_C1 + 16 * s + 4 * q);
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (q == 0) {
+            rx = a.res[rowc * 3 + 0]; ry = a.res[rowc * 3 + 1]; rz = a.res[rowc * 3 + 2];
+        }
+        for (int j = 0; j < a.r; ++j) {
+            // h0 = relu(a + c_j), as the B operands of the four slab pairs
+            h8 h0[RT_C1 / 32];
+#pragma unroll
+            for (int S = 0; S < RT_C1 / 32; ++S) {
+                v4f v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u] = av[2 * S + u] + ld4(cc + j * RT_C1 + 16 * (2 * S + u) + 4 * q);
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+                h0[S] = cat_h8(v[0], v[1]);
+            }
+            // layer 2: 128 -> 128, ReLU
+            v4f t1[RT_C2 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C2 / 16; ++t)
+                t1[t] = ld4(b2 + 16 * t + 4 * q);
+#pragma unroll
+            for (int S = 0; S < RT_C1 / 32; ++S) {
+#pragma unroll
+                for (int t = 0; t < RT_C2 / 16; ++t)
+                    t1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh_w8(w2, RH_S, 16 * t + pt, S, q), h0[S], t1[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keep the next slab pairs' LDS reads from piling up in VGPRs
+            }
+            h8 h1[RT_C2 / 32];
+#pragma unroll
+            for (int S = 0; S < RT_C2 / 32; ++S) {
+                v4f v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u] = t1[2 * S + u];
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+                h1[S] = cat_h8(v[0], v[1]);
+            }
+            // layer 3: 128 -> 64, ReLU
+            v4f t2[RT_C3 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C3 / 16; ++t)
+                t2[t] = ld4(b3 + 16 * t + 4 * q);
+#pragma unroll
+            for (int S = 0; S < RT_C2 / 32; ++S) {
+#pragma unroll
+                for (int t = 0; t < RT_C3 / 16; ++t)
+                    t2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh_w8(w3, RH_S, 16 * t + pt, S, q), h1[S], t2[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // layer 4: 64 -> 3 (one output tile, rows >= 3 are zero weights), bias, residual
+            v4f o = zero;
+#pragma unroll
+            for (int S = 0; S < RT_C3 / 32; ++S) {
+                v4f v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u] = t2[2 * S + u];
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh_w8(w4, RH_S4, pt, S, q), cat_h8(v[0], v[1]), o, 0, 0, 0);
+            }
+            if (q == 0 && row < a.m) {          // lanes 0-15 hold outputs 0..3 of their point
+                float *dst = a.out + (row * a.r + j) * 3;
+                dst[0] = (o.x + b4[0]) + rx;
+                dst[1] = (o.y + b4[1]) + ry;
+                dst[2] = (o.z + b4[2]) + rz;
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
                                      int x_stride, const float *w, const float *bias, int relu, float *y,
-                                     int y_stride)
+                                     int y_stride, int mfma)
 {
+    if (mfma != TPU3_MFMA_F32 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
     if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
     if (cout > 32 || cin > LS_CIN_MAX || cin % 4 || cout % 4 || x_stride % 4 || y_stride % 4) return TPU3_ELIMIT;
     if (x_stride < cin || y_stride < cout) return TPU3_EINVAL;
@@ -262,7 +480,12 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
     if (blocks > 256 * 8) blocks = 256 * 8;       // persistent: the weights are staged once per workgroup
     const int tout = cout <= 16 ? 1 : 2;
     const size_t lds = (size_t)16 * tout * (cin + 4) * sizeof(float);
-    if (tout == 1)
+    if (mfma == TPU3_MFMA_F16) {
+        if (tout == 1)
+            hipLaunchKernelGGL(linear_small_f16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(linear_small_f16_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    } else if (tout == 1)
         hipLaunchKernelGGL(linear_small_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(linear_small_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
@@ -271,19 +494,29 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
 
 extern "C" int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, const float *c,
                                      const float *w2, const float *b2, const float *w3, const float *b3,
-                                     const float *w4, const float *b4, const float *residual, float *out)
+                                     const float *w4, const float *b4, const float *residual, float *out, int mfma)
 {
     if (m < 0 || r <= 0 || r > RT_RMAX) return TPU3_EINVAL;
+    if (mfma != TPU3_MFMA_F32 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
     if (m == 0) return TPU3_OK;
     if (!a || !c || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !residual || !out) return TPU3_EINVAL;
     if (((uintptr_t)a & 15) != 0) return TPU3_ELIMIT;
     TailArgs t{m, r, a, c, w2, b2, w3, b3, w4, b4, residual, out};
+    const long tiles = (m + 15) / 16;
+    long blocks = (tiles + 7) / 8;
+    if (mfma == TPU3_MFMA_F16) {
+        const size_t lds = rh_lds_bytes();
+        hipError_t e = hipFuncSetAttribute((const void *)regress_tail_f16_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (blocks > 512) blocks = 512;         // two persistent workgroups per CU (55 KB of weights each)
+        hipLaunchKernelGGL(regress_tail_f16_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, t);
+        return tpu3_launch_status();
+    }
     const size_t lds = rt_lds_floats() * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void *)regress_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
-    const long tiles = (m + 15) / 16;
-    long blocks = (tiles + 7) / 8;
     if (blocks > 256) blocks = 256;             // one persistent workgroup per CU (106 KB of weights each)
     hipLaunchKernelGGL(regress_tail_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, t);
     return tpu3_launch_status();

@@ -243,7 +243,13 @@ def _fused_linear(layer, x):
             or layer.activation not in (None, "relu") or layer.conv.out_channels > 32):
         return None
     w = layer.conv.weight
-    return be.linear_small(x, w.view(w.size(0), -1), layer.conv.bias, layer.activation == "relu")
+    f16 = getattr(layer, "mlp_precision", "f32") == "f16"
+    y = be.linear_small(x, w.view(w.size(0), -1), layer.conv.bias, layer.activation == "relu",
+                        mfma=L.MFMA_F16 if f16 else L.MFMA_F32)
+    if y is None and f16:
+        raise RuntimeError("mlp_precision='f16': the fused per-point kernel does not cover this layer "
+                           "(%d -> %d channels)" % (x.size(-1), w.size(0)))
+    return y
 
 
 def _make_norm(normalization, out_channels, momentum, dims):

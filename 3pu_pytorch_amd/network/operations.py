@@ -260,7 +260,7 @@ class HipBackend(object):
                 "tpu3_interlevel_skip_f32")
         return feat
 
-    def linear_small(self, x, weight, bias, relu):
+    def linear_small(self, x, weight, bias, relu, mfma=L.MFMA_F32):
         """Per-point linear layer with <= 32 outputs on channel-last rows: x (..., C_in) with unit
         channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),
         weight (C_out, C_in) -> (..., C_out), or None when the shape is not covered."""
@@ -284,7 +284,7 @@ class HipBackend(object):
         y = torch.empty(lead + (cout,), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             L.check(L.lib().tpu3_linear_small_f32(L.stream_of(x), m, cin, cout, L.ptr(x), rs, L.ptr(w),
-                                                  L.ptr(bias), 1 if relu else 0, L.ptr(y), cout),
+                                                  L.ptr(bias), 1 if relu else 0, L.ptr(y), cout, int(mfma)),
                     "tpu3_linear_small_f32")
         return y
 
@@ -304,13 +304,13 @@ class HipBackend(object):
                                               dy.stride(0), L.ptr(dw), L.ptr(ws), need), "tpu3_linear_wgrad_f32")
         return dw
 
-    def regress_tail(self, a, c, w2, b2, w3, b3, w4, b4, residual):
+    def regress_tail(self, a, c, w2, b2, w3, b3, w4, b4, residual, mfma=L.MFMA_F32):
         """a (M,128), c (r,128), residual (M,3) -> (M*r, 3); see tpu3_regress_tail_f32."""
         m, r = a.size(0), c.size(0)
         out = torch.empty((m * r, 3), dtype=torch.float32, device=a.device)
         ts = [t.contiguous() for t in (a, c, w2, b2, w3, b3, w4, b4, residual)]
         with torch.cuda.device(a.device):
-            L.check(L.lib().tpu3_regress_tail_f32(L.stream_of(a), m, r, *[L.ptr(t) for t in ts], L.ptr(out)),
+            L.check(L.lib().tpu3_regress_tail_f32(L.stream_of(a), m, r, *[L.ptr(t) for t in ts], L.ptr(out), int(mfma)),
                     "tpu3_regress_tail_f32")
         return out
 

@@ -152,12 +152,14 @@ class Net(torch.nn.Module):
     def set_mlp_precision(self, precision):
         """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):
         "f32" -- fp32 operands (default; what the parity tests pin), or "f16" -- operands rounded to fp16,
-        fp32 accumulate (BASELINE config C5: "fp16 feature MLPs on MFMA").  FPS, every kNN and the Chamfer
-        distance stay fp32 either way.  Explicit: a layer shape the f16 kernels do not cover raises."""
+        fp32 accumulate (BASELINE config C5: "fp16 feature MLPs on MFMA").  FPS, every kNN, the Chamfer
+        distance and the 3 -> 24 coordinate embedding (layer0) stay fp32 either way.  Explicit: a layer shape the f16 kernels do not cover raises."""
         if precision not in ("f32", "f16"):
             raise ValueError("mlp precision must be 'f32' or 'f16'")
         for m in self.modules():
-            if isinstance(m, (layers.DenseEdgeConv, Level)):
+            if isinstance(m, (layers.Conv1d, layers.Conv2d)) and m.conv.in_channels < 16:
+                continue            # layer0 embeds the xyz coordinates themselves (3 -> 24): kept in fp32
+            if isinstance(m, (layers.DenseEdgeConv, layers.Conv1d, layers.Conv2d, Level)):
                 m.mlp_precision = precision
         return self
 
@@ -232,6 +234,8 @@ class Net(torch.nn.Module):
 
 class Level(torch.nn.Module):
     """3PU per-level network (reference :192-374)."""
+
+    mlp_precision = "f32"       # see Net.set_mlp_precision
 
     def __init__(self, dense_n=3, growth_rate=12, knn=16, fm_knn=5, step_ratio=2):
         super(Level, self).__init__()
@@ -413,7 +417,11 @@ class Level(torch.nn.Module):
             # concatenation of the reference is never built (half the FLOPs of this layer)
             w = up1.conv.weight.view(up1.conv.weight.size(0), -1)
             cin = x.size(-1)
-            a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)                 # (B,N,128)
+            f16 = getattr(self, "mlp_precision", "f32") == "f16"
+            if f16:     # the per-point half of up_layer1 as an fp16 GEMM (hipBLASLt -> MFMA), fp32 result
+                a = torch.nn.functional.linear(x.half(), w[:, :cin].half(), up1.conv.bias.half()).float()
+            else:
+                a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)             # (B,N,128)
             c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])          # (r,128)
             up2, fc1, fc2 = self.up_layer.up_layer2, self.fc_layer1, self.fc_layer2
             be = operations.BACKEND
@@ -425,8 +433,11 @@ class Level(torch.nn.Module):
                 flat = lambda l: l.conv.weight.view(l.conv.weight.size(0), -1)
                 out = be.regress_tail(a.reshape(B * N, 128), c, flat(up2), up2.conv.bias, flat(fc1),
                                       fc1.conv.bias, flat(fc2), fc2.conv.bias,
-                                      xyz_normalized.reshape(B * N, 3))
+                                      xyz_normalized.reshape(B * N, 3),
+                                      mfma=operations.L.MFMA_F16 if f16 else operations.L.MFMA_F32)
                 return out.view(B, N * ratio, 3), point_features
+            if f16:
+                raise RuntimeError("mlp_precision='f16': the fused regressor tail does not cover step ratio %d" % ratio)
             operations.note_generic_path("regressor tail with step ratio %d / widths %s (fused kernel: ratio <= 4, "
                                          "128 -> 128 -> 64 -> 3)" % (ratio, (a.size(-1), up2.conv.out_channels,
                                                                             fc1.conv.out_channels, fc2.conv.out_channels)))

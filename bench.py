@@ -239,6 +239,28 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
         ex["train_step_ms"] = train
     except Exception as e:                                               # noqa: BLE001
         ex["train_step_ms"] = "failed: %s" % (str(e).splitlines()[0][:120])
+    # config C5 (stress): one 80 000-point cloud, num_point = 1024 (234 outer patches), 16x -> 1.28 M points,
+    # feature MLPs on fp16-operand MFMA; FPS / kNN stay fp32.  One warm-up, one timed run.
+    try:
+        c5 = poisson_sphere(5, 80000, dev, ops)
+        net.set_mlp_precision("f16")
+        res = {}
+        for final in (False, True):
+            for it in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = pipe.upsample(net, c5, 1024, 16, 3, final_fps=final, check_small=False)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            res["network_stages_ms" if not final else "total_ms"] = dt * 1e3
+        assert tuple(out.shape) == (1, 3, 1280000) and bool(torch.isfinite(out).all())
+        res["points_per_s"] = 1280000 / (res["total_ms"] * 1e-3)
+        res["config"] = "C5: 1 cloud x 80000 pts, num_point=1024, up_ratio=16, fp16-operand MFMA feature MLPs, 1 GPU"
+        ex["c5_stress"] = res
+    except Exception as e:                                               # noqa: BLE001
+        ex["c5_stress"] = "failed: %s" % (str(e).splitlines()[0][:160])
+    finally:
+        net.set_mlp_precision("f32")
     return ex
 
 
@@ -395,6 +417,7 @@ def main():
     total_clouds = 1 if patch_mode else world * C
     assert tuple(out.shape) == (total_clouds, 3, N * r) and bool(torch.isfinite(out).all())
     assert int(net.small_cloud_events) == 0
+    assert not ops.GENERIC_PATH_EVENTS, "generic (unfused) path taken in the measured run: %r" % dict(ops.GENERIC_PATH_EVENTS)
 
     # all-gather bus bandwidth (N > 1): (P-1)/P * gathered bytes / time, 10 back-to-back gathers
     comm = None

@@ -249,9 +249,10 @@ size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
  *   y[i, 0..cout) = act(W x[i, 0..cin) + bias),  x (m, x_stride) rows, y (m, y_stride) rows,
  *   w (cout, cin) row-major = the convolution weight, bias (cout) or NULL, relu != 0 -> ReLU.
  * cout <= 32; cin, cout and both strides multiples of 4, 16-byte aligned bases (else TPU3_ELIMIT:
- * callers then use their generic GEMM path).  fp32 MFMA. */
+ * callers then use their generic GEMM path).  mfma = TPU3_MFMA_F32 / TPU3_MFMA_F16 (fp16 operands, fp32
+ * accumulate; rows stay fp32 in memory). */
 int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
-                          const float *w, const float *bias, int relu, float *y, int y_stride);
+                          const float *w, const float *bias, int relu, float *y, int y_stride, int mfma);
 
 /* Regressor tail of a Level, inference (network/upsampler.py:363-372) for the reference's widths
  * 128 -> 128 -> 64 -> 3: for point i and replica j < r (r <= 4)
@@ -259,10 +260,10 @@ int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const
  * a (m,128) = the per-point half of up_layer1 incl. its bias, c (r,128) = its per-replica (code)
  * half, w2 (128,128), w3 (64,128), w4 (3,64) row-major convolution weights, residual (m,3) the
  * normalised input coordinates, out (m*r,3).  One launch instead of three GEMMs and five
- * elementwise passes over (m*r,128) tensors. */
+ * elementwise passes over (m*r,128) tensors.  mfma = TPU3_MFMA_F32 / TPU3_MFMA_F16 as above. */
 int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, const float *c,
                           const float *w2, const float *b2, const float *w3, const float *b3,
-                          const float *w4, const float *b4, const float *residual, float *out);
+                          const float *w4, const float *b4, const float *residual, float *out, int mfma);
 
 /* Training: weight gradient of a kernel-size-1 convolution with few outputs over very many rows
  * (the dense layers of DenseEdgeConv, network/layers.py:53-61: 48/36/48 -> 12 channels over

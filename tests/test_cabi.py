@@ -58,15 +58,18 @@ def test_argument_validation_without_gpu():
     assert lib.tpu3_knn_graph_self_f32(None, 1, 64, 3, 5, 8, None, 8, 8, 8, None, 0) == -2      # k not 17 / 33
     assert lib.tpu3_knn_unique_compact_i32(None, 2, 8, None, None, None, None, None) == -1      # NULL pointers
     assert lib.tpu3_knn_unique_compact_i32(None, 0, 8, None, None, None, None, None) == 0
-    assert lib.tpu3_linear_small_f32(None, 4, 84, 40, 8, 84, 8, None, 1, 8, 40) == -2           # 40 outputs
-    assert lib.tpu3_linear_small_f32(None, 4, 82, 24, 8, 84, 8, None, 1, 8, 24) == -2           # cin % 4
-    assert lib.tpu3_linear_small_f32(None, 4, 84, 24, 8, 80, 8, None, 1, 8, 24) == -1           # stride < cin
-    assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24) == 0
+    assert lib.tpu3_linear_small_f32(None, 4, 84, 40, 8, 84, 8, None, 1, 8, 40, 0) == -2        # 40 outputs
+    assert lib.tpu3_linear_small_f32(None, 4, 82, 24, 8, 84, 8, None, 1, 8, 24, 0) == -2        # cin % 4
+    assert lib.tpu3_linear_small_f32(None, 4, 84, 24, 8, 80, 8, None, 1, 8, 24, 0) == -1        # stride < cin
+    assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24, 1) == 0
+    assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24, 7) == -1   # unknown mfma
+    assert lib.tpu3_dense_edge_conv_f32(None, 1, 312, 32, 8, 8, 4, 33, 1, 8, 8, 8, 8, 8, 8, 8, 60, 5) == -1
     assert lib.tpu3_linear_wgrad_f32(None, 100, 80, 12, 8, 80, 8, 12, 8, 8, 1 << 20) == -2       # cin > 64
     assert lib.tpu3_linear_wgrad_f32(None, 100, 48, 12, 8, 48, 8, 12, 8, None, 0) == -1          # no workspace
     assert lib.tpu3_linear_wgrad_workspace_bytes(319488) == 1024 * 16 * 64 * 4
-    assert lib.tpu3_regress_tail_f32(None, 4, 5, *([8] * 10)) == -1                              # r > 4
-    assert lib.tpu3_regress_tail_f32(None, 0, 2, *([None] * 10)) == 0
+    assert lib.tpu3_regress_tail_f32(None, 4, 5, *([8] * 10), 0) == -1                           # r > 4
+    assert lib.tpu3_regress_tail_f32(None, 0, 2, *([None] * 10), 1) == 0
+    assert lib.tpu3_regress_tail_f32(None, 0, 2, *([None] * 10), 3) == -1                        # unknown mfma
     assert lib.tpu3_interlevel_skip_workspace_bytes(3, 312, 5) == 3 * 312 * 12 * 4
     assert lib.tpu3_interlevel_skip_f32(None, 1, 312, 9, 264, 8, 8, 264, 8, 8, 10, None, 8, 4, 0.2, 0, None, 0) == -1
     assert lib.tpu3_fps_workspace_bytes(4, 1000) == 0 and lib.tpu3_fps_workspace_bytes(4, 30000) > 0

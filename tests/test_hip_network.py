@@ -662,6 +662,96 @@ def test_regress_tail_matches_torch(dev, m, r):
     assert (out.double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("m,cin,cout,relu", [(5000, 84, 24, True), (777, 204, 24, True), (4099, 144, 24, False),
+                                             (100, 16, 8, True)])
+def test_linear_small_fp16_mfma(dev, m, cin, cout, relu):
+    """mfma = F16 flavour of the prep convolutions: operands rounded to fp16 (2^-11 relative), fp32 accumulate
+    over <= 204 channels of O(1) values -> |diff| <= 1e-2 against fp64, an order tighter on average."""
+    ops, L = pkg("network.operations"), pkg("_lib")
+    g = torch.Generator(device="cpu").manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    y = ops.BACKEND.linear_small(x, w, b, relu, mfma=L.MFMA_F16)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = torch.relu(ref) if relu else ref
+    err = (y.double() - ref).abs()
+    assert float(err.max()) < 1e-2 and float(err.mean()) < 1.5e-3, (float(err.max()), float(err.mean()))
+    y32 = ops.BACKEND.linear_small(x, w, b, relu)
+    assert float((y - y32).abs().max()) > 0            # it is another arithmetic than the fp32 flavour
+
+
+@pytest.mark.parametrize("m,r", [(312, 2), (4096 * 3 + 5, 2), (17, 4)])
+def test_regress_tail_fp16_mfma(dev, m, r):
+    """mfma = F16 flavour of the regressor tail against fp64: three fp16-operand layers deep on O(1)
+    activations, outputs O(1): |diff| <= 3e-2, <= 5e-3 on average."""
+    ops, L = pkg("network.operations"), pkg("_lib")
+    g = torch.Generator(device="cpu").manual_seed(m)
+    a = torch.randn(m, 128, generator=g).to(dev)
+    c = torch.randn(r, 128, generator=g).to(dev)
+    w2 = (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev)
+    w3 = (torch.randn(64, 128, generator=g) / 128 ** 0.5).to(dev)
+    w4 = (torch.randn(3, 64, generator=g) / 8).to(dev)
+    b2, b3, b4 = (torch.randn(n, generator=g).to(dev) for n in (128, 64, 3))
+    res = torch.randn(m, 3, generator=g).to(dev)
+    out = ops.BACKEND.regress_tail(a, c, w2, b2, w3, b3, w4, b4, res, mfma=L.MFMA_F16)
+    d = lambda t: t.double()
+    h = torch.relu(d(a).unsqueeze(1) + d(c).unsqueeze(0))
+    h = torch.relu(h @ d(w2).t() + d(b2))
+    h = torch.relu(h @ d(w3).t() + d(b3))
+    ref = (h @ d(w4).t() + d(b4) + d(res).unsqueeze(1)).reshape(m * r, 3)
+    err = (out.double() - ref).abs()
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 5e-3, (float(err.max()), float(err.mean()))
+
+
+def test_config_c5_full_size_fp16_mlps(orc, dev):
+    """BASELINE config C5 at FULL size: one 80 000-point cloud, num_point = 1024 (234 outer patches of 1024
+    points, inner patches of 312), up_ratio 16 -> 1.28 M points, feature MLPs on fp16-operand MFMA
+    (Net.set_mlp_precision("f16"); FPS / kNN / Chamfer stay fp32).  Size-independent properties:
+    shape, finiteness, no generic (unfused) path, no point sampled twice, the FPS covering-radius property on
+    the 3.83 M -> 1.28 M resampling, and the fp16 cloud against the fp32 cloud of the same weights under
+    Chamfer (both are samplings of the same surface: far below the output's own point spacing)."""
+    pipe, ops, ups = pkg("pipeline"), pkg("network.operations"), pkg("network.upsampler")
+    ml = pkg("network.model_loss")
+    net = _net(dev)
+    g = torch.Generator().manual_seed(0)
+    cand = torch.randn(1, 80000, 3, generator=g)
+    cloud = (cand / cand.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous().to(dev)
+    P = pipe.num_outer_patches(80000, 1024, 3)
+    assert P == 234
+    ops.GENERIC_PATH_EVENTS.clear()
+    merged32 = pipe.upsample(net, cloud, 1024, 16, 3, final_fps=False)
+    net.set_mlp_precision("f16")
+    merged16 = pipe.upsample(net, cloud, 1024, 16, 3, final_fps=False)
+    out16 = pipe.upsample(net, cloud, 1024, 16, 3)
+    net.set_mlp_precision("f32")
+    assert not ops.GENERIC_PATH_EVENTS, dict(ops.GENERIC_PATH_EVENTS)
+    assert tuple(merged16.shape) == (1, 3, P * 1024 * 16) and tuple(out16.shape) == (1, 3, 1280000)
+    assert torch.isfinite(merged16).all() and torch.isfinite(out16).all()
+    assert float((merged16 - merged32).abs().max()) > 0            # another arithmetic ...
+    o = out16.transpose(2, 1).contiguous()
+    m16, m32 = merged16.transpose(2, 1).contiguous(), merged32.transpose(2, 1).contiguous()
+    # ... describing the same surface: Chamfer(fp16 cloud, fp32 cloud) against the fp32 cloud's own spacing
+    sub16, sub32 = m16[:, ::16].contiguous(), m32[:, ::16].contiguous()
+    d1, _, d2, _ = ml.nndistance(sub16, sub32)
+    _, dself, _ = ops.knn_query(2, sub32[:, :20000].contiguous(), sub32[:, :20000].contiguous(), unique=False,
+                                want_grouped=False)
+    spacing2 = float(dself[:, :, 1].clamp_min(0).median())
+    print("C5 fp16 vs fp32 merged clouds: mean sq NN distance %.3e / %.3e, own squared spacing %.3e"
+          % (float(d1.mean()), float(d2.mean()), spacing2))
+    assert float(d1.mean()) < 4 * spacing2 and float(d2.mean()) < 4 * spacing2
+    # FPS properties of the 3.83 M -> 1.28 M resampling
+    idx = ops.fps(m16, 1280000)
+    assert idx.unique().numel() == 1280000
+    assert torch.equal(torch.gather(m16, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)), o)
+    ref_idx, _ = orc.fps(m16.cpu().numpy(), 40)
+    np.testing.assert_array_equal(idx[:, :40].cpu().numpy(), ref_idx)
+    d_cover, _, _, _ = ml.nndistance(m16, o)
+    part = o[:, :200000].contiguous()
+    _, d_self, _ = ops.knn_query(2, part, o, unique=False, want_grouped=False)
+    assert float(d_self[:, :, 1].min()) >= float(d_cover.max()) - 1e-6
+
+
 def test_cli_test_and_train_phases(dev, tmp_path, monkeypatch):
     """The drop-in CLI on the device: --phase test on .xyz files (checkpoint in the reference's
     format) writes <name>.ply with N*up_ratio points; --phase train runs optimiser steps."""
