@@ -45,6 +45,7 @@ constexpr int FB_GS = 16;        // buckets per group = lanes per DPP row
 // `sort_stride` words.
 struct FbArgs {
     int n, m, nb, nbpad, npad, ng;      // n, m: slab strides = upper bounds of the live sizes
+    int ncell;                          // entries of the main kernel's LDS table: nbpad, or nbpad / 16 (three levels)
     int bsz, lb;                        // points per bucket; log2 of the tie-rule block size
     const int32_t *n_arr, *m_arr;       // live sizes per element, or null
     const float *xyz;     // (n,3) original order
@@ -663,17 +664,26 @@ constexpr size_t fm_lds_bytes(int nbpad, int nw)
     return (size_t)nbpad * 36 + (size_t)nw * 64 * 12 * 4 + sizeof(FmShared) + 64;
 }
 
-template <int NW, int PPL, bool PROF = false>
+// L3 (point sets beyond 4096 x 64 = 262 144 points, up to 4.19 M: config C5's 3.83 M): three levels.  The LDS
+// table then holds CELLS of 16 consecutive 64-point leaf buckets (1024 points); the leaves' own entries --
+// the nine-row array the bucket-init kernel wrote, 36 bytes per leaf -- stay in global memory (2 MB for
+// 3.83 M points: L2) and are updated in place.  A reached cell is not re-scanned as a whole: its 16 leaf
+// entries are fetched (one DPP row per cell), tested against the samples that reach the cell, the reached
+// LEAVES are re-scanned exactly as buckets are in the two-level form, and the cell's entry is rebuilt from its
+// leaves.  Three dependent trips to L2 per reached cell instead of streaming 16 KB through the VALU.
+template <int NW, int PPL, bool PROF = false, bool L3 = false>
 __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
 {
+    static_assert(!L3 || PPL == 1, "leaf buckets are 64 points");
     static_assert(NW == 4, "candidate slots are laid out for four waves");
     constexpr int W = NW * 64;
     constexpr int GT = W;                           // group-table entries (owner order), one per lane
-    static_assert(2 * FM_CAP * FM_EW + NW * 64 * 2 <= 6 * GT, "lists must fit the setup-only box area");
+    static_assert(2 * FM_CAP * FM_EW + 2 * NW * 64 * 2 <= 6 * GT, "lists must fit the setup-only box area");
     constexpr int CH = PPL <= 2 ? 4 : 2;            // buckets in flight per re-scan step (8: register arrays spill)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FbArgs a = fb_elem(a0, blockIdx.x);
-    const int nbpad = a.nbpad, ng = a.ng, lb = a.lb;
+    const int nbpad = a.ncell, ng = a.ng, lb = a.lb;        // nbpad: entries of the LDS table (cells)
+    const int LS = a.nbpad;                                 // row stride of the leaf table a.ib (L3)
     if (a.n <= 0 || a.m <= 0)
         return;
     // Group g = the 16 CONSECUTIVE Morton buckets [16 g, 16 g + 16) (a compact box); it belongs to wave g % NW,
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     int *g_r = (int *)(g_z + GT);                   // runner-up bound of the group
     float *g_box = (float *)(g_r + GT);             // 6 x GT, setup only ...
     uint32_t *cand = (uint32_t *)g_box;             // ... then the candidate lists [2][FM_CAP][FM_EW]
-    uint32_t *work = cand + 2 * FM_CAP * FM_EW;     // ... and the re-scan work lists [NW][64][2]
+    uint32_t *work = cand + 2 * FM_CAP * FM_EW;     // ... and the re-scan work lists [NW][64][2] (+ leaf lists, L3)
     FmShared &sh = *(FmShared *)(g_box + 6 * GT);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -704,9 +714,10 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     float4 *__restrict__ sp = a.sp;
     const uint32_t *__restrict__ skey = a.skey;
     uint32_t *wl = work + wave * 128;
+    uint32_t *wl2 = work + NW * 128 + wave * 128;   // L3: the reached leaves of the cells being worked on
 
     // group g <-> wave g % NW, owner lane g / NW
-    auto refresh_groups = [&](int slot, bool with_box) {
+    auto refresh_groups = [&](int slot, bool with_box) __attribute__((always_inline)) {
         const bool valid = slot >= 0 && slot * NW + wave < ng;
         const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
         const int bits = valid ? t_max[beta] : (int)0x80000000;
@@ -742,17 +753,65 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     };
 
     // ---- setup ------------------------------------------------------------------------------------
-    for (int i = tid; i < nbpad; i += W) {
-        const int ti = i;                               // table slot = bucket id
-        t_max[ti] = (int)a.ib[0 * nbpad + i];
-        t_key[ti] = a.ib[1 * nbpad + i];
-        t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
-        t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
-        t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
-        t_b0[ti] = a.ib[5 * nbpad + i];
-        t_b1[ti] = a.ib[6 * nbpad + i];
-        t_b2[ti] = a.ib[7 * nbpad + i];
-        t_r[ti] = (int)a.ib[8 * nbpad + i];
+    // a cell's entry from its 16 leaves (L3): DPP row `row` handles cell `cell` (< 0: idle), lane `col` leaf
+    // 16 cell + col.  Best leaf by (distance, tie key); runner-up = the other leaves' bests and the winner's own
+    // runner-up; with_box: union of the leaves' fp16 boxes (exact: min / max of fp16 values).
+    auto cell_from_leaves = [&](int cell, bool with_box) __attribute__((always_inline)) {
+        const bool valid = cell >= 0;
+        const int leaf = valid ? cell * FB_GS + col : 0;
+        const int bits = valid ? (int)a.ib[0 * LS + leaf] : (int)0x80000000;
+        const uint32_t key = valid ? a.ib[1 * LS + leaf] : 0xFFFFFFFFu;
+        const int lr = valid ? (int)a.ib[8 * LS + leaf] : (int)0x80000000;
+        const int rmax = tpu3_row_max_i32_fast(bits);
+        unsigned long long tie = __ballot(valid && bits == rmax);
+        const unsigned long long rows = __ballot(valid && col == 0);
+        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
+            const uint32_t k2 = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
+            tie = __ballot(valid && bits == rmax && key == k2);
+        }
+        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
+        const bool winner = valid && ((tie >> lane) & 1ull) && (tie & below) == 0;
+        const int rr = tpu3_row_max_i32_fast(valid ? (winner ? lr : bits) : (int)0x80000000);
+        if (winner) {
+            t_max[cell] = rmax; t_key[cell] = key; t_r[cell] = rr;
+            t_x[cell] = __uint_as_float(a.ib[2 * LS + leaf]);
+            t_y[cell] = __uint_as_float(a.ib[3 * LS + leaf]);
+            t_z[cell] = __uint_as_float(a.ib[4 * LS + leaf]);
+        }
+        if (with_box) {
+            const uint32_t w0 = valid ? a.ib[5 * LS + leaf] : 0, w1 = valid ? a.ib[6 * LS + leaf] : 0;
+            const uint32_t w2 = valid ? a.ib[7 * LS + leaf] : 0;
+            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
+                          fb_half_hi(w2)};
+            uint32_t h[6];
+#pragma unroll
+            for (int c3 = 0; c3 < 6; ++c3) {
+                if (!valid)
+                    v[c3] = -__builtin_inff();
+                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
+                h[c3] = __half_as_ushort(__float2half(c3 < 3 ? -m : m));
+            }
+            if (valid && col == 0) {
+                t_b0[cell] = h[0] | (h[1] << 16); t_b1[cell] = h[2] | (h[3] << 16); t_b2[cell] = h[4] | (h[5] << 16);
+            }
+        }
+    };
+    if constexpr (L3) {
+        for (int c0 = wave * 4; c0 < nbpad; c0 += NW * 4)
+            cell_from_leaves(c0 + row, true);
+    } else {
+        for (int i = tid; i < nbpad; i += W) {
+            const int ti = i;                               // table slot = bucket id
+            t_max[ti] = (int)a.ib[0 * nbpad + i];
+            t_key[ti] = a.ib[1 * nbpad + i];
+            t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
+            t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
+            t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
+            t_b0[ti] = a.ib[5 * nbpad + i];
+            t_b1[ti] = a.ib[6 * nbpad + i];
+            t_b2[ti] = a.ib[7 * nbpad + i];
+            t_r[ti] = (int)a.ib[8 * nbpad + i];
+        }
     }
     for (int i = tid; i < GT; i += W) {
         g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu; g_r[i] = (int)0x80000000;
@@ -793,7 +852,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     // ---- re-scan the first `nwork` buckets of the wave's work list (entry = bucket, set of samples that
     // reach it), CH at a time with all their loads in flight together.  (Fetching the next CH while the current
     // ones are worked on was tried through a two-buffer struct: the compiler put it in scratch, 200 vs 103 ms.)
-    auto flush = [&](int nwork) {
+    auto rescan = [&](const uint32_t *list, int nwork) __attribute__((always_inline)) {
         for (int w0 = 0; w0 < nwork; w0 += CH) {
             FbBucket<PPL> bk[CH];
             int tb[CH];
@@ -801,8 +860,8 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int e = w0 + u < nwork ? w0 + u : w0;         // a short tail repeats the first (idempotent)
-                tb[u] = __builtin_amdgcn_readfirstlane((int)wl[2 * e]);
-                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl[2 * e + 1]);
+                tb[u] = __builtin_amdgcn_readfirstlane((int)list[2 * e]);
+                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2 * e + 1]);
                 fb_load<PPL>(bk[u], sp, skey, tb[u], lane);
             }
             FbCand c[CH];
@@ -842,8 +901,14 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             for (int u = 0; u < CH; ++u)
                 if (win[u] && (u == 0 || w0 + u < nwork)) {
                     const int b = tb[u];
-                    t_max[b] = mx[u]; t_key[b] = c[u].key; t_x[b] = c[u].x; t_y[b] = c[u].y; t_z[b] = c[u].z;
-                    t_r[b] = rx[u];
+                    if constexpr (L3) {                     // leaf entries live in global memory
+                        a.ib[0 * LS + b] = (uint32_t)mx[u]; a.ib[1 * LS + b] = c[u].key;
+                        a.ib[2 * LS + b] = __float_as_uint(c[u].x); a.ib[3 * LS + b] = __float_as_uint(c[u].y);
+                        a.ib[4 * LS + b] = __float_as_uint(c[u].z); a.ib[8 * LS + b] = (uint32_t)rx[u];
+                    } else {
+                        t_max[b] = mx[u]; t_key[b] = c[u].key; t_x[b] = c[u].x; t_y[b] = c[u].y; t_z[b] = c[u].z;
+                        t_r[b] = rx[u];
+                    }
                 }
 #pragma unroll
             for (int u = 0; u < CH; ++u)
@@ -852,8 +917,49 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
         }
     };
 
+    // ---- work off the first `nwork` entries of the wave's list (cell or bucket, set of samples reaching it) ----
+    auto flush = [&](int nwork) __attribute__((always_inline)) {
+        if constexpr (!L3) {
+            rescan(wl, nwork);
+        } else {
+            for (int w0 = 0; w0 < nwork; w0 += 4) {
+                // four listed cells at a time, one per DPP row; lane `col` looks at leaf `col` of its row's cell
+                const int e = w0 + row;
+                const bool valid = e < nwork;
+                const int cell = valid ? (int)wl[2 * e] : -1;
+                uint32_t rem = valid ? wl[2 * e + 1] : 0u;
+                const int leaf = valid ? cell * FB_GS + col : 0;
+                const uint32_t w0b = a.ib[5 * LS + leaf], w1b = a.ib[6 * LS + leaf], w2b = a.ib[7 * LS + leaf];
+                const float tm = __int_as_float((int)a.ib[0 * LS + leaf]);
+                const float lx = fb_half_lo(w0b), ly = fb_half_hi(w0b), lz = fb_half_lo(w1b);
+                const float hx = fb_half_hi(w1b), hy = fb_half_lo(w2b), hz = fb_half_hi(w2b);
+                uint32_t pm = 0;
+                while (__ballot(rem != 0)) {
+                    const int i = rem ? __builtin_ctz(rem) : 0;
+                    const float qx = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(px)));
+                    const float qy = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(py)));
+                    const float qz = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(pz)));
+                    pm |= (rem != 0 && fb_dbox(qx, qy, qz, lx, ly, lz, hx, hy, hz) < tm) ? (1u << i) : 0u;
+                    rem &= rem - 1;
+                }
+                const unsigned long long bt = __ballot(pm != 0);
+                if (pm != 0) {
+                    const int pos = __builtin_popcountll(bt & ((1ull << lane) - 1ull));
+                    wl2[2 * pos] = (uint32_t)leaf;
+                    wl2[2 * pos + 1] = pm;
+                }
+                rescan(wl2, __builtin_popcountll(bt));
+                // the leaves' new entries were written by lanes of this wave: make them visible to its other lanes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                cell_from_leaves(cell, false);
+                if (PROF) pc[7] += __builtin_popcountll(bt);
+            }
+        }
+    };
+
     // ---- fold the first `nj` current samples into everything they reach -------------------------------
-    auto apply = [&](int nj) {
+    auto apply = [&](int nj) __attribute__((always_inline)) {
         unsigned long long t0 = 0, t1 = 0;
         if (PROF) t0 = now();
         // 1. group prune: which samples reach this lane's group?
@@ -903,7 +1009,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                 flush(nwork);
                 nwork = 0;
             }
-            if (PROF) pc[7] += cnt;
+            if (PROF && !L3) pc[7] += cnt;
             if (pm != 0) {
                 const int pos = nwork + __builtin_popcountll(bt & ((1ull << lane) - 1ull));
                 wl[2 * pos] = (uint32_t)beta;
@@ -1045,7 +1151,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             // into rank order: lane `rank` receives this candidate (dead lanes keep to themselves, behind)
             const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
             const int dst = (live ? rank : deadpos) * 4;
-            auto perm = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(v))); };
+            auto perm = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(v))); };
             px = perm(cx); py = perm(cy); pz = perm(cz);
             okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
             const int sM = __builtin_amdgcn_ds_permute(dst, cM);
@@ -1267,7 +1373,8 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
 
 struct FbPlan {
-    int ppl, nw, ngpt, nb, nbpad, npad, ng;
+    int ppl, nw, ngpt, nb, nbpad, npad, ng, ncell;
+    bool l3;              // three levels: LDS cells of 16 leaf buckets, leaf table in global memory
     int rb_rows;          // > 0: register-resident kernel with this many rows per wave
     bool segmented;       // one segmented sort for the batch instead of a device sort per element
     bool global64;        // large sets, several elements: one device sort on (element << 32 | key)
@@ -1302,18 +1409,18 @@ bool fb_plan(int b, int n, FbPlan &p)
                 break;
             }
     }
-    p.ppl = 0;
-    for (int ppl : {1, 2, 4, 8, 16})
-        if ((long)FB_NB_MAX * 64 * ppl >= n) {
-            p.ppl = ppl;
-            break;
-        }
-    if (!p.ppl)
-        return false;
-    const int bsz = 64 * p.ppl;
+    // 64-point buckets throughout.  Up to FB_NB_MAX of them the bucket table itself sits in LDS (two levels);
+    // beyond, LDS holds cells of 16 leaf buckets and the leaf table stays in global memory (three levels).
+    p.ppl = 1;
+    const int bsz = 64;
     p.nb = (n + bsz - 1) / bsz;
-    p.nbpad = (p.nb + FB_GS * FB_NW - 1) / (FB_GS * FB_NW) * (FB_GS * FB_NW);       // whole groups per wave
-    p.ng = p.nbpad / FB_GS;
+    p.l3 = p.nb > FB_NB_MAX;
+    if (p.l3 && p.nb > FB_NB_MAX * FB_GS)
+        return false;
+    const int unit = FB_GS * FB_NW * (p.l3 ? FB_GS : 1);                            // whole groups per wave
+    p.nbpad = (p.nb + unit - 1) / unit * unit;
+    p.ncell = p.l3 ? p.nbpad / FB_GS : p.nbpad;
+    p.ng = p.ncell / FB_GS;
     p.npad = p.nb * bsz;
     p.nw = FB_NW;
     p.ngpt = (p.ng + p.nw * 64 - 1) / (p.nw * 64);          // 1 for ng <= 256
@@ -1358,8 +1465,8 @@ int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
 {
     if (p.ngpt != 1)
         return TPU3_ELIMIT;
-    const size_t lds = fm_lds_bytes(p.nbpad, FB_NW);
-    auto kern = fm_main_kernel<FB_NW, PPL, PROF>;
+    const size_t lds = fm_lds_bytes(p.ncell, FB_NW);
+    auto kern = p.l3 ? fm_main_kernel<FB_NW, PPL, PROF, true> : fm_main_kernel<FB_NW, PPL, PROF, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
@@ -1395,7 +1502,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     char *slabs = base + p.sort_bytes;
     char *sort_tmp = slabs + (size_t)b * p.per_elem;
     FbArgs a0;
-    a0.n = n; a0.m = m; a0.nb = p.nb; a0.nbpad = p.nbpad; a0.npad = p.npad; a0.ng = p.ng;
+    a0.n = n; a0.m = m; a0.nb = p.nb; a0.nbpad = p.nbpad; a0.npad = p.npad; a0.ng = p.ng; a0.ncell = p.ncell;
     a0.bsz = 64 * p.ppl; a0.lb = tpu3_fps_log2_bs(n);
     a0.n_arr = n_arr; a0.m_arr = m_arr;
     a0.xyz = xyz; a0.temp = temp; a0.idx = idx; a0.prof = prof;
@@ -1457,27 +1564,8 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
 #undef RB_LAUNCH
         return tpu3_launch_status();
     }
-    const dim3 gi((p.nbpad + 3) / 4, b);
-    switch (p.ppl) {
-    case 1: hipLaunchKernelGGL(fb_bucket_init_kernel<1>, gi, dim3(256), 0, s, a0); break;
-    case 2: hipLaunchKernelGGL(fb_bucket_init_kernel<2>, gi, dim3(256), 0, s, a0); break;
-    case 4: hipLaunchKernelGGL(fb_bucket_init_kernel<4>, gi, dim3(256), 0, s, a0); break;
-    case 8: hipLaunchKernelGGL(fb_bucket_init_kernel<8>, gi, dim3(256), 0, s, a0); break;
-    default: hipLaunchKernelGGL(fb_bucket_init_kernel<16>, gi, dim3(256), 0, s, a0); break;
-    }
-    int r;
-    if (prof) {
-        if (p.ppl != 1) return TPU3_EINVAL;
-        r = fb_launch_main<1, true>(s, b, a0, p);
-    } else {
-        switch (p.ppl) {
-        case 1: r = fb_launch_main<1, false>(s, b, a0, p); break;
-        case 2: r = fb_launch_main<2, false>(s, b, a0, p); break;
-        case 4: r = fb_launch_main<4, false>(s, b, a0, p); break;
-        case 8: r = fb_launch_main<8, false>(s, b, a0, p); break;
-        default: r = fb_launch_main<16, false>(s, b, a0, p); break;
-        }
-    }
+    hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
+    const int r = prof ? fb_launch_main<1, true>(s, b, a0, p) : fb_launch_main<1, false>(s, b, a0, p);
     if (r)
         return r;
     hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);

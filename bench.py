@@ -104,10 +104,10 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
     """One extra UNTIMED single-stream step with events around every hand-written network kernel."""
     be = ops.BACKEND
     kt = KernelTimer(be)
-    kt.wrap("dense_edge_conv", lambda x, idx, off, k, mlps, out: (x.shape[0], x.shape[1], k))
+    kt.wrap("dense_edge_conv", lambda x, idx, off, k, mlps, out, **kw: (x.shape[0], x.shape[1], k))
     kt.wrap("knn_graph", lambda k, x, layout=None: (x.shape[0], x.shape[1], x.shape[2], k))
-    kt.wrap("regress_tail", lambda a, c, *rest: (a.shape[0], c.shape[0]))
-    kt.wrap("linear_small", lambda x, w, b, relu: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
+    kt.wrap("regress_tail", lambda a, c, *rest, **kw: (a.shape[0], c.shape[0]))
+    kt.wrap("linear_small", lambda x, w, b, relu, **kw: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
     kt.wrap("interlevel_skip", lambda xyz, feat, pxyz, pfeat, pts_of, idx, **kw: (feat.shape[0], feat.shape[1],
                                                                                   idx.shape[2], feat.shape[2]))
     kt.wrap("fps", lambda xyz, npoint, n_arr=None, m_arr=None: (xyz.shape[0], xyz.shape[1], npoint))

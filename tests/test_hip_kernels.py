@@ -37,6 +37,9 @@ def test_fps_bit_exact(orc, dev, b, n, m):
                                           # a quarter of the metric's final resampling (239 616 -> 80 000):
                                           # 4.8 G point-rounds of the oracle, multi-core C
                                           (1, 239616, 20000, False),
+                                          # beyond 4096 x 64 points: three levels (LDS cells of 16 leaf buckets,
+                                          # leaf table in global memory) -- the form config C5's 3.83 M points take
+                                          (1, 300000, 4000, False), (2, 270000, 600, False), (1, 400000, 3000, True),
                                           (1, 26000, 26000, False), (3, 25601, 300, False)])
 def test_fps_bucketed_kernel_bit_exact(orc, dev, b, n, m, dups):
     """Point sets beyond the register-resident limit take the Morton-bucket kernel with exact
