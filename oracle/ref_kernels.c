@@ -29,6 +29,9 @@
  * -ffp-contract=off so the compiler adds no contraction of its own.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,8 +109,15 @@ void orc_fps_f32(int b, int n, int m, const float *xyz, float *temp, int32_t *id
              * different host cores (OpenMP) without changing any result: chunk c owns the
              * emulated threads [c*cw, (c+1)*cw) and walks their k in ascending order. */
             const int nchunk = (n >= 8192 && bs >= 64) ? 16 : 1;
+            /* one parallel region per round: more threads than chunks (or than cores) only adds barrier cost */
+            int fps_threads = 1;
+#ifdef _OPENMP
+            fps_threads = omp_get_max_threads();
+#endif
+            if (fps_threads > nchunk)
+                fps_threads = nchunk;
             const int cw = bs / nchunk;
-#pragma omp parallel for schedule(static) if (nchunk > 1)
+#pragma omp parallel for schedule(static) num_threads(fps_threads) if (nchunk > 1)
             for (int c = 0; c < nchunk; ++c)
                 for (int kb = 0; kb < n; kb += bs) {
                     const int hi = (kb + (c + 1) * cw < n) ? kb + (c + 1) * cw : n;
