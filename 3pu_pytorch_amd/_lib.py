@@ -47,6 +47,7 @@ SIGNATURES = {
     "tpu3_regress_tail_f32": (_i, [_vp, ctypes.c_long, _i] + [_vp] * 10 + [_i]),
     "tpu3_knn_unique_compact_i32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_knn_graph_self_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp, _vp, _sz]),
+    "tpu3_knn_graph_self_optimistic_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp]),
     "tpu3_knn_graph_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp]),
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),

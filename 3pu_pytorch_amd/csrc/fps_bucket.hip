@@ -11,21 +11,20 @@
 //           Every bucket / group knows an AABB and its current (max distance, tie key, xyz of that
 //           point).  Bucket table + fp16 (outward-rounded) bucket boxes live in LDS, group boxes in
 //           the owner lane's registers, the group table in LDS.
-//   round   1. every lane tests the groups it owns:  dbox(sample, AABB) >= max  ==> nothing inside
+//   round   1. every lane tests the group it owns:  dbox(sample, AABB) >= max  ==> nothing inside
 //              can change (dbox uses the fp32 association of the point distance and fp32 rounding is
 //              monotone, so dbox <= d(p) for every p inside: min(d(p), temp[p]) == temp[p] exactly);
 //           2. the 16 children of each touched group are tested the same way by one DPP row (up to 4
 //              groups per wave instruction);
-//           3. touched buckets are re-scanned two at a time (64 lanes = 64 points; both buckets'
-//              loads in flight together, the two reduction chains interleaved);
+//           3. touched buckets are re-scanned (64 lanes = 64 points), several at a time with all their loads
+//              in flight, the reduction chains interleaved;
 //           4. the touched groups' entries are rebuilt by a 16-lane row arg-max;
-//           5. arg-max over the group table (fused-DPP wave reduction, one LDS hand-off across the
-//              waves, ONE s_barrier per round) picks the next sample with the reference's tie rule.
+//           5. the group table yields the next sampleS -- several per round, exactly (fm_main_kernel below).
 //
-// One workgroup of NW waves (one per SIMD: the per-round work is a dependent chain, extra waves only
-// add issue pressure -- a 16-wave version of this kernel was issue-bound at 4400 cycles per round)
-// per batch element.  Group g belongs to wave g % NW, so spatially adjacent groups are handled by
-// different waves; every table entry is written and read by the same wave, hence no second barrier.
+// One workgroup of 4 waves (one per SIMD: the per-round work is a dependent chain, extra waves only
+// add issue pressure -- a 16-wave version of the single-sample kernel was issue-bound at 4400 cycles per
+// round) per batch element.  Group g belongs to wave g % 4; every table entry is written and read by the same
+// wave, hence no barrier between update and selection.
 #include "tpu3_dev.h"
 
 #include <hip/hip_fp16.h>
@@ -221,25 +220,8 @@ __device__ __forceinline__ void fb_load(FbBucket<PPL> &b, const float4 *__restri
     }
 }
 
-template <int PPL>
-__device__ __forceinline__ FbCand fb_apply(FbBucket<PPL> &b, float qx, float qy, float qz, bool update)
-{
-    FbCand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
-#pragma unroll
-    for (int p = 0; p < PPL; ++p) {
-        float t = b.v[p].w;
-        if (update)
-            t = fminf(tpu3_sqdist3(b.v[p].x - qx, b.v[p].y - qy, b.v[p].z - qz), t);
-        b.nt[p] = t;
-        if (t > c.t || (t == c.t && b.key[p] < c.key)) {
-            c.t = t; c.key = b.key[p]; c.x = b.v[p].x; c.y = b.v[p].y; c.z = b.v[p].z;
-        }
-    }
-    return c;
-}
-
-// The same for SEVERAL samples at once: lane i of (px, py, pz) holds sample i, `pmask` (wave-uniform)
-// selects the samples to fold in.  Also returns the lane-local runner-up.
+// Fold samples into a loaded bucket: lane i of (px, py, pz) holds sample i, `pmask` (wave-uniform) selects the
+// samples to fold in (0: none, the bucket is only reduced).  Returns the lane-local best and runner-up.
 template <int PPL>
 __device__ __forceinline__ FbCand fm_apply(FbBucket<PPL> &b, uint32_t pmask, float px, float py, float pz,
                                            float &second)
@@ -345,268 +327,6 @@ __device__ __forceinline__ float fb_dbox(float qx, float qy, float qz, float lx,
     const float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
     const float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
     return tpu3_sqdist3(dx, dy, dz);
-}
-
-struct FbSlots {        // cross-wave hand-off, up to 8 waves
-    int d[2][8];
-    uint32_t key[2][8];
-    float x[2][8], y[2][8], z[2][8];
-};
-
-// LDS bytes of the main kernel: 8 words per bucket, 11 per group-table entry, the slots
-constexpr size_t fb_lds_bytes(int nbpad, int nw, int ngpt)
-{
-    return (size_t)nbpad * 32 + (size_t)ngpt * nw * 64 * 11 * 4 + sizeof(FbSlots) + 64;
-}
-
-template <int NW, int NGPT, int PPL, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void fb_main_kernel(FbArgs a0)
-{
-    constexpr int W = NW * 64;
-    constexpr int GT = NGPT * W;                    // group-table entries (owner order)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FbArgs a = fb_elem(a0, blockIdx.x);
-    const int nbpad = a.nbpad, ng = a.ng, lb = a.lb;
-    if (a.n <= 0 || a.m <= 0)
-        return;
-    // Bucket i (64 * PPL consecutive Morton points) belongs to wave i % NW; a wave groups ITS buckets
-    // 16 to a group in order.  Spatially adjacent buckets -- the handful a sample touches -- are thus
-    // re-scanned by different waves in parallel (with groups of 16 consecutive buckets one wave did
-    // most of a round's re-scans while the others waited at the barrier).  The LDS bucket table is
-    // stored wave-major (slot = (i % NW) * Q + i / NW), so a group's children are 16 consecutive words.
-    const int Q = nbpad / NW;
-    // bucket table, indexed by bucket id (a DPP row reads 16 consecutive children)
-    int *t_max = (int *)smem;
-    uint32_t *t_key = (uint32_t *)(t_max + nbpad);
-    float *t_x = (float *)(t_key + nbpad);
-    float *t_y = t_x + nbpad;
-    float *t_z = t_y + nbpad;
-    uint32_t *t_b0 = (uint32_t *)(t_z + nbpad);     // fp16 boxes: lo.x|lo.y, lo.z|hi.x, hi.y|hi.z
-    uint32_t *t_b1 = t_b0 + nbpad;
-    uint32_t *t_b2 = t_b1 + nbpad;
-    // group table in OWNER order (entry of the group owned by lane `l`, slot `j` at j*W + tid):
-    // the per-round read of a wave is 64 consecutive words, no bank conflicts
-    int *g_max = (int *)(t_b2 + nbpad);
-    uint32_t *g_key = (uint32_t *)(g_max + GT);
-    float *g_x = (float *)(g_key + GT);
-    float *g_y = g_x + GT;
-    float *g_z = g_y + GT;
-    float *g_box = g_z + GT;                        // 6 x GT, setup only
-    FbSlots &sl = *(FbSlots *)(g_box + 6 * GT);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = lane >> 4, col = lane & 15;
-    float4 *__restrict__ sp = a.sp;
-    const uint32_t *__restrict__ skey = a.skey;
-
-    // group g  <->  wave g % NW, owner slot g / NW (lane slot % 64, register slot / 64)
-    auto group_entry = [&](int slot) { return (slot >> 6) * W + wave * 64 + (slot & 63); };
-
-    // Rebuild the entries of up to four groups at once: DPP row r handles the group in owner slot
-    // `slot` (per lane; < 0 = row idle).  Row arg-max over the 16 children with the FPS tie rule.
-    auto refresh_groups = [&](int slot, bool with_box) {
-        const bool valid = slot >= 0 && slot * NW + wave < ng;
-        const int beta = valid ? wave * Q + slot * FB_GS + col : 0;         // table index (see below)
-        const int bits = valid ? t_max[beta] : (int)0x80000000;
-        const uint32_t key = valid ? t_key[beta] : 0xFFFFFFFFu;
-        const int rmax = tpu3_row_max_i32_fast(bits);
-        unsigned long long tie = __ballot(valid && bits == rmax);
-        const unsigned long long rows = __ballot(valid && col == 0);
-        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
-            const uint32_t k = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
-            tie = __ballot(valid && bits == rmax && key == k);
-        }
-        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
-        if (valid && ((tie >> lane) & 1ull) && (tie & below) == 0) {
-            const int e = group_entry(slot);
-            g_max[e] = rmax; g_key[e] = key;
-            g_x[e] = t_x[beta]; g_y[e] = t_y[beta]; g_z[e] = t_z[beta];
-        }
-        if (with_box) {     // setup: group AABB = union of the children's (outward-rounded) boxes
-            const uint32_t w0 = valid ? t_b0[beta] : 0, w1 = valid ? t_b1[beta] : 0, w2 = valid ? t_b2[beta] : 0;
-            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
-                          fb_half_hi(w2)};
-            for (int c3 = 0; c3 < 6; ++c3) {
-                if (!valid)
-                    v[c3] = -__builtin_inff();
-                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
-                if (valid && col == 0)
-                    g_box[c3 * GT + group_entry(slot)] = c3 < 3 ? -m : m;
-            }
-        }
-    };
-
-    // ---- setup: bucket table from the init kernel's arrays, then every group's entry + AABB --------
-    for (int i = tid; i < nbpad; i += W) {
-        const int ti = (i % NW) * Q + i / NW;           // bucket i -> table slot
-        t_max[ti] = (int)a.ib[0 * nbpad + i];
-        t_key[ti] = a.ib[1 * nbpad + i];
-        t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
-        t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
-        t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
-        t_b0[ti] = a.ib[5 * nbpad + i];
-        t_b1[ti] = a.ib[6 * nbpad + i];
-        t_b2[ti] = a.ib[7 * nbpad + i];
-    }
-    for (int i = tid; i < GT; i += W) {
-        g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu;
-        g_x[i] = g_y[i] = g_z[i] = 0.f;
-        for (int c3 = 0; c3 < 6; ++c3)
-            g_box[c3 * GT + i] = __builtin_inff();          // lo = hi = +inf: infinitely far away
-    }
-    __syncthreads();
-    for (int s0 = 0; s0 < NGPT * 64; s0 += 4)
-        if ((s0 * NW + wave) < ng)
-            refresh_groups(s0 + row, true);
-    __syncthreads();
-    float gbox[NGPT][6];
-    int gmax[NGPT];
-#pragma unroll
-    for (int j = 0; j < NGPT; ++j) {
-        for (int c3 = 0; c3 < 6; ++c3)
-            gbox[j][c3] = g_box[c3 * GT + j * W + tid];
-        gmax[j] = g_max[j * W + tid];
-    }
-
-    if (tid == 0)
-        a.idx[0] = 0;
-    float qx = a.xyz[0], qy = a.xyz[1], qz = a.xyz[2];
-
-    unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = 1; r < a.m; ++r) {
-        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-        if (PROF) tk0 = __builtin_amdgcn_s_memtime();
-        // ---- 1. group prune --------------------------------------------------------------------------
-        unsigned long long gm[NGPT];
-#pragma unroll
-        for (int j = 0; j < NGPT; ++j)
-            gm[j] = __ballot(fb_dbox(qx, qy, qz, gbox[j][0], gbox[j][1], gbox[j][2], gbox[j][3], gbox[j][4],
-                                     gbox[j][5]) < __int_as_float(gmax[j]));
-        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
-        if (PROF) { ta = __builtin_amdgcn_s_memtime(); pc[8] += ta - tk0; }
-#pragma unroll
-        for (int j = 0; j < NGPT; ++j) {
-            unsigned long long mask = gm[j];
-            while (mask) {
-                // up to four touched groups, one per DPP row
-                int slot = -1;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    if (mask) {
-                        const int l = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        if (row == rr)
-                            slot = j * 64 + l;
-                    }
-                // ---- 2. children test ------------------------------------------------------------------
-                const bool valid = slot >= 0;
-                const int beta = valid ? wave * Q + slot * FB_GS + col : 0;
-                const uint32_t w0 = t_b0[beta], w1 = t_b1[beta], w2 = t_b2[beta];
-                const float db = fb_dbox(qx, qy, qz, fb_half_lo(w0), fb_half_hi(w0), fb_half_lo(w1), fb_half_hi(w1),
-                                         fb_half_lo(w2), fb_half_hi(w2));
-                unsigned long long bt = __ballot(valid && db < __int_as_float(t_max[beta]));
-                if (PROF) { tb = __builtin_amdgcn_s_memtime(); pc[9] += tb - ta; }
-                // ---- 3. re-scan the touched buckets two at a time (an odd one out twice: idempotent) ---
-                while (bt) {
-                    const int p0 = __builtin_ctzll(bt);
-                    bt &= bt - 1;
-                    int p1 = p0;
-                    if (bt) {
-                        p1 = __builtin_ctzll(bt);
-                        bt &= bt - 1;
-                    }
-                    const int b0 = __builtin_amdgcn_readlane(beta, p0), b1 = __builtin_amdgcn_readlane(beta, p1);
-                    const int d0 = (b0 - wave * Q) * NW + wave, d1 = (b1 - wave * Q) * NW + wave;    // bucket ids
-                    FbBucket<PPL> k0, k1;
-                    fb_load<PPL>(k0, sp, skey, d0, lane);
-                    fb_load<PPL>(k1, sp, skey, d1, lane);
-                    const FbCand c0 = fb_apply<PPL>(k0, qx, qy, qz, true);
-                    const FbCand c1 = fb_apply<PPL>(k1, qx, qy, qz, true);
-                    int m0 = __float_as_int(c0.t), m1 = __float_as_int(c1.t);
-                    if (PROF) { asm volatile("" :: "v"(m0), "v"(m1)); tc = __builtin_amdgcn_s_memtime(); pc[10] += tc - tb; }
-                    tpu3_wave_max_i32_fast_x2(m0, m1);
-                    unsigned long long t0 = __ballot(__float_as_int(c0.t) == m0);
-                    unsigned long long t1 = __ballot(__float_as_int(c1.t) == m1);
-                    if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
-                        const uint32_t k = tpu3_wave_min_u32(__float_as_int(c0.t) == m0 ? c0.key : 0xFFFFFFFFu);
-                        t0 = __ballot(__float_as_int(c0.t) == m0 && c0.key == k);
-                    }
-                    if (__builtin_popcountll(t1) != 1) {
-                        const uint32_t k = tpu3_wave_min_u32(__float_as_int(c1.t) == m1 ? c1.key : 0xFFFFFFFFu);
-                        t1 = __ballot(__float_as_int(c1.t) == m1 && c1.key == k);
-                    }
-                    if (lane == (int)__builtin_ctzll(t0)) {
-                        t_max[b0] = m0; t_key[b0] = c0.key; t_x[b0] = c0.x; t_y[b0] = c0.y; t_z[b0] = c0.z;
-                    }
-                    if (lane == (int)__builtin_ctzll(t1)) {
-                        t_max[b1] = m1; t_key[b1] = c1.key; t_x[b1] = c1.x; t_y[b1] = c1.y; t_z[b1] = c1.z;
-                    }
-                    fb_store<PPL>(k0, sp, d0, lane);        // stores last, off the dependent chain
-                    if (b1 != b0)
-                        fb_store<PPL>(k1, sp, d1, lane);
-                    if (PROF) pc[5] += 1 + (b1 != b0);
-                    if (PROF) { tb = __builtin_amdgcn_s_memtime(); pc[11] += tb - tc; }
-                }
-                // ---- 4. rebuild the touched groups' entries ------------------------------------------------
-                if (PROF) td = __builtin_amdgcn_s_memtime();
-                refresh_groups(slot, false);
-                if (PROF) { ta = __builtin_amdgcn_s_memtime(); pc[12] += ta - td; }
-                if (PROF) pc[6] += 1;
-            }
-        }
-        if (PROF) tk1 = __builtin_amdgcn_s_memtime();
-        // ---- 5. arg-max over the group table ----------------------------------------------------------
-        int best = (int)0x80000000, bj = 0;
-        uint32_t bkey = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < NGPT; ++j) {
-            const int v = g_max[j * W + tid];
-            const uint32_t k = g_key[j * W + tid];
-            gmax[j] = v;
-            if (v > best || (v == best && k < bkey)) {
-                best = v; bkey = k; bj = j;
-            }
-        }
-        const int par = r & 1;
-        int wl;
-        const int wmax = tpu3_wave_argmax(best, bkey, wl);
-        if (lane == wl) {
-            const int e = bj * W + tid;
-            sl.d[par][wave] = wmax;
-            sl.key[par][wave] = bkey;
-            sl.x[par][wave] = g_x[e];
-            sl.y[par][wave] = g_y[e];
-            sl.z[par][wave] = g_z[e];
-        }
-        if (PROF) tk2 = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        if (PROF) tk3 = __builtin_amdgcn_s_memtime();
-        const int sd = lane < NW ? sl.d[par][lane] : (int)0x80000000;
-        const uint32_t sk = lane < NW ? sl.key[par][lane] : 0xFFFFFFFFu;
-        // lane l < NW holds wave l's whole slot: the winner's coordinates come by readlane, not by a
-        // second LDS round trip
-        const float sx = sl.x[par][lane & (NW - 1)], sy = sl.y[par][lane & (NW - 1)], sz = sl.z[par][lane & (NW - 1)];
-        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-        unsigned long long who = __ballot(lane < NW && sd == gbest);
-        if (__builtin_popcountll(who) != 1) {
-            const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
-            const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
-            who = __ballot(lane < NW && sd == gbest && sk == win);
-        }
-        const int ww = __builtin_ctzll(who | (1ull << 63)) & 7;
-        qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), ww));
-        qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), ww));
-        qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), ww));
-        if (tid == 0)
-            a.idx[r] = tpu3_fps_tiekey_to_index((uint32_t)__builtin_amdgcn_readlane((int)sk, ww), lb);
-        if (PROF) {
-            const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
-            pc[0] += tk1 - tk0; pc[1] += tk2 - tk1; pc[2] += tk3 - tk2; pc[3] += tk4 - tk3;
-        }
-    }
-    if (PROF && lane == 0 && a.prof)
-        for (int i = 0; i < 16; ++i)
-            a.prof[wave * 16 + i] = pc[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1457,7 +1177,7 @@ bool fb_plan(int b, int n, FbPlan &p)
 }
 
 // measurement hook (bench.py): events recorded on the launch stream immediately around the next
-// fb_main_kernel launch, see tpu3_debug_fps_bucket_events
+// fm_main_kernel launch, see tpu3_debug_fps_bucket_events
 hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
 template <int PPL, bool PROF>
@@ -1589,7 +1309,7 @@ int tpu3_fps_bucket_launch(hipStream_t s, int b, int n, int m, const int32_t *n_
 }
 
 // Measurement hook (not part of include/tpu3.h): the NEXT bucketed-FPS call records `start` / `stop`
-// (hipEvent_t, created by the caller) on its stream right before / after fb_main_kernel, so that a
+// (hipEvent_t, created by the caller) on its stream right before / after fm_main_kernel, so that a
 // caller can time exactly that kernel on whatever stream it runs.  One-shot; host-side state only.
 extern "C" int tpu3_debug_fps_bucket_events(void *start, void *stop)
 {

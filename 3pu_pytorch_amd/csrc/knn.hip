@@ -1216,6 +1216,40 @@ extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c
     return dispatch_insert(s, b, a);
 }
 
+// Optimistic form of the self graph: ONLY the two-pass kernel, no de-duplication state, no gated launches
+// behind it (five tiny launches per call that, on a busy GPU, each wait for a compute unit: ~0.8 ms of
+// stream time apiece under the bench's eight streams).  If some query saw a second zero distance -- rows
+// may be duplicated -- the kernel raises events[2]; the result of that call must then be recomputed by
+// tpu3_knn_graph_self_f32.  `events`: 4 u32 device words zeroed once by the caller, shared by any number of
+// calls (events[0] must stay 0); the caller inspects events[2] at its own synchronisation point.
+extern "C" int tpu3_knn_graph_self_optimistic_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
+                                                  const tpu3_knn_layout *layout, uint32_t *events, int32_t *idx)
+{
+    if (bad_dims(b, n, n, c, k)) return TPU3_EINVAL;
+    if (c > 32 || (k != 17 && k != 33)) return TPU3_ELIMIT;
+    if (b == 0 || n == 0) return TPU3_OK;
+    if (k > n) return TPU3_EINVAL;
+    if (!x || !idx || !events) return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    const tpu3_knn_layout L = layout ? *layout : tpu3_knn_layout{nullptr, nullptr, nullptr, nullptr, b, 1};
+    if (L.pts_of || L.n_arr || L.m_arr) return TPU3_EINVAL;      // dense self query only
+    hipStream_t s = (hipStream_t)stream;
+    KnnArgs a{n, n, c, k, b, 1, x, x, nullptr, nullptr, nullptr, L.grp, nullptr, events, 2, 0, idx, 0, nullptr};
+    int threads = ((n + 63) / 64) * 64;
+    if (threads > 512) threads = 256;
+    const dim3 g((n + threads - 1) / threads, b);
+#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+    if (k == 33) {
+        if (c == 3) KG(3, 33); else if (c <= 8) KG(8, 33); else if (c <= 16) KG(16, 33);
+        else if (c <= 24) KG(24, 33); else KG(32, 33);
+    } else {
+        if (c == 3) KG(3, 17); else if (c <= 8) KG(8, 17); else if (c <= 16) KG(16, 17);
+        else if (c <= 24) KG(24, 17); else KG(32, 17);
+    }
+#undef KG
+    return tpu3_launch_status();
+}
+
 extern "C" int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,
                                   const float *points, const tpu3_knn_layout *layout, const uint8_t *dup,
                                   uint32_t *uws, int32_t *idx)

@@ -86,8 +86,8 @@ class DenseEdgeConv(nn.Module):
             if need_grad and x.is_cuda and x.dtype == torch.float32 and hasattr(operations.BACKEND, "knn_graph"):
                 # training: only the neighbour SET matters (the nearest is dropped, the rest is max-pooled),
                 # so the graph kernel serves here too; None = configuration it does not cover
-                with torch.no_grad():
-                    full = operations.BACKEND.knn_graph(k + 1, x.detach().contiguous(), layout)
+                with torch.no_grad():      # (exact form: nobody inspects the optimistic events in a training loop)
+                    full = operations.BACKEND.knn_graph(k + 1, x.detach().contiguous(), layout, optimistic=False)
             if full is not None:
                 idx, knn_point = full.long(), None
             else:

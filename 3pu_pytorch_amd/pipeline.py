@@ -89,7 +89,8 @@ def shard_range(total, rank, world):
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
              timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, check_small=None):
-    """See _upsample.  check_small: after enqueueing, synchronise and raise if the outlier filter left
+    """See _upsample.  check_small: after enqueueing, synchronise, (i) recompute with the exact kNN-graph form if
+    an optimistic graph call reported possibly duplicated feature rows, and (ii) raise if the outlier filter left
     some cloud with fewer points than a patch at some level (the batched path does not reproduce the
     reference's shrunken k there, network/upsampler.py:75-78).  Default: on for plain calls, off when
     the caller overlaps work on side streams (fps_stream / net_streams) -- such callers (bench.py)
@@ -98,8 +99,20 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
         check_small = fps_stream is None and not net_streams
     if check_small and hasattr(net, "reset_small_cloud_events"):
         net.reset_small_cloud_events()
+    be = operations.BACKEND
+    if check_small and hasattr(be, "graph_dup_events"):
+        be.graph_dup_events(reset=True)
     out = _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
                     net_streams, sub_batch, fps_offset)
+    if check_small and hasattr(be, "graph_dup_events") and be.graph_dup_events(reset=True):
+        # an optimistic feature-space kNN graph met (possibly) duplicated rows: recompute with the exact form
+        saved = be.optimistic_graph
+        be.optimistic_graph = False
+        try:
+            out = _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
+                            net_streams, sub_batch, fps_offset)
+        finally:
+            be.optimistic_graph = saved
     if check_small and hasattr(net, "small_cloud_events"):
         bad = net.small_cloud_events
         if bad:

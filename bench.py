@@ -417,6 +417,7 @@ def main():
     total_clouds = 1 if patch_mode else world * C
     assert tuple(out.shape) == (total_clouds, 3, N * r) and bool(torch.isfinite(out).all())
     assert int(net.small_cloud_events) == 0
+    assert ops.BACKEND.graph_dup_events() == 0, "an optimistic kNN graph asked for the exact path: result not final"
     assert not ops.GENERIC_PATH_EVENTS, "generic (unfused) path taken in the measured run: %r" % dict(ops.GENERIC_PATH_EVENTS)
 
     # all-gather bus bandwidth (N > 1): (P-1)/P * gathered bytes / time, 10 back-to-back gathers

@@ -184,6 +184,14 @@ int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, co
                             const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,
                             void *workspace, size_t workspace_bytes);
 
+/* Optimistic form of the call above: only the two-pass graph kernel -- no scratch, no gated fallback
+ * launches behind it.  If some query saw a second zero distance (rows may be duplicated) events[2] is set to 1
+ * and the result of THAT call is not guaranteed: recompute it with tpu3_knn_graph_self_f32.  events: 4 u32
+ * device words zeroed once by the caller and shared by any number of calls (events[0] must stay 0); the caller
+ * reads events[2] at its own synchronisation point. */
+int tpu3_knn_graph_self_optimistic_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
+                                       const tpu3_knn_layout *layout, uint32_t *events, int32_t *idx);
+
 /* unique=True pre-pass: dup (bp,n) u8 = 1 iff an identical row exists at a smaller index of
  * the same point set (complement of np.unique(axis=0, return_index=True), operations.py:194-200).
  * O(n) per point set (open-addressing table of class representatives) above 1024 points,

@@ -411,12 +411,23 @@ def test_knn_graph_is_the_exact_topk_set(orc, dev, b, n, c, k, dups):
     if not dups:
         x[0, :min(50, n // 2)] = 0
         x[0, :min(50, n // 2), 0] = np.arange(min(50, n // 2), dtype=np.float32)
-    idx = ops.BACKEND.knn_graph(k, _t(x, dev)).cpu().numpy()
     ri, _ = orc.knn(k, x, x, True)
+    # exact form: the gated hash de-duplication + exact kernels take over when rows are duplicated
+    idx = ops.BACKEND.knn_graph(k, _t(x, dev), optimistic=False).cpu().numpy()
     np.testing.assert_array_equal(idx[:, :, 0], ri[:, :, 0])
     np.testing.assert_array_equal(np.sort(idx[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
     if not dups:
         assert (np.diff(idx[:, :, 1:], axis=-1) > 0).all()
+    # optimistic form (what the inference path launches): only the two-pass kernel; exact whenever no event is
+    # raised, and an event MUST be raised when rows are duplicated
+    ops.BACKEND.graph_dup_events(reset=True)
+    opt = ops.BACKEND.knn_graph(k, _t(x, dev), optimistic=True).cpu().numpy()
+    events = ops.BACKEND.graph_dup_events(reset=True)
+    if dups:
+        assert events == 1
+    else:
+        assert events == 0
+        np.testing.assert_array_equal(opt, idx)
 
 
 @pytest.mark.parametrize("n", [700, 1500])

@@ -406,6 +406,36 @@ def test_pipeline_on_device_against_reference_driver(orc, dev):
     assert _set_close(orc, final, g["final"]) >= 0.99
 
 
+def test_pipeline_recomputes_when_an_optimistic_graph_reports_duplicates(orc, dev):
+    """The inference path launches the feature-space kNN graphs optimistically (no gated fallback launches).
+    A cloud with duplicated points makes duplicated feature rows: the event must be seen by pipeline.upsample,
+    which recomputes with the exact form -- same result as running the exact form from the start."""
+    pipe, ops = pkg("pipeline"), pkg("network.operations")
+    net = _net(dev)
+    base = sphere(77, 800)
+    cloud = np.concatenate([base, base[:, :200]], axis=1)                    # 200 duplicated points
+    x = torch.from_numpy(np.ascontiguousarray(cloud.transpose(0, 2, 1))).to(dev)
+    be = ops.BACKEND
+    calls = []
+    real = be.knn_graph
+
+    def spy(k, xx, layout=None, optimistic=None):
+        calls.append(be.optimistic_graph if optimistic is None else optimistic)
+        return real(k, xx, layout, optimistic)
+    be.knn_graph = spy
+    try:
+        out = pipe.upsample(net, x, 312, 2, 3)
+    finally:
+        del be.knn_graph
+    assert True in calls and False in calls                  # optimistic first, exact on the recomputation
+    be.optimistic_graph = False
+    try:
+        ref = pipe.upsample(net, x, 312, 2, 3)
+    finally:
+        be.optimistic_graph = True
+    assert torch.equal(out, ref)
+
+
 def test_pipeline_concurrent_sub_batches_and_side_stream(orc, dev):
     """upsample(net_streams=..., fps_stream=...): clouds split over concurrent streams, final FPS on
     a side stream.  Every cloud is independent, so the result must be the single-stream one up to
