@@ -1088,6 +1088,302 @@ __global__ __launch_bounds__(1024) void rb_main_kernel(FbArgs a0)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The register-resident form with several samples per round (same scheme as fm_main_kernel: cells = the
+// 64-point rows; every row record also carries its runner-up; rows whose best beats every runner-up bound are
+// candidates, at most RM_WCAP per wave; one barrier per round; every wave ranks the <= 32 candidates itself).
+// ---------------------------------------------------------------------------------------------
+constexpr int RM_EW = 8;            // words per candidate entry (5 used)
+
+struct RmShared {
+    FmHeader h[2][16];
+    uint32_t cand[2][FM_CAP * RM_EW];
+    float pick[2][FM_CAP][4];           // the round's samples in order (x, y, z, tie key), written by wave 0
+    int npick[2];
+};
+
+constexpr size_t rm_lds_bytes(int rows)
+{
+    return (size_t)rows * 64 * 4 + (size_t)rows * 6 * 4 + sizeof(RmShared) + 64;
+}
+
+// NW waves x R rows each.  16 waves of up to 20 rows (128 registers per lane); the largest sets (<= 25 600 points)
+// take 8 waves of 50 rows (two waves per SIMD, 256 registers per lane) -- 25 rows of points plus the selection
+// state do not fit 128 registers.
+template <int R, int NW>
+__global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
+{
+    constexpr int ROWS = NW * R;
+    constexpr int RM_WCAP = FM_CAP / NW;    // candidates a wave may enter per round
+    static_assert(NW == 16 || NW == 8, "waves per workgroup");
+    static_assert(R <= 64, "a lane per row");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: tie keys [wave][slot][lane] and row records [wave][slot]{max, key, x, y, z, runner-up}: everything a
+    // wave touches in the round loop is its own base address plus a compile-time offset
+    uint32_t *skl = (uint32_t *)smem;
+    uint32_t *tbl = skl + ROWS * 64;
+    RmShared &sh = *(RmShared *)(tbl + ROWS * 6);
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    if (a.n <= 0 || a.m <= 0)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = a.lb;
+    uint32_t *kw = skl + wave * R * 64 + lane;      // this lane's keys: kw[64 * j]
+    uint32_t *tw = tbl + wave * R * 6;              // this wave's records: tw[6 * j + field]
+
+    // row r = 16 * slot + wave (neighbouring rows go to different waves); lane l holds point 64 r + l
+    float px[R], py[R], pz[R], pt[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int slot = (j * NW + wave) * 64 + lane;
+        float4 v = make_float4(0.f, 0.f, 0.f, -1.0f);
+        uint32_t key = 0xFFFFFFFFu;
+        if (slot < a0.npad) {
+            v = a.sp[slot];
+            key = a.skey[slot];
+        }
+        px[j] = v.x; py[j] = v.y; pz[j] = v.z; pt[j] = v.w;
+        kw[64 * j] = key;
+    }
+    // Row records and boxes come from the bucket-init kernel (a row is a 64-point bucket); lane j < R
+    // keeps row j's AABB (fp16, rounded outward, packed), current maximum and runner-up in registers
+    for (int i = tid; i < ROWS; i += NW * 64) {
+        const int w = i / R, j = i - w * R, row = j * NW + w;
+        const bool in = row < a0.nbpad;
+        tbl[i * 6 + 0] = in ? a.ib[0 * a0.nbpad + row] : 0x80000000u;
+        tbl[i * 6 + 1] = in ? a.ib[1 * a0.nbpad + row] : 0xFFFFFFFFu;
+        tbl[i * 6 + 2] = in ? a.ib[2 * a0.nbpad + row] : 0u;
+        tbl[i * 6 + 3] = in ? a.ib[3 * a0.nbpad + row] : 0u;
+        tbl[i * 6 + 4] = in ? a.ib[4 * a0.nbpad + row] : 0u;
+        tbl[i * 6 + 5] = in ? a.ib[8 * a0.nbpad + row] : 0x80000000u;
+    }
+    uint32_t bw0, bw1, bw2;
+    int rowmax = (int)0x80000000, rowrun = (int)0x80000000;
+    {
+        const int row = min(lane, R - 1) * NW + wave;
+        const bool in = lane < R && row < a0.nbpad;
+        const uint32_t pinf = 0x7C00u | (0x7C00u << 16);
+        bw0 = in ? a.ib[5 * a0.nbpad + row] : pinf;
+        bw1 = in ? a.ib[6 * a0.nbpad + row] : pinf;
+        bw2 = in ? a.ib[7 * a0.nbpad + row] : pinf;
+        rowmax = in ? (int)a.ib[0 * a0.nbpad + row] : (int)0x80000000;
+        rowrun = in ? (int)a.ib[8 * a0.nbpad + row] : (int)0x80000000;
+    }
+    __syncthreads();
+
+    if (tid == 0)
+        a.idx[0] = 0;
+    // current samples: lane i < J holds sample i; start with point 0
+    float sx = a.xyz[0], sy = a.xyz[1], sz = a.xyz[2];
+    int J = 1, r = 1, rstar = 0x7FFFFFFF;
+    auto rl = [](float v, int i) __attribute__((always_inline)) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    };
+
+    // re-scan of slot j (compile-time j) with the samples of `pm` folded in: row arg-max with the FPS tie rule
+    // and the row's runner-up, published to the row's record; returns both (wave-uniform)
+    auto rescan = [&](auto jc, uint32_t pm, int &wrun) __attribute__((always_inline)) -> int {
+        constexpr int j = decltype(jc)::value;
+        float t = pt[j];
+        while (pm) {
+            const int i = __builtin_ctz(pm);
+            pm &= pm - 1;
+            t = fminf(tpu3_sqdist3(px[j] - rl(sx, i), py[j] - rl(sy, i), pz[j] - rl(sz, i)), t);
+        }
+        pt[j] = t;
+        const int bits = __float_as_int(t);
+        const int wmax = tpu3_wave_max_i32_fast(bits);
+        unsigned long long tie = __ballot(bits == wmax);
+        if (__builtin_popcountll(tie) != 1) {                    // duplicated points: smallest tie key
+            const uint32_t k = kw[64 * j];
+            const uint32_t kmin = tpu3_wave_min_u32(bits == wmax ? k : 0xFFFFFFFFu);
+            tie = __ballot(bits == wmax && k == kmin);
+        }
+        const bool win = lane == (int)__builtin_ctzll(tie);
+        wrun = tpu3_wave_max_i32_fast(win ? (int)0x80000000 : bits);
+        if (win) {
+            tw[6 * j + 0] = (uint32_t)wmax; tw[6 * j + 1] = kw[64 * j];
+            tw[6 * j + 2] = __float_as_uint(px[j]); tw[6 * j + 3] = __float_as_uint(py[j]);
+            tw[6 * j + 4] = __float_as_uint(pz[j]); tw[6 * j + 5] = (uint32_t)wrun;
+        }
+        return wmax;
+    };
+
+    // fold the first nj current samples into every row they reach
+    auto apply = [&](int nj) __attribute__((always_inline)) {
+        uint32_t pm = 0;
+        {   // (the row's box stays packed in three registers between rounds: 25 rows of points leave no room)
+            const float blx = fb_half_lo(bw0), bly = fb_half_hi(bw0), blz = fb_half_lo(bw1);
+            const float bhx = fb_half_hi(bw1), bhy = fb_half_lo(bw2), bhz = fb_half_hi(bw2);
+            for (int i = 0; i < nj; ++i)
+                pm |= (lane < R && fb_dbox(rl(sx, i), rl(sy, i), rl(sz, i), blx, bly, blz, bhx, bhy, bhz) <
+                                       __int_as_float(rowmax)) ? (1u << i) : 0u;
+        }
+        const unsigned long long mask = __ballot(pm != 0);
+        if (mask)
+            rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+                if ((mask >> decltype(jc)::value) & 1ull) {
+                    int wr;
+                    const int wm = rescan(jc, (uint32_t)__builtin_amdgcn_readlane((int)pm, decltype(jc)::value), wr);
+                    rowmax = lane == decltype(jc)::value ? wm : rowmax;
+                    rowrun = lane == decltype(jc)::value ? wr : rowrun;
+                }
+            });
+    };
+
+    if (a.m > 1)
+        for (int round = 0;; ++round) {
+            apply(J);
+            // ---- select the next samples -------------------------------------------------------------
+            const int par = round & 1;
+            uint32_t *cl = sh.cand[par];
+            const int lj = min(lane, R - 1);
+            const uint32_t rk = tw[6 * lj + 1];
+            const float rx = __uint_as_float(tw[6 * lj + 2]), ry = __uint_as_float(tw[6 * lj + 3]);
+            const float rz = __uint_as_float(tw[6 * lj + 4]);
+            const int mine = lane < R ? rowmax : (int)0x80000000;
+            {
+                int wlane;
+                const int wv = tpu3_wave_argmax(mine, rk, wlane);
+                const int wr = tpu3_wave_max_i32_fast(lane < R ? rowrun : (int)0x80000000);
+                bool is_cand = mine > rstar;
+                unsigned long long cm = __ballot(is_cand);
+                int drop = (int)0x80000000;
+                if (__builtin_popcountll(cm) > RM_WCAP) {
+                    int lrank = 0;
+                    for (unsigned long long mm = cm; mm;) {
+                        const int i = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const int mi = __builtin_amdgcn_readlane(mine, i);
+                        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)rk, i);
+                        lrank += (mi > mine || (mi == mine && ki < rk)) ? 1 : 0;
+                    }
+                    const bool keep = is_cand && lrank < RM_WCAP;
+                    drop = tpu3_wave_max_i32_fast(is_cand && !keep ? mine : (int)0x80000000);
+                    is_cand = keep;
+                    cm = __ballot(is_cand);
+                }
+                if (is_cand) {
+                    uint32_t *e = cl + (wave * RM_WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RM_EW;
+                    e[0] = (uint32_t)mine; e[1] = rk;
+                    e[2] = __float_as_uint(rx); e[3] = __float_as_uint(ry); e[4] = __float_as_uint(rz);
+                }
+                if (lane == wlane) {
+                    FmHeader &h = sh.h[par][wave];
+                    h.best = wv; h.key = rk; h.x = rx; h.y = ry; h.z = rz;
+                    h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
+                }
+            }
+            __syncthreads();
+            // With 16 (8) waves on 4 SIMDs a ranking repeated by every wave would be issue-bound: wave 0 ranks,
+            // the others wait at a second barrier and read the round's samples from LDS.
+            const int left = a.m - r;
+            if (wave == 0) {
+                const FmHeader &hh = sh.h[par][lane & (NW - 1)];
+                const int sd = lane < NW ? hh.best : (int)0x80000000;
+                const uint32_t sk = lane < NW ? hh.key : 0xFFFFFFFFu;
+                const int sr = lane < NW ? hh.rmax : (int)0x80000000;
+                const int sdrop = lane < NW ? hh.drop : (int)0x80000000;
+                const float hx = hh.x, hy = hh.y, hz = hh.z;
+                const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+                const int nrstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+                const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
+                // candidate `lane` of the list: wave lane / RM_WCAP, entry lane % RM_WCAP
+                const bool live = lane < FM_CAP && (lane % RM_WCAP) < sh.h[par][(lane / RM_WCAP) & (NW - 1)].count;
+                const unsigned long long lm = __ballot(live);
+                const int total = __builtin_popcountll(lm);
+                float qx, qy, qz;
+                uint32_t okey;
+                int nj;
+                if (total < 2) {
+                    // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
+                    unsigned long long who = __ballot(lane < NW && sd == gbest);
+                    if (__builtin_popcountll(who) != 1) {
+                        const uint32_t wk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
+                        const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)wk, 0);
+                        who = __ballot(lane < NW && sd == gbest && sk == win);
+                    }
+                    const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
+                    qx = rl(hx, ww); qy = rl(hy, ww); qz = rl(hz, ww);
+                    okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
+                    nj = 1;
+                } else {
+                    const uint32_t *e = cl + (lane & (FM_CAP - 1)) * RM_EW;
+                    const int cM = live ? (int)e[0] : (int)0x80000000;
+                    const uint32_t cK = live ? e[1] : 0xFFFFFFFFu;
+                    const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
+                    int rank = 0;
+                    bool tie = false;
+                    for (unsigned long long mm = lm; mm;) {
+                        const int i = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const int mi = __builtin_amdgcn_readlane(cM, i);
+                        rank += mi > cM ? 1 : 0;
+                        tie |= (mi == cM && i != lane);
+                    }
+                    if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
+                        rank = 0;
+                        for (unsigned long long mm = lm; mm;) {
+                            const int i = __builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const int mi = __builtin_amdgcn_readlane(cM, i);
+                            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
+                            rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
+                        }
+                    }
+                    const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
+                    const int dst = (live ? rank : deadpos) * 4;
+                    qx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cx)));
+                    qy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cy)));
+                    qz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cz)));
+                    okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
+                    const int sM = __builtin_amdgcn_ds_permute(dst, cM);
+                    int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
+                    jmax = jmax < 1 ? 1 : jmax;
+                    jmax = jmax < left ? jmax : left;
+                    for (int i = 0; i + 1 < jmax; ++i) {
+                        const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
+                        const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
+                        if (hit) {
+                            const int f = __builtin_ctzll(hit);
+                            jmax = f < jmax ? f : jmax;
+                        }
+                    }
+                    nj = jmax;
+                }
+                nj = nj < left ? nj : left;
+                if (lane < FM_CAP) {
+                    sh.pick[par][lane][0] = qx; sh.pick[par][lane][1] = qy; sh.pick[par][lane][2] = qz;
+                }
+                if (lane < nj)
+                    a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
+                if (lane == 0) {
+                    sh.npick[par] = nj;
+                    sh.h[par][0].rmax = nrstar;             // (every wave picks the new bound up from here)
+                }
+            }
+            __syncthreads();
+            J = sh.npick[par];
+            rstar = sh.h[par][0].rmax;
+            sx = sh.pick[par][lane & (FM_CAP - 1)][0];
+            sy = sh.pick[par][lane & (FM_CAP - 1)][1];
+            sz = sh.pick[par][lane & (FM_CAP - 1)][2];
+            r += J;
+            if (r >= a.m) {
+                if (J > 1)
+                    apply(J - 1);                       // every sample but the last one updates `temp`
+                break;
+            }
+        }
+    // final running distances, back in the caller's order
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t key = kw[64 * j];
+        if (key != 0xFFFFFFFFu)
+            a.temp[tpu3_fps_tiekey_to_index(key, lb)] = pt[j];
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
@@ -1120,14 +1416,16 @@ using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 
 bool fb_plan(int b, int n, FbPlan &p)
 {
-    p.rb_rows = 0;
+    p.rb_rows = 0;                  // rows per wave for 16 waves (<= 20), or 50 = the 8-wave form
     if (n <= RB_MAX_N) {
         const int rows = ((n + 63) / 64 + 15) / 16;
-        for (int r : {4, 7, 10, 13, 16, 20, 25})
+        for (int r : {4, 7, 10, 13, 16, 20})
             if (r >= rows) {
                 p.rb_rows = r;
                 break;
             }
+        if (!p.rb_rows)
+            p.rb_rows = 50;
     }
     // 64-point buckets throughout.  Up to FB_NB_MAX of them the bucket table itself sits in LDS (two levels);
     // beyond, LDS holds cells of 16 leaf buckets and the leaf table stays in global memory (three levels).
@@ -1265,21 +1563,35 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     if (p.rb_rows && !prof && p.ppl == 1) {
         // the set fits the register file: rows (= 64-point buckets) in VGPRs, no write-back pass
         hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
-        const size_t lds = rb_lds_bytes(p.rb_rows);
+        const int rm_nw = p.rb_rows == 50 ? 8 : 16;
+        const size_t lds = rm_lds_bytes(rm_nw * p.rb_rows);
         hipError_t e = hipSuccess;
-#define RB_LAUNCH(RR)                                                                                    \
-    e = hipFuncSetAttribute((const void *)rb_main_kernel<RR>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+#define RB_LAUNCH(RR, WW)                                                                                \
+    e = hipFuncSetAttribute((const void *)rm_main_kernel<RR, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds);                                                                   \
     if (e != hipSuccess) return (int)e;                                                                  \
-    hipLaunchKernelGGL(rb_main_kernel<RR>, dim3(b), dim3(1024), lds, s, a0)
+    hipLaunchKernelGGL((rm_main_kernel<RR, WW>), dim3(b), dim3(WW * 64), lds, s, a0)
+        // (sparse resampling of small sets yields ~1 candidate per round: below 8 rows per wave the plain
+        // one-sample-per-round kernel is faster -- 1.75 vs 2.28 ms for 384 sets of 6240 -> 1248)
+        if (p.rb_rows <= 7) {
+            const size_t lds1 = rb_lds_bytes(p.rb_rows);
+            if (p.rb_rows == 4) {
+                e = hipFuncSetAttribute((const void *)rb_main_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(rb_main_kernel<4>, dim3(b), dim3(1024), lds1, s, a0);
+            } else {
+                e = hipFuncSetAttribute((const void *)rb_main_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(rb_main_kernel<7>, dim3(b), dim3(1024), lds1, s, a0);
+            }
+            return tpu3_launch_status();
+        }
         switch (p.rb_rows) {
-        case 4: RB_LAUNCH(4); break;
-        case 7: RB_LAUNCH(7); break;
-        case 10: RB_LAUNCH(10); break;
-        case 13: RB_LAUNCH(13); break;
-        case 16: RB_LAUNCH(16); break;
-        case 20: RB_LAUNCH(20); break;
-        default: RB_LAUNCH(25); break;
+        case 10: RB_LAUNCH(10, 16); break;
+        case 13: RB_LAUNCH(13, 16); break;
+        case 16: RB_LAUNCH(16, 16); break;
+        case 20: RB_LAUNCH(20, 16); break;
+        default: RB_LAUNCH(50, 8); break;
         }
 #undef RB_LAUNCH
         return tpu3_launch_status();
