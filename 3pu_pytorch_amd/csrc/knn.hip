@@ -366,8 +366,8 @@ __device__ __forceinline__ void kg_dist(const float4 *tile, const float *rps, in
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (i == 0)
-                    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(p[g].x), "v"(q[0]));
+                if (i == 0)     // (s_nop: the compiler may have copied an operand into place with a v_mov just before)
+                    asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc[g]) : "v"(p[g].x), "v"(q[0]));
                 else
                     asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(p[g].x), "v"(q[4 * i]));
             }
@@ -611,6 +611,202 @@ __global__ __launch_bounds__(512, 4) void knn_graph_kernel(KnnArgs a)
                 w &= ~bit;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self kNN graph in ONE pass: the candidate index rides in the low mantissa bits
+// ---------------------------------------------------------------------------------------------
+// The two-pass kernel above computes every distance twice (pass 2 re-derives them to find the indices:
+// ~35 % of its time).  For a SELF query the indices can travel through the sorting networks instead:
+//     key = (bits(D) with the low IB bits cleared) | j          IB = ceil(log2 n), signed-int order
+// The query's own row is left out (it is the nearest by definition: D == 0 exactly for identical rows), the
+// list keeps the L = k - 1 smallest keys of the others and `e` the next one.  Truncation can only misorder
+// candidates whose truncated distances are EQUAL, and that only matters at the boundary: if
+// trunc(lst[L-1]) != trunc(e) the L keys hold exactly the L nearest others (ties to the lowest index, like the
+// oracle).  Otherwise -- 0.4 % of the queries at n = 312 -- a second sweep (run by the wave only if one of its
+// lanes needs it) re-derives the distances and picks, among the candidates with that truncated value, the
+// ones with the smallest (D, j): up to two boundary slots per query are settled this way; more (or a negative
+// or zero distance to another row: possibly duplicated rows) raise uws[2] = "use the exact path".
+// Output: slot 0 = the query itself, slots 1 .. k-1 = the other members in no particular order (DenseEdgeConv
+// drops the first and max-pools over the rest).
+__device__ __forceinline__ void kg_cx_i32(int &a, int &b)
+{
+    int lo, hi;
+    asm("v_min_i32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_i32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo;
+    b = hi;
+}
+
+// Fold L new keys into the running selection: `lst` = the L smallest so far (ascending), `e1` <= `e2` = the next
+// two (the two smallest keys ever discarded).
+template <int L>
+__device__ __forceinline__ void kg_fold_i32(int (&lst)[L], int &e1, int &e2, int (&nw)[L])
+{
+    static_assert(L == 16 || L == 32, "list length");
+    if constexpr (L == 32) {
+        KG_SORT32(nw, kg_cx_i32)
+    } else {
+        KG_SORT16(nw, kg_cx_i32)
+    }
+    // two interleaved (smallest, second smallest) pairs over the discarded keys (four cost registers the
+    // kernel does not have: 136 spilled)
+    int d1[2] = {e1, 0x7FFFFFFF}, d2[2] = {e2, 0x7FFFFFFF};
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        kg_cx_i32(lst[i], nw[L - 1 - i]);               // lst[i] = min, nw[L-1-i] = max (discarded)
+        const int x = nw[L - 1 - i];
+        d2[i & 1] = min(d2[i & 1], max(d1[i & 1], x));
+        d1[i & 1] = min(d1[i & 1], x);
+    }
+    e2 = min(min(d2[0], d2[1]), max(d1[0], d1[1]));
+    e1 = min(d1[0], d1[1]);
+#pragma unroll
+    for (int st = L / 2; st >= 1; st >>= 1)
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            if ((i & st) == 0)
+                kg_cx_i32(lst[i], lst[i + st]);
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void knn_graph_key_kernel(KnnArgs a)
+{
+    constexpr int TILE = tile_rows(C);
+    constexpr int F4 = Row<C>::F4;
+    constexpr int L = K - 1;
+    __shared__ float4 tile[TILE * F4];
+    __shared__ __attribute__((aligned(16))) float rps[TILE];
+    if (a.uws && a.uws[0] != 0)
+        return;
+    const int b = blockIdx.y;
+    const int n = a.n;                              // dense self query: m == n, no layout
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = qi < n;
+    float q[C], rq;
+    load_query<C>(q, rq, a.query + ((size_t)b * n + (live ? qi : 0)) * a.c, a.c, live);
+    const float *P = a.points + (size_t)b * n * a.c;
+    const int IB = 32 - __clz(n - 1);               // index bits (n >= 2)
+    const int keep = ~((1 << IB) - 1);
+
+    int lst[L], e = 0x7FFFFFFF, e2 = 0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+        lst[i] = 0x7FFFFFFF;
+    for (int j0 = 0; j0 < n; j0 += TILE) {
+        const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
+        __syncthreads();
+        kg_stage<C>(tile, rps, P, j0, len, a.c);
+        __syncthreads();
+        for (int j = 0; j < len; j += L) {
+            float d[L];
+#pragma unroll
+            for (int t = 0; t < L; t += 16)
+                kg_dist<C, 4>(tile, rps, j + t, q, rq, d + t);
+            int nw[L];
+#pragma unroll
+            for (int t = 0; t < L; ++t) {
+                const int idx = j0 + j + t;         // wave-uniform
+                const int key = (__float_as_int(d[t]) & keep) | idx;
+                nw[t] = idx == qi ? 0x7FFFFFFF : key;
+            }
+            kg_fold_i32<L>(lst, e, e2, nw);
+        }
+    }
+    // a negative or (truncated) zero distance to ANOTHER row: rows may be duplicated -> the exact path decides
+    bool redo = live && (lst[0] >> IB) <= 0;
+    // boundary check: does a key OUTSIDE the list share the truncated distance T of the list's last member?
+    const int T = lst[L - 1] >> IB;
+    bool amb = live && !redo && (e >> IB) == T && e != 0x7FFFFFFF;
+    if (n <= TILE && __builtin_amdgcn_ballot_w64(amb)) {
+        // Usually only ONE outsider collides (the second does in ~0.06 % of the queries): then every candidate in
+        // question is known by index -- the list's members with truncated value T (at its end) and e -- and the
+        // lane re-derives just their distances (the same fmaf chain, rows still staged) and keeps the smallest
+        // (D, j).  Settles up to two boundary slots; anything deeper goes to the sweep below.
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            cnt += (lst[i] >> IB) == T ? 1 : 0;
+        const bool easy = amb && (e2 >> IB) != T && cnt <= 2;
+        if (easy) {
+            const int ja = lst[L - 1] & ~keep, jb = lst[L - 2] & ~keep, jc = e & ~keep;
+            __builtin_amdgcn_sched_barrier(0);          // one row's loads in flight at a time (registers)
+            const int da = __float_as_int(row_dist<C>(tile + ja * F4, q, rq));
+            __builtin_amdgcn_sched_barrier(0);
+            const int dc = __float_as_int(row_dist<C>(tile + jc * F4, q, rq));
+            __builtin_amdgcn_sched_barrier(0);
+            // (D, j) order; the members are kept unless the outsider is strictly better
+            auto less = [](int d0, int j0, int d1, int j1) { return d0 < d1 || (d0 == d1 && j0 < j1); };
+            if (cnt == 1) {
+                if (less(dc, jc, da, ja))
+                    lst[L - 1] = (dc & keep) | jc;
+            } else {
+                const int db = __float_as_int(row_dist<C>(tile + jb * F4, q, rq));
+                // drop the worst of the three
+                const bool a_worst = !less(da, ja, db, jb) && !less(da, ja, dc, jc);
+                const bool b_worst = !a_worst && !less(db, jb, dc, jc);
+                if (a_worst)
+                    lst[L - 1] = (dc & keep) | jc;
+                else if (b_worst)
+                    lst[L - 2] = (dc & keep) | jc;
+            }
+            amb = false;
+        }
+    }
+    // (the sweep re-stages tiles when the set spans several: then the whole workgroup must take it together)
+    const bool sweep = n > TILE ? (bool)__syncthreads_or(amb ? 1 : 0) : __builtin_amdgcn_ballot_w64(amb) != 0;
+    if (sweep) {
+        // second sweep, wave-uniform: among the candidates with truncated distance T keep the two smallest
+        // (D, j) -- candidates arrive in ascending j, so strict comparisons keep the lowest index on ties
+        int b0 = 0x7FFFFFFF, b1 = 0x7FFFFFFF, j0b = 0, j1b = 0;
+        for (int j0 = 0; j0 < n; j0 += TILE) {
+            const int len = __builtin_amdgcn_readfirstlane(min(TILE, n - j0));
+            if (n > TILE) {
+                __syncthreads();
+                kg_stage<C>(tile, rps, P, j0, len, a.c);
+                __syncthreads();
+            }
+            for (int j = 0; j < len; j += 16) {
+                float d[16];
+                kg_dist<C, 4>(tile, rps, j, q, rq, d);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int idx = j0 + j + t;
+                    const int bits = __float_as_int(d[t]);
+                    if ((bits >> IB) == T && idx != qi) {
+                        if (bits < b0) {
+                            b1 = b0; j1b = j0b; b0 = bits; j0b = idx;
+                        } else if (bits < b1) {
+                            b1 = bits; j1b = idx;
+                        }
+                    }
+                }
+            }
+        }
+        if (amb) {
+            // the list's members with truncated value T sit at its end (sorted): replace them
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+                cnt += (lst[i] >> IB) == T ? 1 : 0;
+            if (cnt > 2) {
+                redo = true;
+            } else {
+                lst[L - 1] = ((cnt == 1 ? b0 : b1) & keep) | (cnt == 1 ? j0b : j1b);
+                if (cnt == 2)
+                    lst[L - 2] = (b0 & keep) | j0b;
+            }
+        }
+    }
+    if (redo)
+        a.uws[2] = 1u;
+    if (live) {
+        int32_t *out = (int32_t *)a.idx + ((size_t)b * n + qi) * K;
+        out[0] = qi;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            out[1 + i] = lst[i] & ~keep;
     }
 }
 
@@ -1238,15 +1434,26 @@ extern "C" int tpu3_knn_graph_self_optimistic_f32(tpu3_stream_t stream, int b, i
     int threads = ((n + 63) / 64) * 64;
     if (threads > 512) threads = 256;
     const dim3 g((n + threads - 1) / threads, b);
+    // one pass with the index in the key's low bits (n up to 2^13: >= 10 mantissa bits stay); the two-pass kernel
+    // beyond that and for n == k
 #define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+#define KK1(CC, KK) hipLaunchKernelGGL((knn_graph_key_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+    const bool onepass = n > k && n <= 8192;
     if (k == 33) {
-        if (c == 3) KG(3, 33); else if (c <= 8) KG(8, 33); else if (c <= 16) KG(16, 33);
-        else if (c <= 24) KG(24, 33); else KG(32, 33);
+        if (c == 3) { if (onepass) KK1(3, 33); else KG(3, 33); }
+        else if (c <= 8) { if (onepass) KK1(8, 33); else KG(8, 33); }
+        else if (c <= 16) { if (onepass) KK1(16, 33); else KG(16, 33); }
+        else if (c <= 24) { if (onepass) KK1(24, 33); else KG(24, 33); }
+        else { if (onepass) KK1(32, 33); else KG(32, 33); }
     } else {
-        if (c == 3) KG(3, 17); else if (c <= 8) KG(8, 17); else if (c <= 16) KG(16, 17);
-        else if (c <= 24) KG(24, 17); else KG(32, 17);
+        if (c == 3) { if (onepass) KK1(3, 17); else KG(3, 17); }
+        else if (c <= 8) { if (onepass) KK1(8, 17); else KG(8, 17); }
+        else if (c <= 16) { if (onepass) KK1(16, 17); else KG(16, 17); }
+        else if (c <= 24) { if (onepass) KK1(24, 17); else KG(24, 17); }
+        else { if (onepass) KK1(32, 17); else KG(32, 17); }
     }
 #undef KG
+#undef KK1
     return tpu3_launch_status();
 }
 

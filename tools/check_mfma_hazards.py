@@ -32,16 +32,23 @@ def scan(asm_path):
         ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
         src = regs(ops[1]) | regs(ops[2])
         srcc = regs(ops[3]) if len(ops) > 3 else set()
-        for back in (1, 2):
-            if k - back < 0:
-                continue
+        # walk back until two issue slots separate the producer from this MFMA (`s_nop n` fills n + 1 of them)
+        slots, back = 0, 1
+        while slots < 2 and k - back >= 0:
             pl = ins[k - back]
+            m = re.match(r"s_nop\s+(\d+)", pl)
+            if m:
+                slots += int(m.group(1)) + 1
+                back += 1
+                continue
             if pl.startswith("v_") and not pl.startswith("v_mfma"):
                 if regs(pl.split(None, 1)[1].split(",")[0].strip()) & src:
                     bad.append("A/B written just before use: %s -> %s" % (pl, l))
-            if pl.startswith("v_mfma") and back == 1:
+            if pl.startswith("v_mfma") and slots == 0:
                 if regs(pl.split(None, 1)[1].split(",")[0].strip()) & srcc:
                     bad.append("dependent MFMA without wait states: %s -> %s" % (pl, l))
+            slots += 1
+            back += 1
     return total, bad
 
 
