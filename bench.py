@@ -139,10 +139,11 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
     if shp:
         flop = sum(p * n * n * (2.0 * c + 3.0) for p, n, c, k in shp)   # B*M*N*(2C+3), M = N
         ach = flop / (ms * 1e-3) / 1e12
-        out.append({"kernel": "knn_graph_kernel (+ self-check) (feature kNN k=33, unique), %d launches/step" % len(shp),
+        out.append({"kernel": "knn_graph_key_kernel (feature kNN graph k=33, one pass, exact) incl. its output allocation, "
+                              "%d launches/step" % len(shp),
                     "bound": "valu", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                     "basis": "SURVEY 8d compute model B*M*N*(2C+3) FLOP against the fp32 vector peak",
-                    "ms_per_step": ms, "model_flop_per_step": flop, "traffic": tr("knn_graph_kernel")})
+                    "ms_per_step": ms, "model_flop_per_step": flop, "traffic": tr("knn_graph_key_kernel")})
     ms, shp = kt.total("regress_tail")
     if shp:
         ex = sum(m * rr * 2.0 * (128 * 128 + 128 * 64 + 64 * 16) for m, rr in shp)
@@ -170,7 +171,7 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
     ms, shp = kt.total("fps", lambda s: s[2] >= 256)
     if shp:
         rounds = sum(m - 1 for _, _, m in shp)
-        out.append({"kernel": "rb_main_kernel / fps_resident_kernel (per-level resampling FPS), %d launches/step" % len(shp),
+        out.append({"kernel": "rm_main_kernel / rb_main_kernel (per-level resampling FPS), %d launches/step" % len(shp),
                     "bound": "latency", "us_per_round": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
                     "sets_per_launch": [b for b, _, _ in shp], "basis": "dependent chain: one workgroup per set"})
     ms, shp = kt.total("knn")
