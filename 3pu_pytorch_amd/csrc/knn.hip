@@ -650,18 +650,28 @@ __device__ __forceinline__ void kg_fold_i32(int (&lst)[L], int &e1, int &e2, int
     } else {
         KG_SORT16(nw, kg_cx_i32)
     }
-    // two interleaved (smallest, second smallest) pairs over the discarded keys (four cost registers the
-    // kernel does not have: 136 spilled)
-    int d1[2] = {e1, 0x7FFFFFFF}, d2[2] = {e2, 0x7FFFFFFF};
+    // The discarded keys x_i = max(lst[i], nw[L-1-i]) are the maximum of an ascending and a descending sequence:
+    // V-shaped, so their two smallest are NEIGHBOURS -- smallest = min_i x_i, second = min_i max(x_i, x_{i+1})
+    // (any pair's maximum is >= the second smallest; the pair around the valley attains it).  ~2 instructions
+    // per key (v_max + v_min3 trees) instead of 4 for a running (min, second-min) pair.
 #pragma unroll
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < L; ++i)
         kg_cx_i32(lst[i], nw[L - 1 - i]);               // lst[i] = min, nw[L-1-i] = max (discarded)
-        const int x = nw[L - 1 - i];
-        d2[i & 1] = min(d2[i & 1], max(d1[i & 1], x));
-        d1[i & 1] = min(d1[i & 1], x);
+    int pm[L];
+#pragma unroll
+    for (int i = 0; i + 1 < L; ++i)
+        pm[i] = max(nw[i], nw[i + 1]);
+    pm[L - 1] = e2;
+    int c1 = nw[0], c2 = pm[0];
+#pragma unroll
+    for (int i = 1; i + 1 < L; i += 2) {
+        c1 = min(c1, min(nw[i], nw[i + 1]));
+        c2 = min(c2, min(pm[i], pm[i + 1]));
     }
-    e2 = min(min(d2[0], d2[1]), max(d1[0], d1[1]));
-    e1 = min(d1[0], d1[1]);
+    c1 = min(c1, nw[L - 1]);
+    c2 = min(c2, pm[L - 1]);                            // ... and the old e2
+    e2 = min(c2, max(e1, c1));
+    e1 = min(e1, c1);
 #pragma unroll
     for (int st = L / 2; st >= 1; st >>= 1)
 #pragma unroll
@@ -689,6 +699,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float *P = a.points + (size_t)b * n * a.c;
     const int IB = 32 - __clz(n - 1);               // index bits (n >= 2)
     const int keep = ~((1 << IB) - 1);
+    const int q_first = __builtin_amdgcn_readfirstlane(qi);      // lane 0's query: qi - lane
 
     int lst[L], e = 0x7FFFFFFF, e2 = 0x7FFFFFFF;
 #pragma unroll
@@ -705,11 +716,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int t = 0; t < L; t += 16)
                 kg_dist<C, 4>(tile, rps, j + t, q, rq, d + t);
             int nw[L];
+            const int c0 = j0 + j;                  // wave-uniform
 #pragma unroll
-            for (int t = 0; t < L; ++t) {
-                const int idx = j0 + j + t;         // wave-uniform
-                const int key = (__float_as_int(d[t]) & keep) | idx;
-                nw[t] = idx == qi ? 0x7FFFFFFF : key;
+            for (int t = 0; t < L; ++t)
+                nw[t] = (__float_as_int(d[t]) & keep) | (c0 + t);
+            // the query's own row is left out; only the chunks that overlap this wave's 64 queries can hold it
+            if (c0 + L > q_first && c0 < q_first + 64) {
+#pragma unroll
+                for (int t = 0; t < L; ++t)
+                    nw[t] = c0 + t == qi ? 0x7FFFFFFF : nw[t];
             }
             kg_fold_i32<L>(lst, e, e2, nw);
         }

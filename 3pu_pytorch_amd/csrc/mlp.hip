@@ -461,7 +461,69 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// y[m, cout] = act(x[m, cin] W^T + b) for a handful of input channels (the 3 -> 24 lift of a Level)
+// ---------------------------------------------------------------------------------------------
+// HBM-bound: 4 cin B read, 4 cout B written per row (twice when the row is also stored into the level's feature
+// buffer).  A lane owns four outputs of a row; the weights sit in registers as wave-uniform values.
+struct LiftArgs {
+    long m;
+    int cin, cout, xs, ys, y2s, relu;
+    const float *x, *w, *b;
+    float *y, *y2;
+};
+
+constexpr int LIFT_CIN_MAX = 8;
+
+__global__ __launch_bounds__(256) void linear_lift_kernel(LiftArgs a)
+{
+    const int q = a.cout >> 2;                  // float4 groups per row
+    const long total = a.m * q;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long row = t / q;
+        const int o = (int)(t - row * q) * 4;
+        float xv[LIFT_CIN_MAX];
+#pragma unroll
+        for (int c = 0; c < LIFT_CIN_MAX; ++c)
+            xv[c] = c < a.cin ? a.x[row * a.xs + c] : 0.f;
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[u] = a.b ? a.b[o + u] : 0.f;
+#pragma unroll
+            for (int c = 0; c < LIFT_CIN_MAX; ++c)
+                if (c < a.cin)
+                    acc[u] = __builtin_fmaf(a.w[(o + u) * a.cin + c], xv[c], acc[u]);
+            if (a.relu)
+                acc[u] = fmaxf(acc[u], 0.f);
+        }
+        const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *(float4 *)(a.y + row * a.ys + o) = v;
+        if (a.y2)
+            *(float4 *)(a.y2 + row * a.y2s + o) = v;
+    }
+}
+
 } // namespace
+
+extern "C" int tpu3_linear_lift_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                                    const float *w, const float *bias, int relu, float *y, int y_stride,
+                                    float *y2, int y2_stride)
+{
+    if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
+    if (cin > LIFT_CIN_MAX || cout > 64 || cout % 4 || y_stride % 4 || (y2 && y2_stride % 4)) return TPU3_ELIMIT;
+    if (x_stride < cin || y_stride < cout || (y2 && y2_stride < cout)) return TPU3_EINVAL;
+    if (m == 0) return TPU3_OK;
+    if (!x || !w || !y) return TPU3_EINVAL;
+    if ((((uintptr_t)y | (uintptr_t)y2) & 15) != 0) return TPU3_ELIMIT;
+    LiftArgs a{m, cin, cout, x_stride, y_stride, y2_stride, relu, x, w, bias, y, y2};
+    long blocks = (m * (cout / 4) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(linear_lift_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
+
 
 extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
                                      int x_stride, const float *w, const float *bias, int relu, float *y,

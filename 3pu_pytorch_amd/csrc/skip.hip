@@ -64,38 +64,101 @@ __device__ __forceinline__ void skip_item(const SkipArgs &a, int &b, int &slice)
     slice = id - b * a.slices;
 }
 
-__device__ __forceinline__ float block_sum256(float v, float *red)
-{
-    v = tpu3_wave_sum_f32(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0)
-        red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 typedef float sk_f4 __attribute__((ext_vector_type(4)));
+#define SK_DPP(V, CTRL, RM) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, RM, 0xF, false))
 // sum over the wave by DPP (no LDS traffic); every lane of the LAST row ends with the total
 __device__ __forceinline__ float sk_wave_sum(float v)
 {
-#define SK_DPP_ADD(CTRL, RM)                                                                                 \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xF, false))
-    SK_DPP_ADD(0xB1, 0xF);      // quad_perm [1,0,3,2]
-    SK_DPP_ADD(0x4E, 0xF);      // quad_perm [2,3,0,1]
-    SK_DPP_ADD(0x141, 0xF);     // row_half_mirror
-    SK_DPP_ADD(0x140, 0xF);     // row_mirror: every lane holds its row's sum
-    SK_DPP_ADD(0x142, 0xA);     // row_bcast15 -> rows 1, 3
-    SK_DPP_ADD(0x143, 0xC);     // row_bcast31 -> rows 2, 3
-#undef SK_DPP_ADD
+    v += SK_DPP(v, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+    v += SK_DPP(v, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+    v += SK_DPP(v, 0x141, 0xF);     // row_half_mirror
+    v += SK_DPP(v, 0x140, 0xF);     // row_mirror: every lane holds its row's sum
+    v += SK_DPP(v, 0x142, 0xA);     // row_bcast15 -> rows 1, 3
+    v += SK_DPP(v, 0x143, 0xC);     // row_bcast31 -> rows 2, 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// K is a template parameter so that the K x NS row loads of a point are ALL issued before the first
-// one is consumed (with a run-time K the compiler keeps one uniform branch per neighbour and the
-// point costs K dependent memory round trips instead of one).
-// VEC: rows are read as float4 (C % 4 == 0, 16-byte aligned slabs): lane l owns float4 l and 64 + l.
-template <int K, bool VEC>
-__global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
+// sum / minimum over each aligned group of 8 lanes (fixed order), result in all 8
+__device__ __forceinline__ float sk_group8_sum(float v)
+{
+    v += SK_DPP(v, 0xB1, 0xF);
+    v += SK_DPP(v, 0x4E, 0xF);
+    v += SK_DPP(v, 0x141, 0xF);
+    return v;
+}
+
+__device__ __forceinline__ float sk_group8_min(float v)
+{
+    v = fminf(v, SK_DPP(v, 0xB1, 0xF));
+    v = fminf(v, SK_DPP(v, 0x4E, 0xF));
+    v = fminf(v, SK_DPP(v, 0x141, 0xF));
+    return v;
+}
+
+// What a wave does per point is bound by the NUMBER of vector-memory instructions it issues (each row-wide
+// float4 load keeps the CU's texture path busy for 16 cycles): K row loads + the point's own row, and ONE
+// masked instruction of the first 16 lanes for everything small --
+//   lanes 0 .. K-1     ("group 0", lane kk = neighbour kk): the neighbour's xyz (dist) / its two distances (apply)
+//   lanes 8 .. 15      the point's own xyz (dist)
+//   lane 8 j + kk      TAIL (64 < C/4 <= 72): float4 64 + j of neighbour kk's row and of the point's own row --
+//                      the 8 channels beyond 256 of all K rows in one load (a second row-wide load per neighbour
+//                      would carry 2 useful lanes of 64 at C = 264).
+// K is a template parameter so that the K row loads of a point are ALL issued before the first one is consumed.
+// VEC: rows are read as float4 (C % 4 == 0, C <= 288, 16-byte aligned slabs); otherwise scalar channel loops.
+template <int K>
+struct SkLanes {
+    int tk, tjr, tj;        // lane = 8 tjr + tk; tj = tjr clamped to the tail's float4s
+    bool small, tj_live, tact;
+    __device__ __forceinline__ SkLanes(int lane, int C4, bool tail)
+    {
+        tk = lane & 7;
+        tjr = lane >> 3;
+        const int t = tail ? C4 - 64 : 0;
+        tj = tail ? min(tjr, t - 1) : 0;
+        tj_live = tjr < t;
+        tact = tj_live && tk < K;
+        small = lane < max(16, 8 * t);
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void sk_neighbours(const SkipArgs &a, const void *idx, size_t io, int (&nbr)[K])
+{
+    if (a.idx64) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            nbr[kk] = (int)((const long long *)idx)[io + kk];
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            nbr[kk] = ((const int *)idx)[io + kk];
+    }
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk)
+        nbr[kk] = min(max(nbr[kk], 0), a.m - 1);
+}
+
+// the wave-uniform rows as a per-lane value: lane 8 j + kk -> neighbour kk
+template <int K>
+__device__ __forceinline__ int sk_lane_neighbour(const int (&nbr)[K], int tk)
+{
+    // (readfirstlane: the rows are wave-uniform anyway, and it keeps the compiler from re-forming the select chain
+    // into a dynamically indexed array, which it then places in LDS)
+    int nb = __builtin_amdgcn_readfirstlane(nbr[K - 1]);
+#pragma unroll
+    for (int kk = K - 2; kk >= 0; --kk) {
+        const int t = __builtin_amdgcn_readfirstlane(nbr[kk]);
+        nb = tk == kk ? t : nb;
+    }
+    return nb;
+}
+
+// (the bodies take their pointers as __restrict__ parameters: once inlined, the index loads are known not to be
+// clobbered by the kernel's stores and stay scalar loads)
+template <int K, bool VEC, bool TAIL>
+__device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__restrict__ idx_p,
+                                               const float *__restrict__ feat_p, float *__restrict__ dist_p,
+                                               float *__restrict__ mins_p)
 {
     const int n = a.n, C = a.c;
     int b, slice;
@@ -105,60 +168,88 @@ __global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // i, the neighbour rows: SGPRs
     const int i_lo = slice * a.slice_len, i_hi = min(n, i_lo + a.slice_len);
     const float *XYZ = a.xyz + (size_t)b * n * 3;
-    const float *F = a.feat + (size_t)b * n * a.feat_stride;
+    const float *F = feat_p + (size_t)b * n * a.feat_stride;
     const float *PX = a.prev_xyz + (size_t)pb * a.m * 3;
     const float *PF = a.prev_feat + (size_t)pb * a.m * C;
-    float *DS = a.dist + (size_t)b * n * 2 * K;
-    float *MN = a.mins + (size_t)b * n * 2;
-    constexpr int NS = 2;
+    float2 *DS = (float2 *)dist_p + (size_t)b * n * K;              // (spatial, feature) per neighbour
+    float2 *MN = (float2 *)mins_p + (size_t)b * n;
     const int C4 = C >> 2;
-    const bool v0 = lane < C4, v1 = 64 + lane < C4;
+    const bool v0 = lane < C4;
     // loads are unconditional from clamped slots (a select on the result, not a branch around the load)
-    const int l0 = VEC ? min(lane, C4 - 1) : 0, l1 = VEC ? min(64 + lane, C4 - 1) : 0;
+    const int l0 = VEC ? min(lane, C4 - 1) : 0;
+    const SkLanes<K> L(lane, C4, TAIL);
 
-    for (int i = i_lo + wave; i < i_hi; i += SK_THREADS / 64) {
-        // neighbour rows (wave-uniform) and, in lanes < K, the spatial distance
-        // ((dx^2 + dy^2) + dz^2, like torch.sum over 3 channels)
-        int nbr[K];
-        const size_t io = ((size_t)b * n + i) * K;
-        if (a.idx64) {
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                nbr[kk] = (int)((const long long *)a.idx)[io + kk];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                nbr[kk] = ((const int *)a.idx)[io + kk];
-        }
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk)
-            nbr[kk] = min(max(nbr[kk], 0), a.m - 1);
-        float acc[K];
+    // The point's own row streams from HBM (the longest wait of an iteration) and its neighbour list is a scalar
+    // load the row addresses depend on: both are fetched ONE ITERATION AHEAD (8 registers), so an iteration waits
+    // for L2 (the gathered rows) only.
+    constexpr int STEP = SK_THREADS / 64;
+    int nbr[K];
+    sk_f4 x0 = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
+    if (i_lo + wave < i_hi) {
+        const int i = i_lo + wave;
+        sk_neighbours<K>(a, idx_p, ((size_t)b * n + i) * K, nbr);
         if (VEC) {
             const sk_f4 *X4 = (const sk_f4 *)(F + (size_t)i * a.feat_stride);
-            sk_f4 r[K][NS];
+            x0 = __builtin_nontemporal_load(X4 + l0);
+            if (TAIL && L.small)
+                xt = __builtin_nontemporal_load(X4 + 64 + L.tj);
+        }
+    }
+    for (int i = i_lo + wave; i < i_hi; i += STEP) {
+        const int nb = sk_lane_neighbour<K>(nbr, L.tk);
+        const int inx = i + STEP < i_hi ? i + STEP : i;         // next point of this wave (or this one again)
+        int nbrn[K];
+        sk_f4 x0n = {0.f, 0.f, 0.f, 0.f}, xtn = {0.f, 0.f, 0.f, 0.f};
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        sk_f4 rt = {0.f, 0.f, 0.f, 0.f};
+        float acc[K];
+        if (VEC) {
+            sk_f4 r[K];
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                const sk_f4 *R4 = (const sk_f4 *)(PF + (size_t)nbr[kk] * C);
-                r[kk][0] = R4[l0];
-                r[kk][1] = R4[l1];
+            for (int kk = 0; kk < K; ++kk)
+                r[kk] = ((const sk_f4 *)(PF + (size_t)nbr[kk] * C))[l0];
+            if (L.small) {
+                const float *pp = L.tjr == 0 ? PX + (size_t)nb * 3 : XYZ + (size_t)i * 3;
+                p0 = pp[0];
+                p1 = pp[1];
+                p2 = pp[2];
+                if (TAIL)
+                    rt = ((const sk_f4 *)(PF + (size_t)nb * C))[64 + L.tj];
             }
-            const sk_f4 x0 = __builtin_nontemporal_load(X4 + l0);
-            const sk_f4 x1 = __builtin_nontemporal_load(X4 + l1);
+            {
+                sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
+                const sk_f4 *X4n = (const sk_f4 *)(F + (size_t)inx * a.feat_stride);
+                x0n = __builtin_nontemporal_load(X4n + l0);
+                if (TAIL && L.small)
+                    xtn = __builtin_nontemporal_load(X4n + 64 + L.tj);
+            }
+            float ts = 0.f;
+            if (TAIL) {
+                float d;
+                d = xt.x - rt.x; ts = __builtin_fmaf(d, d, ts);
+                d = xt.y - rt.y; ts = __builtin_fmaf(d, d, ts);
+                d = xt.z - rt.z; ts = __builtin_fmaf(d, d, ts);
+                d = xt.w - rt.w; ts = __builtin_fmaf(d, d, ts);
+            }
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                float s = 0.f, t = 0.f, d;
-                d = x0.x - r[kk][0].x; s += d * d;
-                d = x0.y - r[kk][0].y; s += d * d;
-                d = x0.z - r[kk][0].z; s += d * d;
-                d = x0.w - r[kk][0].w; s += d * d;
-                d = x1.x - r[kk][1].x; t += d * d;
-                d = x1.y - r[kk][1].y; t += d * d;
-                d = x1.z - r[kk][1].z; t += d * d;
-                d = x1.w - r[kk][1].w; t += d * d;
-                acc[kk] = (v0 ? s : 0.f) + (v1 ? t : 0.f);
+                float s = 0.f, d;
+                d = x0.x - r[kk].x; s = __builtin_fmaf(d, d, s);
+                d = x0.y - r[kk].y; s = __builtin_fmaf(d, d, s);
+                d = x0.z - r[kk].z; s = __builtin_fmaf(d, d, s);
+                d = x0.w - r[kk].w; s = __builtin_fmaf(d, d, s);
+                acc[kk] = v0 ? s : 0.f;
+                if (TAIL)
+                    acc[kk] += L.tact && L.tk == kk ? ts : 0.f;
             }
         } else {
+            sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
+            if (L.small) {
+                const float *pp = L.tjr == 0 ? PX + (size_t)nb * 3 : XYZ + (size_t)i * 3;
+                p0 = pp[0];
+                p1 = pp[1];
+                p2 = pp[2];
+            }
             float xv[SK_CPL];
 #pragma unroll
             for (int u = 0; u < SK_CPL; ++u) {
@@ -177,34 +268,43 @@ __global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
                 }
             }
         }
-        float fmin_ = __builtin_inff(), smin_ = __builtin_inff();
-        float mine_f = 0.f, mine_s = 0.f;
-        const float qx = XYZ[i * 3 + 0], qy = XYZ[i * 3 + 1], qz = XYZ[i * 3 + 2];
+        // spatial distance in lane kk: (dx^2 + dy^2) + dz^2, like torch.sum over 3 channels
+        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), 8));
+        const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), 8));
+        const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2), 8));
+        const float dx = qx - p0, dy = qy - p1, dz = qz - p2;
+        const float sp = (dx * dx + dy * dy) + dz * dz;
+        const float smin_ = sk_group8_min(lane < K ? sp : __builtin_inff());
+        float fmin_ = 0.f, mine_f = 0.f;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const float f = sk_wave_sum(acc[kk]);
-            const float dx = qx - PX[nbr[kk] * 3 + 0], dy = qy - PX[nbr[kk] * 3 + 1], dz = qz - PX[nbr[kk] * 3 + 2];
-            const float sp = (dx * dx + dy * dy) + dz * dz;
             fmin_ = kk == 0 ? f : fminf(fmin_, f);
-            smin_ = kk == 0 ? sp : fminf(smin_, sp);
             mine_f = lane == kk ? f : mine_f;
-            mine_s = lane == kk ? sp : mine_s;
         }
-        if (lane < K) {
-            DS[(size_t)i * 2 * K + lane] = mine_s;
-            DS[(size_t)i * 2 * K + K + lane] = mine_f;
-        }
-        if (lane == 0) {
-            MN[i * 2 + 0] = smin_;
-            MN[i * 2 + 1] = fmin_;
-        }
+        if (lane < K)
+            DS[(size_t)i * K + lane] = make_float2(sp, mine_f);
+        if (lane == 0)
+            MN[i] = make_float2(smin_, fmin_);
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            nbr[kk] = nbrn[kk];
+        x0 = x0n;
+        xt = xtn;
     }
 }
 
-template <int K, bool VEC>
-__global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
+template <int K, bool VEC, bool TAIL>
+__global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
 {
-    __shared__ float red[4];
+    skip_dist_body<K, VEC, TAIL>(a, a.idx, a.feat, a.dist, a.mins);
+}
+
+template <int K, bool VEC, bool TAIL>
+__device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *__restrict__ idx_p,
+                                                float *__restrict__ feat_p, const float *__restrict__ prev_p,
+                                                const float *__restrict__ dist_p, const float *__restrict__ mins_p)
+{
     const int n = a.n, C = a.c;
     int b, slice;
     skip_item(a, b, slice);
@@ -212,87 +312,105 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // i, the neighbour rows: SGPRs
     const int i_lo = slice * a.slice_len, i_hi = min(n, i_lo + a.slice_len);
-    float *F = a.feat + (size_t)b * n * a.feat_stride;
-    const float *PF = a.prev_feat + (size_t)pb * a.m * C;
-    const float *DS = a.dist + (size_t)b * n * 2 * K;
-    const float *MN = a.mins + (size_t)b * n * 2;
-    // ---- h = mean over the patch's points of the distance to the closest of the K neighbours; every
-    // slice of a patch sums the same values in the same order --------------------------------------------
+    float *F = feat_p + (size_t)b * n * a.feat_stride;
+    const float *PF = prev_p + (size_t)pb * a.m * C;
+    const float2 *DS = (const float2 *)dist_p + (size_t)b * n * K;
+    const float2 *MN = (const float2 *)mins_p + (size_t)b * n;
+    // ---- h = mean over the patch's points of the distance to the closest of the K neighbours; every wave of
+    // every slice of a patch sums the same values in the same order (no barrier, no LDS) -----------------------
     float ms = 0.f, mf = 0.f;
-    for (int i = tid; i < n; i += SK_THREADS) {
-        ms += MN[i * 2 + 0];
-        mf += MN[i * 2 + 1];
+    for (int i = lane; i < n; i += 64) {
+        const float2 v = MN[i];
+        ms += v.x;
+        mf += v.y;
     }
-    const float hs = block_sum256(ms, red) / (float)n;
-    const float hf = block_sum256(mf, red) / (float)n;
+    const float hs = sk_wave_sum(ms) / (float)n;
+    const float hf = sk_wave_sum(mf) / (float)n;
     const float hs2 = hs / 2, hf2 = hf / 2;
-    constexpr int NS = 2;
     const int C4 = C >> 2;
-    const bool v0 = lane < C4, v1 = 64 + lane < C4;
-    const int l0 = VEC ? min(lane, C4 - 1) : 0, l1 = VEC ? min(64 + lane, C4 - 1) : 0;
+    const bool v0 = lane < C4;
+    const int l0 = VEC ? min(lane, C4 - 1) : 0;
+    const SkLanes<K> L(lane, C4, TAIL);
+    const int lk = min(L.tk, K - 1);                // (lanes 0 .. K-1: their own neighbour; K <= 8)
 
-    for (int i = i_lo + wave; i < i_hi; i += SK_THREADS / 64) {
-        const size_t io = ((size_t)b * n + i) * K;
-        int nbr[K];
-        float w[K], tot = 0.f;
-        if (a.idx64) {
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                nbr[kk] = (int)((const long long *)a.idx)[io + kk];
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                nbr[kk] = ((const int *)a.idx)[io + kk];
+    // (own row and neighbour list one iteration ahead, as in skip_dist_kernel)
+    constexpr int STEP = SK_THREADS / 64;
+    int nbr[K];
+    sk_f4 x0 = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
+    if (i_lo + wave < i_hi) {
+        const int i = i_lo + wave;
+        sk_neighbours<K>(a, idx_p, ((size_t)b * n + i) * K, nbr);
+        if (VEC) {
+            const sk_f4 *X4 = (const sk_f4 *)(F + (size_t)i * a.feat_stride);
+            x0 = __builtin_nontemporal_load(X4 + l0);
+            if (TAIL && L.small)
+                xt = __builtin_nontemporal_load(X4 + 64 + L.tj);
         }
+    }
+    for (int i = i_lo + wave; i < i_hi; i += STEP) {
+        const int nb = sk_lane_neighbour<K>(nbr, L.tk);
+        const int inx = i + STEP < i_hi ? i + STEP : i;
+        int nbrn[K];
+        sk_f4 x0n = {0.f, 0.f, 0.f, 0.f}, xtn = {0.f, 0.f, 0.f, 0.f};
+        sk_f4 *X4 = (sk_f4 *)(F + (size_t)i * a.feat_stride);
+        sk_f4 r[K];
+        if (VEC) {
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk)
+                r[kk] = ((const sk_f4 *)(PF + (size_t)nbr[kk] * C))[l0];
+        }
+        float2 ds = make_float2(0.f, 0.f);
+        sk_f4 rt = {0.f, 0.f, 0.f, 0.f};
+        if (L.small) {
+            ds = DS[(size_t)i * K + lk];
+            if (VEC && TAIL)
+                rt = ((const sk_f4 *)(PF + (size_t)nb * C))[64 + L.tj];
+        }
+        sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
+        if (VEC && inx != i) {      // (the row of `i` itself is about to be rewritten: never re-read it)
+            const sk_f4 *X4n = (const sk_f4 *)(F + (size_t)inx * a.feat_stride);
+            x0n = __builtin_nontemporal_load(X4n + l0);
+            if (TAIL && L.small)
+                xtn = __builtin_nontemporal_load(X4n + 64 + L.tj);
+        }
+        // weights (reference :340-342): w = ws*wf;  w /= sum_k (w + 1e-5).  Lane 8 j + kk evaluates neighbour kk
+        // (two divisions, two exponentials, then one more division) and group 0's results are broadcast -- the
+        // same operations on the same values as evaluating all K in every lane, a fifth of the VALU work
+        // (IEEE divisions and expf are ~10 instructions each).
+        float w[K], tot = 0.f;
+        const float mine = expf(-ds.x / hs2) * expf(-ds.y / hf2);
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), kk));
+            tot += w[kk] + 1e-5f;
+        }
+        const float mine_w = mine / tot;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk)
-            nbr[kk] = min(max(nbr[kk], 0), a.m - 1);
-        // weights (reference :340-342): w = ws*wf;  w /= sum_k (w + 1e-5).  Lane kk evaluates neighbour kk
-        // (two divisions, two exponentials, then one more division) and the results are broadcast -- the
-        // same operations on the same values as evaluating all K in every lane, a fifth of the VALU work
-        // (IEEE divisions and expf are ~10 instructions each and this loop is not memory-bound).
-        {
-            const int lk = min(lane, K - 1);
-            const float mine = expf(-DS[(size_t)i * 2 * K + lk] / hs2) * expf(-DS[(size_t)i * 2 * K + K + lk] / hf2);
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), kk));
-                tot += w[kk] + 1e-5f;
-            }
-            const float mine_w = mine / tot;
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-                w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_w), kk));
-        }
+            w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_w), kk));
         if (VEC) {
-            sk_f4 *X4 = (sk_f4 *)(F + (size_t)i * a.feat_stride);
-            sk_f4 r[K][NS];
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                const sk_f4 *R4 = (const sk_f4 *)(PF + (size_t)nbr[kk] * C);
-                r[kk][0] = R4[l0];
-                r[kk][1] = R4[l1];
-            }
-            const sk_f4 x0 = __builtin_nontemporal_load(X4 + l0);
-            const sk_f4 x1 = __builtin_nontemporal_load(X4 + l1);
-            sk_f4 s0, s1;
-            s0.x = w[0] * r[0][0].x; s0.y = w[0] * r[0][0].y; s0.z = w[0] * r[0][0].z; s0.w = w[0] * r[0][0].w;
-            s1.x = w[0] * r[0][1].x; s1.y = w[0] * r[0][1].y; s1.z = w[0] * r[0][1].z; s1.w = w[0] * r[0][1].w;
+            sk_f4 s0;
+            s0.x = w[0] * r[0].x; s0.y = w[0] * r[0].y; s0.z = w[0] * r[0].z; s0.w = w[0] * r[0].w;
 #pragma unroll
             for (int kk = 1; kk < K; ++kk) {
-                s0.x = s0.x + w[kk] * r[kk][0].x; s0.y = s0.y + w[kk] * r[kk][0].y;
-                s0.z = s0.z + w[kk] * r[kk][0].z; s0.w = s0.w + w[kk] * r[kk][0].w;
-                s1.x = s1.x + w[kk] * r[kk][1].x; s1.y = s1.y + w[kk] * r[kk][1].y;
-                s1.z = s1.z + w[kk] * r[kk][1].z; s1.w = s1.w + w[kk] * r[kk][1].w;
+                s0.x = __builtin_fmaf(w[kk], r[kk].x, s0.x); s0.y = __builtin_fmaf(w[kk], r[kk].y, s0.y);
+                s0.z = __builtin_fmaf(w[kk], r[kk].z, s0.z); s0.w = __builtin_fmaf(w[kk], r[kk].w, s0.w);
             }
-            s0.x = a.scale * s0.x + x0.x; s0.y = a.scale * s0.y + x0.y;
-            s0.z = a.scale * s0.z + x0.z; s0.w = a.scale * s0.w + x0.w;
-            s1.x = a.scale * s1.x + x1.x; s1.y = a.scale * s1.y + x1.y;
-            s1.z = a.scale * s1.z + x1.z; s1.w = a.scale * s1.w + x1.w;
+            s0.x = __builtin_fmaf(a.scale, s0.x, x0.x); s0.y = __builtin_fmaf(a.scale, s0.y, x0.y);
+            s0.z = __builtin_fmaf(a.scale, s0.z, x0.z); s0.w = __builtin_fmaf(a.scale, s0.w, x0.w);
             if (v0)
                 __builtin_nontemporal_store(s0, X4 + lane);
-            if (v1)
-                __builtin_nontemporal_store(s1, X4 + 64 + lane);
+            if (TAIL) {
+                // lane 8 j + kk holds float4 64 + j of neighbour kk: weight it, add up the eight lanes of the group
+                const float wt = L.tact ? mine_w : 0.f;
+                sk_f4 t;
+                t.x = sk_group8_sum(wt * rt.x); t.y = sk_group8_sum(wt * rt.y);
+                t.z = sk_group8_sum(wt * rt.z); t.w = sk_group8_sum(wt * rt.w);
+                t.x = __builtin_fmaf(a.scale, t.x, xt.x); t.y = __builtin_fmaf(a.scale, t.y, xt.y);
+                t.z = __builtin_fmaf(a.scale, t.z, xt.z); t.w = __builtin_fmaf(a.scale, t.w, xt.w);
+                if (L.tk == 0 && L.tj_live)
+                    __builtin_nontemporal_store(t, X4 + 64 + L.tj);
+            }
         } else {
             float s[SK_CPL];
 #pragma unroll
@@ -317,18 +435,32 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
                 }
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            nbr[kk] = nbrn[kk];
+        x0 = x0n;
+        xt = xtn;
     }
+}
+
+template <int K, bool VEC, bool TAIL>
+__global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
+{
+    skip_apply_body<K, VEC, TAIL>(a, a.idx, a.feat, a.prev_feat, a.dist, a.mins);
 }
 
 template <int K>
 int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec)
 {
-    if (vec) {
-        hipLaunchKernelGGL((skip_dist_kernel<K, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-        hipLaunchKernelGGL((skip_apply_kernel<K, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+    if (vec && a.c > 256) {
+        hipLaunchKernelGGL((skip_dist_kernel<K, true, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        hipLaunchKernelGGL((skip_apply_kernel<K, true, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+    } else if (vec) {
+        hipLaunchKernelGGL((skip_dist_kernel<K, true, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        hipLaunchKernelGGL((skip_apply_kernel<K, true, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
     } else {
-        hipLaunchKernelGGL((skip_dist_kernel<K, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-        hipLaunchKernelGGL((skip_apply_kernel<K, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        hipLaunchKernelGGL((skip_dist_kernel<K, false, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        hipLaunchKernelGGL((skip_apply_kernel<K, false, false>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
     }
     return tpu3_launch_status();
 }
@@ -371,7 +503,7 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
     SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale,
                per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k};
     // float4 rows: every row start must be 16-byte aligned
-    const bool vec = c % 4 == 0 && c <= 512 && feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 &&
+    const bool vec = c % 4 == 0 && c <= 288 && feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 &&
                      ((uintptr_t)prev_feat & 15) == 0;
     const int blocks = b * slices;
     int r;

@@ -234,15 +234,21 @@ class SampledDenseEdgeConv(DenseEdgeConv):
         return y.transpose(2, 1).contiguous(), sampled_xyz, sampled_idx
 
 
-def _fused_linear(layer, x):
+def _fused_linear(layer, x, also=None):
     """Inference shortcut of a pointwise Conv1d / Conv2d with at most 32 outputs (the prep
     convolutions of a Level): linear + bias + ReLU in one MFMA kernel that reads the input rows in
-    place (e.g. a channel slice of the level's feature buffer).  None = not applicable."""
+    place (e.g. a channel slice of the level's feature buffer); layers with <= 8 INPUT channels (the 3 -> 24
+    lift) go to the streaming kernel, which can store the rows a second time into `also`.
+    None = not applicable (`also` is then untouched)."""
     be = operations.BACKEND
     if (torch.is_grad_enabled() or not hasattr(be, "linear_small") or not x.is_cuda
-            or layer.activation not in (None, "relu") or layer.conv.out_channels > 32):
+            or layer.activation not in (None, "relu")):
         return None
     w = layer.conv.weight
+    if x.size(-1) <= 8 and hasattr(be, "linear_lift"):
+        return be.linear_lift(x, w.view(w.size(0), -1), layer.conv.bias, layer.activation == "relu", also=also)
+    if layer.conv.out_channels > 32 or also is not None:
+        return None
     f16 = getattr(layer, "mlp_precision", "f32") == "f16"
     y = be.linear_small(x, w.view(w.size(0), -1), layer.conv.bias, layer.activation == "relu",
                         mfma=L.MFMA_F16 if f16 else L.MFMA_F32)
@@ -295,15 +301,17 @@ class Conv2d(nn.Module):
         return (self.normalization is None and tuple(c.kernel_size) == (1, 1)
                 and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0))
 
-    def forward_cl(self, x):
-        """channel-last (..., C_in) -> (..., C_out)."""
+    def forward_cl(self, x, also=None):
+        """channel-last (..., C_in) -> (..., C_out); `also`: a view that receives a copy of the result."""
         assert self.pointwise()
-        y = _fused_linear(self, x)
+        y = _fused_linear(self, x, also)
         if y is not None:
             return y
         x = linear_1x1(self.conv, x)
         if self.activation is not None:
             x = self.act(x)
+        if also is not None:
+            also.copy_(x)
         return x
 
     def forward(self, x, epoch=None):

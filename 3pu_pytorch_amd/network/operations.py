@@ -322,6 +322,35 @@ class HipBackend(object):
                     "tpu3_linear_small_f32")
         return y
 
+    def linear_lift(self, x, weight, bias, relu, also=None):
+        """Per-point linear layer with <= 8 input channels (the 3 -> 24 lift of a Level): x (..., C_in)
+        contiguous rows, weight (C_out, C_in) -> (..., C_out) contiguous; `also`: a (..., C_out) view with unit
+        channel stride and one row stride (a slice of the level's feature buffer) that receives the same rows.
+        None when the shape is not covered."""
+        cin, cout = x.size(-1), weight.size(0)
+        if cin > 8 or cout > 64 or cout % 4 or x.dtype != torch.float32 or not x.is_contiguous():
+            return None
+        lead = x.shape[:-1]
+        m = x.numel() // cin
+        y2, y2s = None, 0
+        if also is not None:
+            if (tuple(also.shape) != tuple(lead) + (cout,) or also.stride(-1) != 1 or also.dtype != torch.float32
+                    or also.stride(-2) % 4 or (also.data_ptr() & 15)):
+                return None
+            exp = also.stride(-2)
+            for d, st in zip(reversed(lead), reversed(also.stride()[:-1])):
+                if d != 1 and st != exp:
+                    return None
+                exp *= d
+            y2, y2s = also, also.stride(-2)
+        w = weight.contiguous()
+        y = torch.empty(lead + (cout,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_linear_lift_f32(L.stream_of(x), m, cin, cout, L.ptr(x), cin, L.ptr(w), L.ptr(bias),
+                                                 1 if relu else 0, L.ptr(y), cout, L.ptr(y2), y2s),
+                    "tpu3_linear_lift_f32")
+        return y
+
     def linear_wgrad(self, x, dy):
         """x (M, C_in), dy (M, C_out) f32 rows with unit channel stride -> dW (C_out, C_in) =
         dy^T x, or None when the shape is not covered (C_out <= 16, C_in <= 64)."""

@@ -15,6 +15,8 @@ load unchanged), same numerical definition of every step; the execution is re-de
 from collections import OrderedDict
 from math import log, sqrt
 
+import os
+
 import torch
 
 from . import layers
@@ -292,7 +294,7 @@ class Level(torch.nn.Module):
 
     # patches per launch group of forward_cl: bounds the (B,N,K,264) / (B,N*r,265) temporaries of the
     # skip connection and the regressor (25 GB / 10 GB for the 15 360 level-4 patches of 8 clouds)
-    max_patches = 4096
+    max_patches = int(os.environ.get("TPU3_MAX_PATCHES", "4096"))
 
     def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):
         """Channel-last level; large batches are processed in chunks of whole owner groups (every
@@ -346,18 +348,19 @@ class Level(torch.nn.Module):
         # prep convolution reads the tail slice, so nothing is copied.
         blocks = ((self.layer1, None), (self.layer2, self.layer2_prep), (self.layer3, self.layer3_prep),
                   (self.layer4, self.layer4_prep))
-        x0 = self.layer0.forward_cl(xyz_normalized)
         widths = [blk.in_channels + blk.n * blk.growth_rate for blk, _ in blocks]
-        total = x0.size(-1) + sum(widths)
+        c0 = self.layer0.conv.out_channels
+        total = c0 + sum(widths)
         if torch.is_grad_enabled():
+            x0 = self.layer0.forward_cl(xyz_normalized)
             x = x0
             for blk, prep in blocks:
                 y, _ = blk.forward_cl(x if prep is None else prep.forward_cl(x), layout=graph_layout)
                 x = torch.cat([y, x], dim=-1)
         else:
-            feat = feat_buf if feat_buf is not None else x0.new_empty((B, N, total))
-            lo = total - x0.size(-1)
-            feat[..., lo:] = x0
+            feat = feat_buf if feat_buf is not None else xyz_normalized.new_empty((B, N, total))
+            lo = total - c0
+            x0 = self.layer0.forward_cl(xyz_normalized, also=feat[..., lo:])     # x0 and its slice in one pass
             for (blk, prep), wdt in zip(blocks, widths):
                 inp = x0 if prep is None else prep.forward_cl(feat[..., lo:])
                 blk.forward_cl(inp, layout=graph_layout, out=feat[..., lo - wdt:lo])

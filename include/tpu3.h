@@ -262,6 +262,16 @@ size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                           const float *w, const float *bias, int relu, float *y, int y_stride, int mfma);
 
+/* Per-point linear layer with a handful of INPUT channels, inference: the 3 -> 24 coordinate lift that opens
+ * every Level (network/upsampler.py:209 `layer0 = Conv2d(3, 24, [1, 1], activation=None)`, applied at :288):
+ *   y[i, 0..cout) = act(W x[i, 0..cin) + bias); optionally the same row is also stored at y2 (the slice of the
+ *   level's dense-concatenation buffer the reference builds with torch.cat, :293-311).
+ * cin <= 8, cout <= 64 and a multiple of 4, output strides multiples of 4, 16-byte aligned outputs (else
+ * TPU3_ELIMIT). */
+int tpu3_linear_lift_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                         const float *w, const float *bias, int relu, float *y, int y_stride, float *y2,
+                         int y2_stride);
+
 /* Regressor tail of a Level, inference (network/upsampler.py:363-372) for the reference's widths
  * 128 -> 128 -> 64 -> 3: for point i and replica j < r (r <= 4)
  *   out[i*r + j, 0..3) = W4 relu(W3 relu(W2 relu(a_i + c_j) + b2) + b3) + b4 + residual_i

@@ -619,6 +619,54 @@ def test_interlevel_skip_fused_matches_unfused(dev, monkeypatch):
     np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("C,K,idx_dtype", [(264, 5, torch.int64), (256, 5, torch.int32), (64, 3, torch.int64),
+                                           (288, 8, torch.int32), (272, 1, torch.int64), (300, 5, torch.int64),
+                                           (6, 2, torch.int32)])
+def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
+    """tpu3_interlevel_skip_f32 alone against network/upsampler.py:317-347 written out in float64: every row
+    layout of the kernel (one float4 per lane; the packed tail of 257..288 channels; the scalar path)."""
+    ops = pkg("network.operations")
+    g = torch.Generator(device="cpu").manual_seed(C * 10 + K)
+    B, Bp, N, M = 7, 3, 100, 150
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat = torch.randn(B, N, C, generator=g).to(dev)
+    pxyz = torch.rand(Bp, M, 3, generator=g).to(dev)
+    pfeat = torch.randn(Bp, M, C, generator=g).to(dev)
+    owner = torch.tensor([0, 0, 1, 1, 1, 2, 2], dtype=torch.int32, device=dev)
+    idx = torch.randint(0, M, (B, N, K), generator=g).to(dev).to(idx_dtype)
+    got = ops.BACKEND.interlevel_skip(xyz, feat.clone(), pxyz, pfeat, owner, idx)
+    o = owner.long().view(-1, 1, 1)
+    kf = pfeat.double()[o, idx.long()]                                     # (B,N,K,C)
+    kp = pxyz.double()[o, idx.long()]
+    ds = ((xyz.double().unsqueeze(2) - kp) ** 2).sum(-1)                   # (B,N,K)
+    df = ((feat.double().unsqueeze(2) - kf) ** 2).sum(-1)
+    hs = ds.min(-1, keepdim=True)[0].mean(-2, keepdim=True)
+    hf = df.min(-1, keepdim=True)[0].mean(-2, keepdim=True)
+    w = torch.exp(-ds / (hs / 2)) * torch.exp(-df / (hf / 2))
+    w = w / (w + 1e-5).sum(-1, keepdim=True)
+    ref = feat.double() + 0.2 * (w.unsqueeze(-1) * kf).sum(2)
+    assert (got.double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("m,cin,cout,relu", [(1000, 3, 24, False), (77, 3, 24, True), (5, 8, 64, False), (300, 1, 4, True)])
+def test_linear_lift_matches_torch(dev, m, cin, cout, relu):
+    """tpu3_linear_lift_f32 (the 3 -> 24 lift of a Level) against torch in fp64, with and without the second
+    copy of the rows into a channel slice of a wider buffer."""
+    ops = pkg("network.operations")
+    g = torch.Generator(device="cpu").manual_seed(m + cin)
+    x = torch.randn(2, m, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, generator=g).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = torch.relu(ref) if relu else ref
+    y = ops.BACKEND.linear_lift(x, w, b, relu)
+    assert y is not None and (y.double() - ref).abs().max() < 1e-5
+    wide = torch.full((2, m, cout + 40), -7.0, device=dev)
+    y2 = ops.BACKEND.linear_lift(x, w, b, relu, also=wide[..., 40:])
+    assert torch.equal(y2, y) and torch.equal(wide[..., 40:], y) and bool((wide[..., :40] == -7.0).all())
+    assert ops.BACKEND.linear_lift(torch.randn(4, 9, device=dev), torch.randn(4, 9, device=dev), None, False) is None
+
+
 @pytest.mark.parametrize("m,cin,cout,relu,off", [(1000, 84, 24, True, 180), (777, 204, 24, True, 60),
                                                 (50, 144, 24, False, 120), (33, 16, 32, True, 0),
                                                 (5, 8, 4, False, 0)])

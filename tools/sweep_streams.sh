@@ -1,4 +1,7 @@
+#!/bin/bash
+# sweep of the level chunk size (TPU3_MAX_PATCHES) and the network streams of the bench (GPU box)
 cd /root/repo
-for cfg in "--clouds 32" "--clouds 64 --net_streams 8 --sub_batch 4" "--clouds 64 --net_streams 16 --sub_batch 4" "--clouds 48 --net_streams 12 --sub_batch 4"; do
-  echo -n "$cfg: "; timeout 200 python bench.py --no_cpu_baseline --steps 12 $cfg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f M  %.1f ms/step  fps launch %.0f ms' % (d['value']/1e6, d['ms_per_step'], d['roofline']['launch_ms']))" || echo failed
-done
+for mp in 4096 1024 512 256; do for ns in 8 4 2; do
+  sb=$((32/ns)); [ $sb -gt 4 ] && sb=4
+  echo "max_patches=$mp net_streams=$ns sub_batch=$sb: $(TPU3_MAX_PATCHES=$mp python bench.py --no_cpu_baseline --no_extras --steps 6 --warmup 1 --net_streams $ns --sub_batch $sb 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]/1e6,3), round(d["ms_per_step"],1))')"
+done; done

@@ -13,12 +13,13 @@ ds = data.H5Dataset(path, num_shape_point=5000, num_patch_point=312, batch_size=
 torch.manual_seed(0)
 net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev)
 model = Model(net, "train", types.SimpleNamespace(lr_init=1e-3, ckpt=None))
-for r in (2, 4, 8, 16):
+STEPS = int(os.environ.get("STEPS", "5"))
+for r in [int(v) for v in os.environ.get("RATIOS", "2,4,8,16").split(",")]:
     ds.unset_combined(); ds.set_max_ratio(r)
     for i in range(2):
         a, b, rr = ds[i]; model.set_input(a, rr, label_pc=b); model.optimize()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 5
+    n = STEPS
     for i in range(n):
         a, b, rr = ds[i]; model.set_input(a, rr, label_pc=b); model.optimize()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / n
