@@ -903,6 +903,149 @@ __global__ __launch_bounds__(1024) void knn_sort_kernel(KnnArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// 64 < k <= 512 of at most 3072 candidates: one WAVE per query, selection by bisection
+// ---------------------------------------------------------------------------------------------
+// The patch extraction of every level asks for the k = 312 nearest of 624 .. 2496 points (upsampler.py:59-86).
+// Sorting all candidates (the kernel above: 78 compare-exchange stages over 4096 LDS slots per query) does ~15x
+// the necessary work.  Here a wave keeps the query's candidate keys in registers (mono(D), candidate
+// j = 64 p + lane), finds the k-th smallest key VALUE by bisection over the 32 key bits (count(key < trial) per
+// step: a compare and an add per register, one DPP reduction), compacts the selected ones -- everything below
+// the threshold plus the first ties in index order, the oracle's rule -- into LDS and sorts just those
+// (S = 512 slots for k = 312: 45 stages over 256 pairs).  Same distance arithmetic, same (D, j) order, same
+// treatment of dead slots as knn_sort_kernel.
+__device__ __forceinline__ int ks_wave_sum_i32(int v)
+{
+#define KS_DPP(CTRL, RM) v += __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, false)
+    KS_DPP(0xB1, 0xF);
+    KS_DPP(0x4E, 0xF);
+    KS_DPP(0x141, 0xF);
+    KS_DPP(0x140, 0xF);
+    KS_DPP(0x142, 0xA);
+    KS_DPP(0x143, 0xC);
+#undef KS_DPP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+constexpr int KS_WAVES = 4;
+constexpr int KS_SMAX = 512;
+
+template <int PT>
+__global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(KnnArgs a, int S)
+{
+    __shared__ uint64_t slots[KS_WAVES][KS_SMAX];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, qi0 = blockIdx.x * KS_WAVES + wave;
+    const int pb = a.pts_of ? a.pts_of[b] : b;
+    const int n = a.n_arr ? a.n_arr[pb] : a.n;
+    const int m = a.m_arr ? a.m_arr[b] : a.m;
+    const bool live = qi0 < m;                      // (dead waves run along: the sort below uses barriers)
+    const int qi = live ? qi0 : 0;
+    const int c = a.c, k = a.k;
+    const bool use_dup = a.dup != nullptr && a.uws[0] != 0;
+    const float dmax = use_dup ? tpu3_unmono(a.uws[4 + (a.grp ? a.grp[b] : 0)]) : 0.f;
+    const float *P = a.points + (size_t)pb * a.n * c;
+    const float *Q = a.query + ((size_t)b * a.m + qi) * c;
+    const uint8_t *DUP = use_dup ? a.dup + (size_t)pb * a.n : nullptr;
+    uint64_t *K = slots[wave];
+    float rq = 0.f;
+    for (int i = 0; i < c; ++i)
+        rq = __builtin_fmaf(Q[i], Q[i], rq);
+
+    uint32_t key[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int j = p * 64 + lane;
+        key[p] = 0xFFFFFFFFu;
+        if (j < n) {
+            const float *pr = P + (size_t)j * c;
+            float dot = 0.f, rp = 0.f;
+            for (int i = 0; i < c; ++i) {
+                const float v = pr[i];
+                dot = __builtin_fmaf(Q[i], v, dot);
+                rp = __builtin_fmaf(v, v, rp);
+            }
+            float d = __builtin_fmaf(-2.f, dot, rq) + rp;
+            if (use_dup)
+                d = d + dmax * (float)DUP[j];
+            key[p] = tpu3_mono(d);
+        }
+    }
+    // T = the k-th smallest key: the largest value with fewer than k keys below it
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            cnt += key[p] < trial ? 1 : 0;
+        if (ks_wave_sum_i32(cnt) < k)
+            T = trial;
+    }
+    int c_less = 0;
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+        c_less += key[p] < T ? 1 : 0;
+    c_less = ks_wave_sum_i32(c_less);
+    const int need = k - c_less;                    // ties taken, lowest candidate index first
+    int base_less = 0, base_tie = 0;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const bool lt = key[p] < T, eq = key[p] == T;
+        const uint64_t ml = __builtin_amdgcn_ballot_w64(lt), me = __builtin_amdgcn_ballot_w64(eq);
+        const int pl = __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0));
+        const int pe = __builtin_amdgcn_mbcnt_hi((uint32_t)(me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)me, 0));
+        const int j = p * 64 + lane;
+        // dead slots (j >= n) carry the all-ones key of knn_sort_kernel: index -1, distance unmono(~0)
+        const uint64_t packed = j < n ? ((uint64_t)key[p] << 32) | (uint32_t)j : ~0ull;
+        if (lt)
+            K[base_less + pl] = packed;
+        if (eq && base_tie + pe < need)
+            K[c_less + base_tie + pe] = packed;
+        base_less += __builtin_popcountll(ml);
+        base_tie += __builtin_popcountll(me);
+    }
+    for (int s0 = k + lane; s0 < S; s0 += 64)
+        K[s0] = ~0ull;
+    // bitonic sort of the wave's S slots, ascending (D, j)
+    for (int size = 2; size <= S; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int u = lane; u < S / 2; u += 64) {
+                const int lo = 2 * u - (u & (stride - 1));
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const uint64_t x = K[lo], y = K[hi];
+                if ((x > y) == asc) {
+                    K[lo] = y;
+                    K[hi] = x;
+                }
+            }
+        }
+    __syncthreads();
+    if (!live)
+        return;
+    const size_t o = ((size_t)b * a.m + qi) * k;
+    for (int i = lane; i < k; i += 64) {
+        const uint64_t kk = K[i];
+        store_idx(a, o + i, (int)(uint32_t)kk);
+        if (a.dist)
+            a.dist[o + i] = tpu3_unmono((uint32_t)(kk >> 32));
+    }
+}
+
+template <int PT>
+int launch_select(hipStream_t s, int b, const KnnArgs &a)
+{
+    int S = 128;
+    while (S < a.k)
+        S <<= 1;
+    hipLaunchKernelGGL((knn_select_kernel<PT>), dim3((a.m + KS_WAVES - 1) / KS_WAVES, b), dim3(64 * KS_WAVES), 0, s,
+                       a, S);
+    return tpu3_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // unique=True pre-pass
 // ---------------------------------------------------------------------------------------------
 // dup[i] = 1 iff a row j < i is elementwise equal (float ==, so -0.0 == 0.0, NaN != NaN: the
@@ -1246,6 +1389,13 @@ int dispatch_sort(hipStream_t s, int b, const KnnArgs &a)
     // data path extracts label patches of 16 x 312 = 4992 points)
     long need = a.n < 2L * a.k ? 2L * a.k : a.n;
     if (2L * a.k > 16384) return TPU3_ELIMIT;
+    if (a.k <= KS_SMAX && a.n <= 64 * 48) {         // one wave per query (knn_select_kernel)
+        if (a.n <= 64 * 10) return launch_select<10>(s, b, a);
+        if (a.n <= 64 * 20) return launch_select<20>(s, b, a);
+        if (a.n <= 64 * 32) return launch_select<32>(s, b, a);
+        if (a.n <= 64 * 40) return launch_select<40>(s, b, a);
+        return launch_select<48>(s, b, a);
+    }
     if (2L * a.k > 8192) return launch_sort<14>(s, b, a);
     if (need > 8192) need = 8192;
     if (need <= 128) return launch_sort<7>(s, b, a);

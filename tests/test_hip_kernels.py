@@ -317,6 +317,11 @@ def _knn_check(orc, dev, k, q, p, unique, layout=None):
     (2, 1, 2496, 2496, 3, False),
     (312, 2, 10, 624, 3, False),       # inner patches
     (312, 1, 40, 2496, 3, False),
+    (312, 3, 45, 1248, 3, False),      # one wave per query (knn_select_kernel): every register count
+    (400, 1, 7, 3072, 3, False),
+    (65, 2, 9, 66, 5, False),
+    (512, 1, 5, 512, 3, False),        # k == n == the sorted slots
+    (200, 2, 30, 2000, 16, True),
     (33, 10, 312, 312, 24, True),      # feature-space graph
     (17, 3, 312, 312, 24, True),
     (5, 10, 312, 312, 3, True),        # inter-level skip
@@ -457,6 +462,29 @@ def test_knn_graph_one_pass_settles_boundary_collisions(orc, dev):
             np.testing.assert_array_equal(opt[:, :, 0], ri[i:i + 1, :, 0])
             np.testing.assert_array_equal(np.sort(opt[:, :, 1:], -1), np.sort(ri[i:i + 1, :, 1:], -1))
     assert per[0] == 0 and per[3] == 0, per              # generic rows and the line never need the exact path
+
+
+def test_knn_select_ragged_sets_and_exact_ties(orc, dev):
+    """The patch extraction's shape (k = 312) with ragged point sets (upsampler.py:59-86 after the outlier
+    filter), exact distance ties (lattice points: ties go to the lowest index) and a set with fewer live points
+    than k (dead slots come back as index -1 like the sorted path)."""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(11)
+    b, n, k, m = 4, 1248, 312, 20
+    pts = rng.integers(-6, 7, size=(b, n, 3)).astype(np.float32) * np.float32(0.125)      # many equal distances
+    q = rng.integers(-6, 7, size=(b, m, 3)).astype(np.float32) * np.float32(0.125)
+    n_arr = np.array([n, 700, 313, 100], np.int32)
+    layout = dict(n_arr=_t(n_arr, dev))
+    idx, dist, _ = ops.knn_query(k, _t(q, dev), _t(pts, dev), unique=False, layout=layout, want_grouped=False)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for i in range(3):
+        ri, rd = orc.knn(k, q[i:i + 1], pts[i:i + 1, :n_arr[i]], False)
+        np.testing.assert_array_equal(idx[i], ri[0])
+        np.testing.assert_array_equal(dist[i], rd[0])
+    ri, rd = orc.knn(100, q[3:4], pts[3:4, :100], False)
+    np.testing.assert_array_equal(idx[3, :, :100], ri[0])
+    np.testing.assert_array_equal(dist[3, :, :100], rd[0])
+    assert (idx[3, :, 100:] == -1).all()
 
 
 @pytest.mark.parametrize("n", [700, 1500])
