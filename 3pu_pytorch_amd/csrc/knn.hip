@@ -1272,6 +1272,62 @@ __global__ __launch_bounds__(256) void knn_dup_hash_lookup_kernel(int n_pad, int
     }   // work items
 }
 
+// Both phases for ONE point set per workgroup with the table in LDS (sets of up to 16 384 rows: the merged
+// previous-level patches the inter-level search runs over have 624 .. 6240).  Same slots, same result as the two
+// kernels above; their device-scope atomics on a table in global memory are executed memory-side on a
+// multi-XCD part (~6 G/s for the 2.4 M of a level-4 call: 0.48 ms), LDS atomics are not.
+__global__ __launch_bounds__(1024) void knn_dup_lds_kernel(int n_pad, int c, int tsize, const float *__restrict__ points,
+                                                           const int32_t *__restrict__ n_arr,
+                                                           uint8_t *__restrict__ dup, uint32_t *__restrict__ uws)
+{
+    extern __shared__ uint32_t lds_table[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = n_arr ? n_arr[b] : n_pad;
+    const uint32_t mask = (uint32_t)(tsize - 1);
+    for (int s = tid; s < tsize; s += 1024)
+        lds_table[s] = 0xFFFFFFFFu;
+    __syncthreads();
+    const float *P = points + (size_t)b * n_pad * c;
+    for (int i = tid; i < n; i += 1024) {
+        const float *row = P + (size_t)i * c;
+        uint32_t s = knn_row_hash(row, c) & mask;
+        for (int probes = 0; probes < tsize; ++probes) {
+            uint32_t o = __hip_atomic_load(lds_table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (o == 0xFFFFFFFFu) {
+                o = atomicCAS(lds_table + s, 0xFFFFFFFFu, (uint32_t)i);
+                if (o == 0xFFFFFFFFu)
+                    break;
+            }
+            if (knn_rows_equal(P + (size_t)o * c, row, c)) {
+                atomicMin(lds_table + s, (uint32_t)i);
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+    __syncthreads();
+    bool any = false;
+    for (int i = tid; i < n; i += 1024) {
+        const float *row = P + (size_t)i * c;
+        uint32_t s = knn_row_hash(row, c) & mask;
+        uint8_t d = 0;
+        for (int probes = 0; probes < tsize; ++probes) {
+            const uint32_t o = lds_table[s];
+            if (o == 0xFFFFFFFFu || o == (uint32_t)i)
+                break;                              // (rows with a NaN never match anything, incl. themselves)
+            if (knn_rows_equal(P + (size_t)o * c, row, c)) {
+                d = 1;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+        dup[(size_t)b * n_pad + i] = d;
+        any = any || d;
+    }
+    if (any)
+        uws[0] = 1u;
+}
+
 // cand[b, :count[b]] = ascending indices of the rows of point set b that are not duplicates
 __global__ __launch_bounds__(256) void knn_compact_kernel(int n_pad, const int32_t *__restrict__ n_arr,
                                                           const uint8_t *__restrict__ dup,
@@ -1696,13 +1752,20 @@ extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, i
                            dup, uws);
         return tpu3_launch_status();
     }
+    const int tsize = knn_dup_table_size(n);
+    if ((size_t)tsize * sizeof(uint32_t) <= 128 * 1024) {       // table in LDS: one workgroup per point set
+        const int lds = tsize * (int)sizeof(uint32_t);
+        e = hipFuncSetAttribute((const void *)knn_dup_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(knn_dup_lds_kernel, dim3(bp), dim3(1024), lds, s, n, c, tsize, points, L.n_arr, dup, uws);
+        return tpu3_launch_status();
+    }
     void *ws = workspace;
     const bool own = !(workspace && workspace_bytes >= need);
     if (own) {
         e = hipMallocAsync(&ws, need, s);
         if (e != hipSuccess) return (int)e;
     }
-    const int tsize = knn_dup_table_size(n);
     e = hipMemsetAsync(ws, 0xFF, need, s);
     if (e != hipSuccess) return (int)e;
     const int nblk = (n + 255) / 256;
