@@ -463,6 +463,112 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 
 
 // ---------------------------------------------------------------------------------------------
+// y[m, cout] = x[m, cin] W^T + b with cout = 16 NT <= 128 (the per-point half of up_layer1: 264 -> 128)
+// ---------------------------------------------------------------------------------------------
+// MFMA-bound (67.6 KFLOP for 1.5 KB per row).  The whole weight matrix sits in LDS (128 x 276 floats = 141 KB,
+// one workgroup per CU = one wave per SIMD), a wave owns 16 rows at a time: its B operands (the rows, one float4
+// per 16-channel slab and lane, permuted k slots as in linear_small_kernel) are fetched a whole tile AHEAD into
+// registers -- a lone wave per SIMD has 512 of them and nobody else to hide its memory latency -- and NT
+// independent accumulator chains take the A operands from LDS as float4s, four MFMAs each.
+struct WideArgs {
+    long m;
+    int cin, cout, xs, ws, ys;
+    const float *x, *w, *b;
+    float *y;
+};
+
+constexpr int LW_WAVES = 8;         // two per SIMD: one's loads, LDS reads and address arithmetic hide under the other's MFMAs
+
+template <int NT, int NSL>
+__global__ __launch_bounds__(64 * LW_WAVES) void linear_wide_kernel(WideArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 NT][LD], zero padded
+    constexpr int LD = 16 * NSL + 4;
+    // (the rows of a column slice are not 16-byte aligned: scalar loads, eight in flight per lane)
+    constexpr int WTOT = 16 * NT * 16 * NSL, WSTEP = 64 * LW_WAVES;
+    for (int e0 = threadIdx.x; e0 < WTOT; e0 += 8 * WSTEP) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * WSTEP, WTOT - 1), o = e / (16 * NSL), ch = e - o * (16 * NSL);
+            v[u] = a.w[(size_t)o * a.ws + (ch < a.cin ? ch : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * WSTEP, o = e / (16 * NSL), ch = e - o * (16 * NSL);
+            if (e < WTOT)
+                wl[o * LD + ch] = ch < a.cin ? v[u] : 0.f;
+        }
+    }
+    float *bl = wl + 16 * NT * LD;                                   // bias, added when a tile is finished
+    for (int e = threadIdx.x; e < 16 * NT; e += 64 * LW_WAVES)
+        bl[e] = a.b ? a.b[e] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const long stride = (long)gridDim.x * LW_WAVES;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const bool last_ok = 16 * (NSL - 1) + 4 * q < a.cin;            // cin % 4 == 0: a float4 is all in or all out
+    auto row_of = [&](long tile) __attribute__((always_inline)) {
+        const long row = tile * 16 + pt;
+        return a.x + (row < a.m ? row : a.m - 1) * (long)a.xs + 4 * q;
+    };
+    auto slab = [&](const float *xr, int s) __attribute__((always_inline)) {
+        if (s + 1 < NSL)
+            return ld4(xr + 16 * s);                                // (cin > 16 (NSL - 1): checked by the entry)
+        const v4f v = ld4(xr + (last_ok ? 16 * s : 0));
+        return last_ok ? v : zero;
+    };
+    long tile = (long)blockIdx.x * LW_WAVES + wave;
+    // the wave's B operands: slab s of the NEXT tile is fetched into its register as soon as the MFMAs of slab s
+    // of this tile are issued -- a whole tile (17 k cycles) ahead of its use, one register set
+    v4f xb[NSL];
+    if (tile < ntiles) {
+        const float *xr = row_of(tile);
+#pragma unroll
+        for (int s = 0; s < NSL; ++s)
+            xb[s] = slab(xr, s);
+    }
+    for (; tile < ntiles; tile += stride) {
+        const float *xrn = row_of(tile + stride < ntiles ? tile + stride : tile);
+        v4f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = zero;
+        const float *wr = wl + pt * LD + 4 * q;
+        // A operands one slab ahead of the MFMAs that use them (the fences keep the compiler from hoisting all 17
+        // slabs of LDS reads -- 544 registers -- to the top)
+        v4f av[2][NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            av[0][t] = *(const v4f *)(wr + 16 * t * LD);
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            if (s + 1 < NSL) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    av[(s + 1) & 1][t] = *(const v4f *)(wr + 16 * t * LD + 16 * (s + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][t][j], xb[s][j], acc[t], 0, 0, 0);
+            xb[s] = slab(xrn, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long row = tile * 16 + pt;
+        if (row < a.m) {
+            float *yr = a.y + row * (long)a.ys + 4 * q;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                *(v4f *)(yr + 16 * t) = acc[t] + *(const v4f *)(bl + 16 * t + 4 * q);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // y[m, cout] = act(x[m, cin] W^T + b) for a handful of input channels (the 3 -> 24 lift of a Level)
 // ---------------------------------------------------------------------------------------------
 // HBM-bound: 4 cin B read, 4 cout B written per row (twice when the row is also stored into the level's feature
@@ -506,6 +612,29 @@ __global__ __launch_bounds__(256) void linear_lift_kernel(LiftArgs a)
 }
 
 } // namespace
+
+extern "C" int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                                    const float *w, int w_stride, const float *bias, float *y, int y_stride)
+{
+    if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
+    if (x_stride < cin || y_stride < cout || w_stride < cin) return TPU3_EINVAL;
+    // instantiated: 128 outputs, 257 .. 272 input channels (the reference's 264)
+    if (cout != 128 || cin % 4 || cin <= 256 || cin > 272 || x_stride % 4 || y_stride % 4) return TPU3_ELIMIT;
+    if (m == 0) return TPU3_OK;
+    if (!x || !w || !y) return TPU3_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) != 0) return TPU3_ELIMIT;
+    WideArgs a{m, cin, cout, x_stride, w_stride, y_stride, x, w, bias, y};
+    constexpr int NT = 8, NSL = 17;
+    const int lds = (16 * NT * (16 * NSL + 4) + 16 * NT) * (int)sizeof(float);
+    const hipError_t e = hipFuncSetAttribute((const void *)linear_wide_kernel<NT, NSL>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    long blocks = ((m + 15) / 16 + LW_WAVES - 1) / LW_WAVES;
+    if (blocks > 256) blocks = 256;                 // persistent: one workgroup per CU holds the weights
+    hipLaunchKernelGGL((linear_wide_kernel<NT, NSL>), dim3((unsigned)blocks), dim3(64 * LW_WAVES), lds,
+                       (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
 
 extern "C" int tpu3_linear_lift_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                                     const float *w, const float *bias, int relu, float *y, int y_stride,

@@ -322,6 +322,24 @@ class HipBackend(object):
                     "tpu3_linear_small_f32")
         return y
 
+    def linear_wide(self, x, weight, bias):
+        """Per-point linear layer with 128 outputs (the per-point half of up_layer1): x (..., C_in) contiguous,
+        weight (128, C_in) with unit column stride (a column slice of a wider matrix is fine) -> (..., 128),
+        or None when the shape is not covered (the caller then uses the library GEMM)."""
+        cin, cout = x.size(-1), weight.size(0)
+        if (cout != 128 or cin % 4 or not 256 < cin <= 272 or x.dtype != torch.float32 or not x.is_contiguous()
+                or weight.stride(1) != 1 or weight.dtype != torch.float32 or (x.data_ptr() & 15)):
+            return None
+        if bias is not None and (not bias.is_contiguous() or (bias.data_ptr() & 15)):
+            return None
+        m = x.numel() // cin
+        y = torch.empty(x.shape[:-1] + (cout,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_linear_wide_f32(L.stream_of(x), m, cin, cout, L.ptr(x), cin, L.ptr(weight),
+                                                 weight.stride(0), L.ptr(bias), L.ptr(y), cout),
+                    "tpu3_linear_wide_f32")
+        return y
+
     def linear_lift(self, x, weight, bias, relu, also=None):
         """Per-point linear layer with <= 8 input channels (the 3 -> 24 lift of a Level): x (..., C_in)
         contiguous rows, weight (C_out, C_in) -> (..., C_out) contiguous; `also`: a (..., C_out) view with unit

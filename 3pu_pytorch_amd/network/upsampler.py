@@ -424,7 +424,11 @@ class Level(torch.nn.Module):
             if f16:     # the per-point half of up_layer1 as an fp16 GEMM (hipBLASLt -> MFMA), fp32 result
                 a = torch.nn.functional.linear(x.half(), w[:, :cin].half(), up1.conv.bias.half()).float()
             else:
-                a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)             # (B,N,128)
+                a = None
+                if x.is_cuda and hasattr(operations.BACKEND, "linear_wide"):
+                    a = operations.BACKEND.linear_wide(x, w[:, :cin], up1.conv.bias)    # (B,N,128), csrc/mlp.hip
+                if a is None:
+                    a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)
             c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])          # (r,128)
             up2, fc1, fc2 = self.up_layer.up_layer2, self.fc_layer1, self.fc_layer2
             be = operations.BACKEND

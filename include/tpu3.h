@@ -262,6 +262,17 @@ size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                           const float *w, const float *bias, int relu, float *y, int y_stride, int mfma);
 
+/* Per-point linear layer with a WIDE output, inference: the per-point half of up_layer1
+ * (network/upsampler.py:222 `up_layer1 = Conv2d(265, 128, ...)`, applied at :363 to [features ; code]: the first
+ * 264 input channels are the same for the r replicas of a point, so W[:, :264] x_i + bias is computed once per
+ * point and handed to tpu3_regress_tail_f32 as `a`):
+ *   y[i, 0..cout) = W x[i, 0..cin) + bias,   w (cout, w_stride) row-major with w_stride >= cin (a column slice of
+ *   the convolution weight is fine), bias (cout) or NULL.
+ * Instantiated for cout = 128 and 256 < cin <= 272, cin and the row strides multiples of 4, x / y / bias 16-byte
+ * aligned (else TPU3_ELIMIT: callers then use their library GEMM). */
+int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                         const float *w, int w_stride, const float *bias, float *y, int y_stride);
+
 /* Per-point linear layer with a handful of INPUT channels, inference: the 3 -> 24 coordinate lift that opens
  * every Level (network/upsampler.py:209 `layer0 = Conv2d(3, 24, [1, 1], activation=None)`, applied at :288):
  *   y[i, 0..cout) = act(W x[i, 0..cin) + bias); optionally the same row is also stored at y2 (the slice of the

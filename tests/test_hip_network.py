@@ -648,6 +648,21 @@ def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
     assert (got.double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("m,cin", [(5000, 264), (17, 264), (1, 260), (4099, 272)])
+def test_linear_wide_matches_torch(dev, m, cin):
+    """tpu3_linear_wide_f32 (per-point half of up_layer1, 264 -> 128) against torch in fp64; the weight is a
+    column slice of the (128, 265) convolution weight like at its call site."""
+    ops = pkg("network.operations")
+    g = torch.Generator(device="cpu").manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g).to(dev)
+    wfull = (torch.randn(128, cin + 1, generator=g) / cin ** 0.5).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    y = ops.BACKEND.linear_wide(x, wfull[:, :cin], b)
+    ref = torch.nn.functional.linear(x.double(), wfull[:, :cin].double(), b.double())
+    assert y is not None and (y.double() - ref).abs().max() < 1e-5
+    assert ops.BACKEND.linear_wide(torch.randn(8, 128, device=dev), torch.randn(128, 128, device=dev), None) is None
+
+
 @pytest.mark.parametrize("m,cin,cout,relu", [(1000, 3, 24, False), (77, 3, 24, True), (5, 8, 64, False), (300, 1, 4, True)])
 def test_linear_lift_matches_torch(dev, m, cin, cout, relu):
     """tpu3_linear_lift_f32 (the 3 -> 24 lift of a Level) against torch in fp64, with and without the second
