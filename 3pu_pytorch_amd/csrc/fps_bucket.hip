@@ -1102,17 +1102,26 @@ struct RmShared {
     int npick[2];
 };
 
-constexpr size_t rm_lds_bytes(int rows)
+// 16 waves x 25 rows (the largest sets): 25 rows of x, y, z leave no registers for 25 rows of running distances,
+// so RM_PT_REG rows of them stay in registers and the rest live in LDS, which the tie keys vacate by shrinking to
+// the 16-bit original index (n <= 25 600; key = tpu3_fps_tiekey(index)).
+constexpr int RM_PT_REG = 2;
+constexpr bool rm_k16(int r, int nw) { return r == 25 && nw == 16; }
+constexpr size_t rm_lds_bytes(int r, int nw)
 {
-    return (size_t)rows * 64 * 4 + (size_t)rows * 6 * 4 + sizeof(RmShared) + 64;
+    const size_t rows = (size_t)r * nw;
+    return (rm_k16(r, nw) ? rows * 64 * 2 + (size_t)nw * (r - RM_PT_REG) * 64 * 4 : rows * 64 * 4) + rows * 6 * 4 +
+           sizeof(RmShared) + 64;
 }
 
-// NW waves x R rows each.  16 waves of up to 20 rows (128 registers per lane); the largest sets (<= 25 600 points)
-// take 8 waves of 50 rows (two waves per SIMD, 256 registers per lane) -- 25 rows of points plus the selection
-// state do not fit 128 registers.
-template <int R, int NW>
+// NW waves x R rows each: 16 waves of up to 25 rows (128 registers per lane).  The largest sets (<= 25 600 points,
+// 25 rows) keep only x, y, z in registers (rm_k16 above); an 8-wave x 50-row form with everything in 256
+// registers was 8 % slower (half the waves to share a round's re-scans, 7.6 vs 6.4 us per round under load).
+template <int R, int NW, bool PROF = false>
 __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
 {
+    auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2, tail
     constexpr int ROWS = NW * R;
     constexpr int RM_WCAP = FM_CAP / NW;    // candidates a wave may enter per round
     static_assert(NW == 16 || NW == 8, "waves per workgroup");
@@ -1120,8 +1129,12 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: tie keys [wave][slot][lane] and row records [wave][slot]{max, key, x, y, z, runner-up}: everything a
     // wave touches in the round loop is its own base address plus a compile-time offset
+    constexpr bool K16 = rm_k16(R, NW);
+    constexpr int RREG = K16 ? RM_PT_REG : R;       // rows whose running distances stay in registers
     uint32_t *skl = (uint32_t *)smem;
-    uint32_t *tbl = skl + ROWS * 64;
+    uint16_t *skl16 = (uint16_t *)smem;
+    float *ptl = (float *)(smem + (size_t)ROWS * 64 * 2);
+    uint32_t *tbl = K16 ? (uint32_t *)(ptl + NW * (R - RREG) * 64) : skl + ROWS * 64;
     RmShared &sh = *(RmShared *)(tbl + ROWS * 6);
     const FbArgs a = fb_elem(a0, blockIdx.x);
     if (a.n <= 0 || a.m <= 0)
@@ -1129,10 +1142,18 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = a.lb;
     uint32_t *kw = skl + wave * R * 64 + lane;      // this lane's keys: kw[64 * j]
+    uint16_t *kw16 = skl16 + wave * R * 64 + lane;  // (K16) this lane's original indices
+    float *pw = ptl + wave * (R - RREG) * 64 + lane;    // (K16) this lane's distances of rows >= RREG
     uint32_t *tw = tbl + wave * R * 6;              // this wave's records: tw[6 * j + field]
+    auto key_of = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        if (!K16)
+            return kw[64 * j];
+        const uint32_t i16 = kw16[64 * j];
+        return i16 == 0xFFFFu ? 0xFFFFFFFFu : tpu3_fps_tiekey((int)i16, lb);
+    };
 
     // row r = 16 * slot + wave (neighbouring rows go to different waves); lane l holds point 64 r + l
-    float px[R], py[R], pz[R], pt[R];
+    float px[R], py[R], pz[R], pt[RREG];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int slot = (j * NW + wave) * 64 + lane;
@@ -1142,8 +1163,15 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
             v = a.sp[slot];
             key = a.skey[slot];
         }
-        px[j] = v.x; py[j] = v.y; pz[j] = v.z; pt[j] = v.w;
-        kw[64 * j] = key;
+        px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+        if (j < RREG)
+            pt[j] = v.w;
+        else
+            pw[64 * (j - RREG)] = v.w;
+        if (K16)
+            kw16[64 * j] = key == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)tpu3_fps_tiekey_to_index(key, lb);
+        else
+            kw[64 * j] = key;
     }
     // Row records and boxes come from the bucket-init kernel (a row is a 64-point bucket); lane j < R
     // keeps row j's AABB (fp16, rounded outward, packed), current maximum and runner-up in registers
@@ -1184,25 +1212,32 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
     // and the row's runner-up, published to the row's record; returns both (wave-uniform)
     auto rescan = [&](auto jc, uint32_t pm, int &wrun) __attribute__((always_inline)) -> int {
         constexpr int j = decltype(jc)::value;
-        float t = pt[j];
+        float t;
+        if constexpr (j < RREG)
+            t = pt[j];
+        else
+            t = pw[64 * (j - RREG)];
         while (pm) {
             const int i = __builtin_ctz(pm);
             pm &= pm - 1;
             t = fminf(tpu3_sqdist3(px[j] - rl(sx, i), py[j] - rl(sy, i), pz[j] - rl(sz, i)), t);
         }
-        pt[j] = t;
+        if constexpr (j < RREG)
+            pt[j] = t;
+        else
+            pw[64 * (j - RREG)] = t;
         const int bits = __float_as_int(t);
         const int wmax = tpu3_wave_max_i32_fast(bits);
         unsigned long long tie = __ballot(bits == wmax);
         if (__builtin_popcountll(tie) != 1) {                    // duplicated points: smallest tie key
-            const uint32_t k = kw[64 * j];
+            const uint32_t k = key_of(j);
             const uint32_t kmin = tpu3_wave_min_u32(bits == wmax ? k : 0xFFFFFFFFu);
             tie = __ballot(bits == wmax && k == kmin);
         }
         const bool win = lane == (int)__builtin_ctzll(tie);
         wrun = tpu3_wave_max_i32_fast(win ? (int)0x80000000 : bits);
         if (win) {
-            tw[6 * j + 0] = (uint32_t)wmax; tw[6 * j + 1] = kw[64 * j];
+            tw[6 * j + 0] = (uint32_t)wmax; tw[6 * j + 1] = key_of(j);
             tw[6 * j + 2] = __float_as_uint(px[j]); tw[6 * j + 3] = __float_as_uint(py[j]);
             tw[6 * j + 4] = __float_as_uint(pz[j]); tw[6 * j + 5] = (uint32_t)wrun;
         }
@@ -1233,7 +1268,9 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
 
     if (a.m > 1)
         for (int round = 0;; ++round) {
+            if (PROF) t0 = now();
             apply(J);
+            if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
             // ---- select the next samples -------------------------------------------------------------
             const int par = round & 1;
             uint32_t *cl = sh.cand[par];
@@ -1274,7 +1311,9 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
                     h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
                 }
             }
+            if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
             __syncthreads();
+            if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
             // With 16 (8) waves on 4 SIMDs a ranking repeated by every wave would be issue-bound: wave 0 ranks,
             // the others wait at a second barrier and read the round's samples from LDS.
             const int left = a.m - r;
@@ -1362,7 +1401,9 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
                     sh.h[par][0].rmax = nrstar;             // (every wave picks the new bound up from here)
                 }
             }
+            if (PROF) { t1 = now(); pc[3] += t1 - t0; t0 = t1; }
             __syncthreads();
+            if (PROF) { t1 = now(); pc[4] += t1 - t0; t0 = t1; }
             J = sh.npick[par];
             rstar = sh.h[par][0].rmax;
             sx = sh.pick[par][lane & (FM_CAP - 1)][0];
@@ -1370,6 +1411,13 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
             sz = sh.pick[par][lane & (FM_CAP - 1)][2];
             r += J;
             if (r >= a.m) {
+                if (a0.prof && blockIdx.x == 0 && tid == 0) {       // development probe: rounds, samples
+                    a0.prof[0] = (unsigned long long)(round + 1);
+                    a0.prof[1] = (unsigned long long)r;
+                }
+                if (PROF && a0.prof && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1))
+                    for (int i = 0; i < 6; ++i)
+                        a0.prof[2 + wave * 6 + i] = pc[i];
                 if (J > 1)
                     apply(J - 1);                       // every sample but the last one updates `temp`
                 break;
@@ -1378,9 +1426,10 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
     // final running distances, back in the caller's order
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const uint32_t key = kw[64 * j];
+        const uint32_t key = key_of(j);
+        const float t = j < RREG ? pt[j < RREG ? j : 0] : pw[64 * (j < RREG ? 0 : j - RREG)];
         if (key != 0xFFFFFFFFu)
-            a.temp[tpu3_fps_tiekey_to_index(key, lb)] = pt[j];
+            a.temp[tpu3_fps_tiekey_to_index(key, lb)] = t;
     }
 }
 
@@ -1416,16 +1465,15 @@ using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 
 bool fb_plan(int b, int n, FbPlan &p)
 {
-    p.rb_rows = 0;                  // rows per wave for 16 waves (<= 20), or 50 = the 8-wave form
-    if (n <= RB_MAX_N) {
+    p.rb_rows = 0;                  // rows per wave (16 waves)
+    static const int rb_max_n = getenv("TPU3_RB_MAX_N") ? atoi(getenv("TPU3_RB_MAX_N")) : RB_MAX_N;   // (tuning hook)
+    if (n <= rb_max_n) {
         const int rows = ((n + 63) / 64 + 15) / 16;
-        for (int r : {4, 7, 10, 13, 16, 20})
+        for (int r : {4, 7, 10, 13, 16, 20, 25})
             if (r >= rows) {
                 p.rb_rows = r;
                 break;
             }
-        if (!p.rb_rows)
-            p.rb_rows = 50;
     }
     // 64-point buckets throughout.  Up to FB_NB_MAX of them the bucket table itself sits in LDS (two levels);
     // beyond, LDS holds cells of 16 leaf buckets and the leaf table stays in global memory (three levels).
@@ -1477,6 +1525,9 @@ bool fb_plan(int b, int n, FbPlan &p)
 // measurement hook (bench.py): events recorded on the launch stream immediately around the next
 // fm_main_kernel launch, see tpu3_debug_fps_bucket_events
 hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+// development probe: two device words that the register-resident multi-sample kernel of the NEXT call fills with
+// (rounds, samples) of its first set, see tpu3_debug_fps_level_stats
+unsigned long long *g_level_stats = nullptr;
 
 template <int PPL, bool PROF>
 int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
@@ -1563,8 +1614,10 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     if (p.rb_rows && !prof && p.ppl == 1) {
         // the set fits the register file: rows (= 64-point buckets) in VGPRs, no write-back pass
         hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
-        const int rm_nw = p.rb_rows == 50 ? 8 : 16;
-        const size_t lds = rm_lds_bytes(rm_nw * p.rb_rows);
+        const int rm_nw = 16;
+        a0.prof = g_level_stats;
+        g_level_stats = nullptr;
+        const size_t lds = rm_lds_bytes(p.rb_rows, rm_nw);
         hipError_t e = hipSuccess;
 #define RB_LAUNCH(RR, WW)                                                                                \
     e = hipFuncSetAttribute((const void *)rm_main_kernel<RR, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1591,7 +1644,16 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         case 13: RB_LAUNCH(13, 16); break;
         case 16: RB_LAUNCH(16, 16); break;
         case 20: RB_LAUNCH(20, 16); break;
-        default: RB_LAUNCH(50, 8); break;
+        default:
+            if (a0.prof) {      // development probe: per-phase cycle counters of waves 0 and 1
+                e = hipFuncSetAttribute((const void *)rm_main_kernel<25, 16, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL((rm_main_kernel<25, 16, true>), dim3(b), dim3(16 * 64), lds, s, a0);
+            } else {
+                RB_LAUNCH(25, 16);
+            }
+            break;
         }
 #undef RB_LAUNCH
         return tpu3_launch_status();
@@ -1627,6 +1689,12 @@ extern "C" int tpu3_debug_fps_bucket_events(void *start, void *stop)
 {
     g_ev_start = (hipEvent_t)start;
     g_ev_stop = (hipEvent_t)stop;
+    return TPU3_OK;
+}
+
+extern "C" int tpu3_debug_fps_level_stats(unsigned long long *stats)
+{
+    g_level_stats = stats;
     return TPU3_OK;
 }
 
