@@ -1433,6 +1433,331 @@ __global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same exact several-samples-per-round scheme with a LANE per bucket
+// ---------------------------------------------------------------------------------------------
+// rm_main_kernel keeps a 64-point row across the lanes of a wave: every row a sample reaches costs two
+// dependent wave-wide reductions (maximum, runner-up) plus a record write, ~700 cycles of latency each, and a
+// round re-scans 4 .. 5 rows per wave one after the other.  Here a LANE owns a bucket of R Morton-consecutive
+// points (1024 buckets per set): bucket maximum, runner-up and the winner's coordinates are per-lane register
+// state, a sample's box test covers 64 buckets per instruction, a reached wave updates its R x 64 distances with
+// plain per-lane arithmetic and re-derives the lanes' records once per round; only the wave's arg-max and
+// runner-up bound need cross-lane reductions -- two per ROUND instead of two per ROW.  Finer buckets (R = 25
+// instead of 64 points) also lower the runner-up bound R*, i.e. more candidates qualify per round.
+constexpr int RL_CAP = 32;          // candidates per round
+template <int R> constexpr bool rl_zl() { return R > 13; }       // z coordinates in LDS (registers: x, y, distance)
+
+struct RlShared {
+    FmHeader h[2][16];
+    uint32_t cand[2][RL_CAP * RM_EW];
+    float pick[2][RL_CAP][4];
+    int npick[2];
+};
+
+constexpr size_t rl_lds_bytes(int r, bool zl)
+{
+    return (size_t)1024 * r * 2 + (zl ? (size_t)1024 * r * 4 : 0) + sizeof(RlShared) + 64;
+}
+
+template <int R, bool PROF = false>
+__global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
+{
+    constexpr int NW = 16, WCAP = RL_CAP / NW;
+    constexpr bool ZL = rl_zl<R>();
+    auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *i16 = (uint16_t *)smem;                               // original index of [wave][j][lane]
+    float *zl = (float *)(smem + (size_t)1024 * R * 2);             // (ZL) z of [wave][j][lane]
+    RlShared &sh = *(RlShared *)(zl + (ZL ? 1024 * R : 0));
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    if (a.n <= 0 || a.m <= 0)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = a.lb;
+    uint16_t *kw = i16 + wave * R * 64 + lane;      // kw[64 * j]
+    float *zw = zl + wave * R * 64 + lane;          // (ZL) zw[64 * j]
+    auto key_at = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t v = kw[64 * j];
+        return v == 0xFFFFu ? 0xFFFFFFFFu : tpu3_fps_tiekey((int)v, lb);
+    };
+
+    // bucket `tid` = sorted points [tid R, tid R + R)
+    float px[R], py[R], pz[ZL ? 1 : R], pt[R];
+    float blx = __builtin_inff(), bly = blx, blz = blx, bhx = -blx, bhy = -blx, bhz = -blx;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int slot = tid * R + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, -1.0f);
+        uint32_t key = 0xFFFFFFFFu;
+        if (slot < a0.npad) {
+            v = a.sp[slot];
+            key = a.skey[slot];
+        }
+        px[j] = v.x; py[j] = v.y; pt[j] = v.w;
+        if (ZL)
+            zw[64 * j] = v.z;
+        else
+            pz[ZL ? 0 : j] = v.z;
+        const bool alive = key != 0xFFFFFFFFu;
+        kw[64 * j] = alive ? (uint16_t)tpu3_fps_tiekey_to_index(key, lb) : (uint16_t)0xFFFFu;
+        blx = alive ? fminf(blx, v.x) : blx; bly = alive ? fminf(bly, v.y) : bly; blz = alive ? fminf(blz, v.z) : blz;
+        bhx = alive ? fmaxf(bhx, v.x) : bhx; bhy = alive ? fmaxf(bhy, v.y) : bhy; bhz = alive ? fmaxf(bhz, v.z) : bhz;
+    }
+    auto ld_z = [&](auto jc) __attribute__((always_inline)) -> float {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (ZL)
+            return zw[64 * j];
+        else
+            return pz[j];
+    };
+
+    // the lane's record: bucket maximum (distance bits), runner-up, the winner's slot and coordinates
+    int lmax = (int)0x80000000, lrun = (int)0x80000000, larg = 0;
+    float lbx = 0.f, lby = 0.f, lbz = 0.f;
+    auto lane_scan = [&]() __attribute__((always_inline)) {
+        int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int tb = __float_as_int(pt[j]);
+            const bool gt = tb > best;
+            run = gt ? best : max(run, tb);
+            best = gt ? tb : best;
+            arg = gt ? j : arg;
+            bx = gt ? px[j] : bx; by = gt ? py[j] : by;
+            if constexpr (!ZL)
+                bz = gt ? pz[j] : bz;
+        });
+        // equal maxima inside the bucket (duplicated points): the smallest tie key wins
+        if (__ballot(run == best && best >= 0)) {
+            uint32_t bk = 0xFFFFFFFFu;
+            rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                const int tb = __float_as_int(pt[j]);
+                const uint32_t kj = key_at(j);
+                const bool take = run == best && tb == best && kj < bk;
+                bk = take ? kj : bk;
+                arg = take ? j : arg;
+                bx = take ? px[j] : bx; by = take ? py[j] : by;
+                if constexpr (!ZL)
+                    bz = take ? pz[j] : bz;
+            });
+        }
+        if constexpr (ZL)
+            bz = zw[64 * arg];
+        lmax = best; lrun = run; larg = arg; lbx = bx; lby = by; lbz = bz;
+    };
+    lane_scan();
+    __syncthreads();
+
+    if (tid == 0)
+        a.idx[0] = 0;
+    // current samples: lane i < J holds sample i; start with point 0
+    float sx = a.xyz[0], sy = a.xyz[1], sz = a.xyz[2];
+    int J = 1, r = 1, rstar = 0x7FFFFFFF;
+    auto rl = [](float v, int i) __attribute__((always_inline)) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    };
+
+    // fold the first nj current samples into the buckets they reach.  A sample that does not reach a bucket (box
+    // distance >= the bucket's maximum) cannot lower any of its distances, so a reached wave updates all of its
+    // lanes unconditionally; a wave no sample reaches does nothing.
+    auto apply = [&](int nj) __attribute__((always_inline)) {
+        bool touched = false;
+        for (int i = 0; i < nj; ++i) {
+            const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);
+            if (!__ballot(fb_dbox(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz) < __int_as_float(lmax)))
+                continue;
+            touched = true;
+            rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                pt[j] = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
+                if constexpr (ZL && j % 8 == 7)
+                    __builtin_amdgcn_sched_barrier(0);      // (eight LDS reads in flight, not all R: registers)
+            });
+        }
+        if (touched)
+            lane_scan();
+    };
+
+    if (a.m > 1)
+        for (int round = 0;; ++round) {
+            if (PROF) t0 = now();
+            apply(J);
+            if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
+            // ---- select the next samples -------------------------------------------------------------
+            const int par = round & 1;
+            uint32_t *cl = sh.cand[par];
+            const int mine = lmax;
+            {
+                const int wv = tpu3_wave_max_i32_fast(mine);
+                const int wr = tpu3_wave_max_i32_fast(lrun);
+                bool is_cand = mine > rstar;
+                unsigned long long tie = __ballot(mine == wv);
+                // keys are fetched by the lanes that need one: the wave's best (ties: all of them), the candidates
+                const bool multi = __builtin_popcountll(tie) != 1;
+                uint32_t rk = 0xFFFFFFFFu;
+                if (is_cand || mine == wv)
+                    rk = key_at(larg);
+                if (multi) {
+                    const uint32_t kmin = tpu3_wave_min_u32(mine == wv ? rk : 0xFFFFFFFFu);
+                    tie = __ballot(mine == wv && rk == kmin);
+                }
+                const int wlane = __builtin_ctzll(tie);
+                unsigned long long cm = __ballot(is_cand);
+                int drop = (int)0x80000000;
+                if (__builtin_popcountll(cm) > WCAP) {
+                    int lrank = 0;
+                    for (unsigned long long mm = cm; mm;) {
+                        const int i = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const int mi = __builtin_amdgcn_readlane(mine, i);
+                        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)rk, i);
+                        lrank += (mi > mine || (mi == mine && ki < rk)) ? 1 : 0;
+                    }
+                    const bool keep = is_cand && lrank < WCAP;
+                    drop = tpu3_wave_max_i32_fast(is_cand && !keep ? mine : (int)0x80000000);
+                    is_cand = keep;
+                    cm = __ballot(is_cand);
+                }
+                if (is_cand) {
+                    uint32_t *e = cl + (wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RM_EW;
+                    e[0] = (uint32_t)mine; e[1] = rk;
+                    e[2] = __float_as_uint(lbx); e[3] = __float_as_uint(lby); e[4] = __float_as_uint(lbz);
+                }
+                if (lane == wlane) {
+                    FmHeader &h = sh.h[par][wave];
+                    h.best = wv; h.key = rk; h.x = lbx; h.y = lby; h.z = lbz;
+                    h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
+                }
+            }
+            if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
+            __syncthreads();
+            if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
+            // wave 0 ranks the candidates (as in rm_main_kernel); the others wait at a second barrier
+            const int left = a.m - r;
+            if (wave == 0) {
+                const FmHeader &hh = sh.h[par][lane & 15];
+                const int sd = lane < 16 ? hh.best : (int)0x80000000;
+                const uint32_t sk = lane < 16 ? hh.key : 0xFFFFFFFFu;
+                const int sr = lane < 16 ? hh.rmax : (int)0x80000000;
+                const int sdrop = lane < 16 ? hh.drop : (int)0x80000000;
+                const float hx = hh.x, hy = hh.y, hz = hh.z;
+                const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+                const int nrstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+                const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
+                // candidate `lane` of the list: wave lane / WCAP, entry lane % WCAP
+                const bool live = lane < RL_CAP && (lane % WCAP) < sh.h[par][(lane / WCAP) & 15].count;
+                const unsigned long long lm = __ballot(live);
+                const int total = __builtin_popcountll(lm);
+                float qx, qy, qz;
+                uint32_t okey;
+                int nj;
+                if (total < 2) {
+                    // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
+                    unsigned long long who = __ballot(lane < 16 && sd == gbest);
+                    if (__builtin_popcountll(who) != 1) {
+                        const uint32_t wk = tpu3_row_min_u32(lane < 16 && sd == gbest ? sk : 0xFFFFFFFFu);
+                        const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)wk, 0);
+                        who = __ballot(lane < 16 && sd == gbest && sk == win);
+                    }
+                    const int ww = __builtin_ctzll(who | (1ull << 63)) & 15;
+                    qx = rl(hx, ww); qy = rl(hy, ww); qz = rl(hz, ww);
+                    okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
+                    nj = 1;
+                } else {
+                    const uint32_t *e = cl + (lane & (RL_CAP - 1)) * RM_EW;
+                    const int cM = live ? (int)e[0] : (int)0x80000000;
+                    const uint32_t cK = live ? e[1] : 0xFFFFFFFFu;
+                    const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
+                    int rank = 0;
+                    bool tie = false;
+                    for (unsigned long long mm = lm; mm;) {
+                        const int i = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const int mi = __builtin_amdgcn_readlane(cM, i);
+                        rank += mi > cM ? 1 : 0;
+                        tie |= (mi == cM && i != lane);
+                    }
+                    if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
+                        rank = 0;
+                        for (unsigned long long mm = lm; mm;) {
+                            const int i = __builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const int mi = __builtin_amdgcn_readlane(cM, i);
+                            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
+                            rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
+                        }
+                    }
+                    const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
+                    const int dst = (live ? rank : deadpos) * 4;
+                    qx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cx)));
+                    qy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cy)));
+                    qz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cz)));
+                    okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
+                    const int sM = __builtin_amdgcn_ds_permute(dst, cM);
+                    int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
+                    jmax = jmax < 1 ? 1 : jmax;
+                    jmax = jmax < left ? jmax : left;
+                    for (int i = 0; i + 1 < jmax; ++i) {
+                        const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
+                        const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
+                        if (hit) {
+                            const int f = __builtin_ctzll(hit);
+                            jmax = f < jmax ? f : jmax;
+                        }
+                    }
+                    nj = jmax;
+                }
+                nj = nj < left ? nj : left;
+                if (lane < RL_CAP) {
+                    sh.pick[par][lane][0] = qx; sh.pick[par][lane][1] = qy; sh.pick[par][lane][2] = qz;
+                }
+                if (lane < nj)
+                    a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
+                if (lane == 0) {
+                    sh.npick[par] = nj;
+                    sh.h[par][0].rmax = nrstar;             // (every wave picks the new bound up from here)
+                }
+            }
+            if (PROF) { t1 = now(); pc[3] += t1 - t0; t0 = t1; }
+            __syncthreads();
+            if (PROF) { t1 = now(); pc[4] += t1 - t0; t0 = t1; }
+            J = sh.npick[par];
+            rstar = sh.h[par][0].rmax;
+            sx = sh.pick[par][lane & (RL_CAP - 1)][0];
+            sy = sh.pick[par][lane & (RL_CAP - 1)][1];
+            sz = sh.pick[par][lane & (RL_CAP - 1)][2];
+            r += J;
+            if (r >= a.m) {
+                if (a0.prof && blockIdx.x == 0 && tid == 0) {       // development probe: rounds, samples
+                    a0.prof[0] = (unsigned long long)(round + 1);
+                    a0.prof[1] = (unsigned long long)r;
+                }
+                if (PROF && a0.prof && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1))
+                    for (int i = 0; i < 6; ++i)
+                        a0.prof[2 + wave * 6 + i] = pc[i];
+                if (J > 1) {                            // every sample but the last one updates `temp`
+                    for (int i = 0; i + 1 < J; ++i) {
+                        const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);
+                        rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            pt[j] = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
+                        });
+                    }
+                }
+                break;
+            }
+        }
+    // final running distances, back in the caller's order
+    rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+        const uint32_t v = kw[64 * decltype(jc)::value];
+        if (v != 0xFFFFu)
+            a.temp[v] = pt[decltype(jc)::value];
+    });
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
@@ -1611,6 +1936,30 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
     }
     hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
+    // TPU3_RL (tuning hook): 0 = never, 1 (default) = sets of up to 13 312 points, 2 = also the largest sets (where
+    // 25 points per lane make a reached wave's update as slow as rm_main_kernel's row re-scans: 5.65 vs 5.36 ms)
+    static const int use_rl = getenv("TPU3_RL") ? atoi(getenv("TPU3_RL")) : 1;
+    if (p.rb_rows && !prof && p.ppl == 1 && use_rl && n > 1024 * 4 && m >= 256 && (use_rl > 1 || n <= 1024 * 13)) {
+        // a lane per bucket of R Morton-consecutive points (rl_main_kernel)
+        a0.prof = g_level_stats;
+        g_level_stats = nullptr;
+        hipError_t e = hipSuccess;
+#define RL_LAUNCH(RR, PP)                                                                                 \
+    {                                                                                                     \
+        const size_t lds = rl_lds_bytes(RR, rl_zl<RR>());                                               \
+        e = hipFuncSetAttribute((const void *)rl_main_kernel<RR, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                \
+        if (e != hipSuccess) return (int)e;                                                               \
+        hipLaunchKernelGGL((rl_main_kernel<RR, PP>), dim3(b), dim3(1024), lds, s, a0);                    \
+    }
+        const int rr = (n + 1023) / 1024;
+        if (rr <= 7) RL_LAUNCH(7, false)
+        else if (rr <= 13) RL_LAUNCH(13, false)
+        else if (a0.prof) RL_LAUNCH(25, true)
+        else RL_LAUNCH(25, false)
+#undef RL_LAUNCH
+        return tpu3_launch_status();
+    }
     if (p.rb_rows && !prof && p.ppl == 1) {
         // the set fits the register file: rows (= 64-point buckets) in VGPRs, no write-back pass
         hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
