@@ -1089,367 +1089,28 @@ __global__ __launch_bounds__(1024) void rb_main_kernel(FbArgs a0)
 }
 
 // ---------------------------------------------------------------------------------------------
-// The register-resident form with several samples per round (same scheme as fm_main_kernel: cells = the
-// 64-point rows; every row record also carries its runner-up; rows whose best beats every runner-up bound are
-// candidates, at most RM_WCAP per wave; one barrier per round; every wave ranks the <= 32 candidates itself).
+// Register-resident FPS with several samples per round (sets of 4097 .. 25 600 points: the per-level resampling)
 // ---------------------------------------------------------------------------------------------
-constexpr int RM_EW = 8;            // words per candidate entry (5 used)
-
-struct RmShared {
-    FmHeader h[2][16];
-    uint32_t cand[2][FM_CAP * RM_EW];
-    float pick[2][FM_CAP][4];           // the round's samples in order (x, y, z, tie key), written by wave 0
-    int npick[2];
-};
-
-// 16 waves x 25 rows (the largest sets): 25 rows of x, y, z leave no registers for 25 rows of running distances,
-// so RM_PT_REG rows of them stay in registers and the rest live in LDS, which the tie keys vacate by shrinking to
-// the 16-bit original index (n <= 25 600; key = tpu3_fps_tiekey(index)).
-constexpr int RM_PT_REG = 2;
-constexpr bool rm_k16(int r, int nw) { return r == 25 && nw == 16; }
-constexpr size_t rm_lds_bytes(int r, int nw)
-{
-    const size_t rows = (size_t)r * nw;
-    return (rm_k16(r, nw) ? rows * 64 * 2 + (size_t)nw * (r - RM_PT_REG) * 64 * 4 : rows * 64 * 4) + rows * 6 * 4 +
-           sizeof(RmShared) + 64;
-}
-
-// NW waves x R rows each: 16 waves of up to 25 rows (128 registers per lane).  The largest sets (<= 25 600 points,
-// 25 rows) keep only x, y, z in registers (rm_k16 above); an 8-wave x 50-row form with everything in 256
-// registers was 8 % slower (half the waves to share a round's re-scans, 7.6 vs 6.4 us per round under load).
-template <int R, int NW, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void rm_main_kernel(FbArgs a0)
-{
-    auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2, tail
-    constexpr int ROWS = NW * R;
-    constexpr int RM_WCAP = FM_CAP / NW;    // candidates a wave may enter per round
-    static_assert(NW == 16 || NW == 8, "waves per workgroup");
-    static_assert(R <= 64, "a lane per row");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: tie keys [wave][slot][lane] and row records [wave][slot]{max, key, x, y, z, runner-up}: everything a
-    // wave touches in the round loop is its own base address plus a compile-time offset
-    constexpr bool K16 = rm_k16(R, NW);
-    constexpr int RREG = K16 ? RM_PT_REG : R;       // rows whose running distances stay in registers
-    uint32_t *skl = (uint32_t *)smem;
-    uint16_t *skl16 = (uint16_t *)smem;
-    float *ptl = (float *)(smem + (size_t)ROWS * 64 * 2);
-    uint32_t *tbl = K16 ? (uint32_t *)(ptl + NW * (R - RREG) * 64) : skl + ROWS * 64;
-    RmShared &sh = *(RmShared *)(tbl + ROWS * 6);
-    const FbArgs a = fb_elem(a0, blockIdx.x);
-    if (a.n <= 0 || a.m <= 0)
-        return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lb = a.lb;
-    uint32_t *kw = skl + wave * R * 64 + lane;      // this lane's keys: kw[64 * j]
-    uint16_t *kw16 = skl16 + wave * R * 64 + lane;  // (K16) this lane's original indices
-    float *pw = ptl + wave * (R - RREG) * 64 + lane;    // (K16) this lane's distances of rows >= RREG
-    uint32_t *tw = tbl + wave * R * 6;              // this wave's records: tw[6 * j + field]
-    auto key_of = [&](int j) __attribute__((always_inline)) -> uint32_t {
-        if (!K16)
-            return kw[64 * j];
-        const uint32_t i16 = kw16[64 * j];
-        return i16 == 0xFFFFu ? 0xFFFFFFFFu : tpu3_fps_tiekey((int)i16, lb);
-    };
-
-    // row r = 16 * slot + wave (neighbouring rows go to different waves); lane l holds point 64 r + l
-    float px[R], py[R], pz[R], pt[RREG];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int slot = (j * NW + wave) * 64 + lane;
-        float4 v = make_float4(0.f, 0.f, 0.f, -1.0f);
-        uint32_t key = 0xFFFFFFFFu;
-        if (slot < a0.npad) {
-            v = a.sp[slot];
-            key = a.skey[slot];
-        }
-        px[j] = v.x; py[j] = v.y; pz[j] = v.z;
-        if (j < RREG)
-            pt[j] = v.w;
-        else
-            pw[64 * (j - RREG)] = v.w;
-        if (K16)
-            kw16[64 * j] = key == 0xFFFFFFFFu ? (uint16_t)0xFFFFu : (uint16_t)tpu3_fps_tiekey_to_index(key, lb);
-        else
-            kw[64 * j] = key;
-    }
-    // Row records and boxes come from the bucket-init kernel (a row is a 64-point bucket); lane j < R
-    // keeps row j's AABB (fp16, rounded outward, packed), current maximum and runner-up in registers
-    for (int i = tid; i < ROWS; i += NW * 64) {
-        const int w = i / R, j = i - w * R, row = j * NW + w;
-        const bool in = row < a0.nbpad;
-        tbl[i * 6 + 0] = in ? a.ib[0 * a0.nbpad + row] : 0x80000000u;
-        tbl[i * 6 + 1] = in ? a.ib[1 * a0.nbpad + row] : 0xFFFFFFFFu;
-        tbl[i * 6 + 2] = in ? a.ib[2 * a0.nbpad + row] : 0u;
-        tbl[i * 6 + 3] = in ? a.ib[3 * a0.nbpad + row] : 0u;
-        tbl[i * 6 + 4] = in ? a.ib[4 * a0.nbpad + row] : 0u;
-        tbl[i * 6 + 5] = in ? a.ib[8 * a0.nbpad + row] : 0x80000000u;
-    }
-    uint32_t bw0, bw1, bw2;
-    int rowmax = (int)0x80000000, rowrun = (int)0x80000000;
-    {
-        const int row = min(lane, R - 1) * NW + wave;
-        const bool in = lane < R && row < a0.nbpad;
-        const uint32_t pinf = 0x7C00u | (0x7C00u << 16);
-        bw0 = in ? a.ib[5 * a0.nbpad + row] : pinf;
-        bw1 = in ? a.ib[6 * a0.nbpad + row] : pinf;
-        bw2 = in ? a.ib[7 * a0.nbpad + row] : pinf;
-        rowmax = in ? (int)a.ib[0 * a0.nbpad + row] : (int)0x80000000;
-        rowrun = in ? (int)a.ib[8 * a0.nbpad + row] : (int)0x80000000;
-    }
-    __syncthreads();
-
-    if (tid == 0)
-        a.idx[0] = 0;
-    // current samples: lane i < J holds sample i; start with point 0
-    float sx = a.xyz[0], sy = a.xyz[1], sz = a.xyz[2];
-    int J = 1, r = 1, rstar = 0x7FFFFFFF;
-    auto rl = [](float v, int i) __attribute__((always_inline)) {
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
-    };
-
-    // re-scan of slot j (compile-time j) with the samples of `pm` folded in: row arg-max with the FPS tie rule
-    // and the row's runner-up, published to the row's record; returns both (wave-uniform)
-    auto rescan = [&](auto jc, uint32_t pm, int &wrun) __attribute__((always_inline)) -> int {
-        constexpr int j = decltype(jc)::value;
-        float t;
-        if constexpr (j < RREG)
-            t = pt[j];
-        else
-            t = pw[64 * (j - RREG)];
-        while (pm) {
-            const int i = __builtin_ctz(pm);
-            pm &= pm - 1;
-            t = fminf(tpu3_sqdist3(px[j] - rl(sx, i), py[j] - rl(sy, i), pz[j] - rl(sz, i)), t);
-        }
-        if constexpr (j < RREG)
-            pt[j] = t;
-        else
-            pw[64 * (j - RREG)] = t;
-        const int bits = __float_as_int(t);
-        const int wmax = tpu3_wave_max_i32_fast(bits);
-        unsigned long long tie = __ballot(bits == wmax);
-        if (__builtin_popcountll(tie) != 1) {                    // duplicated points: smallest tie key
-            const uint32_t k = key_of(j);
-            const uint32_t kmin = tpu3_wave_min_u32(bits == wmax ? k : 0xFFFFFFFFu);
-            tie = __ballot(bits == wmax && k == kmin);
-        }
-        const bool win = lane == (int)__builtin_ctzll(tie);
-        wrun = tpu3_wave_max_i32_fast(win ? (int)0x80000000 : bits);
-        if (win) {
-            tw[6 * j + 0] = (uint32_t)wmax; tw[6 * j + 1] = key_of(j);
-            tw[6 * j + 2] = __float_as_uint(px[j]); tw[6 * j + 3] = __float_as_uint(py[j]);
-            tw[6 * j + 4] = __float_as_uint(pz[j]); tw[6 * j + 5] = (uint32_t)wrun;
-        }
-        return wmax;
-    };
-
-    // fold the first nj current samples into every row they reach
-    auto apply = [&](int nj) __attribute__((always_inline)) {
-        uint32_t pm = 0;
-        {   // (the row's box stays packed in three registers between rounds: 25 rows of points leave no room)
-            const float blx = fb_half_lo(bw0), bly = fb_half_hi(bw0), blz = fb_half_lo(bw1);
-            const float bhx = fb_half_hi(bw1), bhy = fb_half_lo(bw2), bhz = fb_half_hi(bw2);
-            for (int i = 0; i < nj; ++i)
-                pm |= (lane < R && fb_dbox(rl(sx, i), rl(sy, i), rl(sz, i), blx, bly, blz, bhx, bhy, bhz) <
-                                       __int_as_float(rowmax)) ? (1u << i) : 0u;
-        }
-        const unsigned long long mask = __ballot(pm != 0);
-        if (mask)
-            rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
-                if ((mask >> decltype(jc)::value) & 1ull) {
-                    int wr;
-                    const int wm = rescan(jc, (uint32_t)__builtin_amdgcn_readlane((int)pm, decltype(jc)::value), wr);
-                    rowmax = lane == decltype(jc)::value ? wm : rowmax;
-                    rowrun = lane == decltype(jc)::value ? wr : rowrun;
-                }
-            });
-    };
-
-    if (a.m > 1)
-        for (int round = 0;; ++round) {
-            if (PROF) t0 = now();
-            apply(J);
-            if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
-            // ---- select the next samples -------------------------------------------------------------
-            const int par = round & 1;
-            uint32_t *cl = sh.cand[par];
-            const int lj = min(lane, R - 1);
-            const uint32_t rk = tw[6 * lj + 1];
-            const float rx = __uint_as_float(tw[6 * lj + 2]), ry = __uint_as_float(tw[6 * lj + 3]);
-            const float rz = __uint_as_float(tw[6 * lj + 4]);
-            const int mine = lane < R ? rowmax : (int)0x80000000;
-            {
-                int wlane;
-                const int wv = tpu3_wave_argmax(mine, rk, wlane);
-                const int wr = tpu3_wave_max_i32_fast(lane < R ? rowrun : (int)0x80000000);
-                bool is_cand = mine > rstar;
-                unsigned long long cm = __ballot(is_cand);
-                int drop = (int)0x80000000;
-                if (__builtin_popcountll(cm) > RM_WCAP) {
-                    int lrank = 0;
-                    for (unsigned long long mm = cm; mm;) {
-                        const int i = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const int mi = __builtin_amdgcn_readlane(mine, i);
-                        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)rk, i);
-                        lrank += (mi > mine || (mi == mine && ki < rk)) ? 1 : 0;
-                    }
-                    const bool keep = is_cand && lrank < RM_WCAP;
-                    drop = tpu3_wave_max_i32_fast(is_cand && !keep ? mine : (int)0x80000000);
-                    is_cand = keep;
-                    cm = __ballot(is_cand);
-                }
-                if (is_cand) {
-                    uint32_t *e = cl + (wave * RM_WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RM_EW;
-                    e[0] = (uint32_t)mine; e[1] = rk;
-                    e[2] = __float_as_uint(rx); e[3] = __float_as_uint(ry); e[4] = __float_as_uint(rz);
-                }
-                if (lane == wlane) {
-                    FmHeader &h = sh.h[par][wave];
-                    h.best = wv; h.key = rk; h.x = rx; h.y = ry; h.z = rz;
-                    h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
-                }
-            }
-            if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
-            __syncthreads();
-            if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
-            // With 16 (8) waves on 4 SIMDs a ranking repeated by every wave would be issue-bound: wave 0 ranks,
-            // the others wait at a second barrier and read the round's samples from LDS.
-            const int left = a.m - r;
-            if (wave == 0) {
-                const FmHeader &hh = sh.h[par][lane & (NW - 1)];
-                const int sd = lane < NW ? hh.best : (int)0x80000000;
-                const uint32_t sk = lane < NW ? hh.key : 0xFFFFFFFFu;
-                const int sr = lane < NW ? hh.rmax : (int)0x80000000;
-                const int sdrop = lane < NW ? hh.drop : (int)0x80000000;
-                const float hx = hh.x, hy = hh.y, hz = hh.z;
-                const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-                const int nrstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
-                const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
-                // candidate `lane` of the list: wave lane / RM_WCAP, entry lane % RM_WCAP
-                const bool live = lane < FM_CAP && (lane % RM_WCAP) < sh.h[par][(lane / RM_WCAP) & (NW - 1)].count;
-                const unsigned long long lm = __ballot(live);
-                const int total = __builtin_popcountll(lm);
-                float qx, qy, qz;
-                uint32_t okey;
-                int nj;
-                if (total < 2) {
-                    // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
-                    unsigned long long who = __ballot(lane < NW && sd == gbest);
-                    if (__builtin_popcountll(who) != 1) {
-                        const uint32_t wk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
-                        const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)wk, 0);
-                        who = __ballot(lane < NW && sd == gbest && sk == win);
-                    }
-                    const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
-                    qx = rl(hx, ww); qy = rl(hy, ww); qz = rl(hz, ww);
-                    okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
-                    nj = 1;
-                } else {
-                    const uint32_t *e = cl + (lane & (FM_CAP - 1)) * RM_EW;
-                    const int cM = live ? (int)e[0] : (int)0x80000000;
-                    const uint32_t cK = live ? e[1] : 0xFFFFFFFFu;
-                    const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
-                    int rank = 0;
-                    bool tie = false;
-                    for (unsigned long long mm = lm; mm;) {
-                        const int i = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const int mi = __builtin_amdgcn_readlane(cM, i);
-                        rank += mi > cM ? 1 : 0;
-                        tie |= (mi == cM && i != lane);
-                    }
-                    if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
-                        rank = 0;
-                        for (unsigned long long mm = lm; mm;) {
-                            const int i = __builtin_ctzll(mm);
-                            mm &= mm - 1;
-                            const int mi = __builtin_amdgcn_readlane(cM, i);
-                            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
-                            rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
-                        }
-                    }
-                    const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
-                    const int dst = (live ? rank : deadpos) * 4;
-                    qx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cx)));
-                    qy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cy)));
-                    qz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cz)));
-                    okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
-                    const int sM = __builtin_amdgcn_ds_permute(dst, cM);
-                    int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
-                    jmax = jmax < 1 ? 1 : jmax;
-                    jmax = jmax < left ? jmax : left;
-                    for (int i = 0; i + 1 < jmax; ++i) {
-                        const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
-                        const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
-                        if (hit) {
-                            const int f = __builtin_ctzll(hit);
-                            jmax = f < jmax ? f : jmax;
-                        }
-                    }
-                    nj = jmax;
-                }
-                nj = nj < left ? nj : left;
-                if (lane < FM_CAP) {
-                    sh.pick[par][lane][0] = qx; sh.pick[par][lane][1] = qy; sh.pick[par][lane][2] = qz;
-                }
-                if (lane < nj)
-                    a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
-                if (lane == 0) {
-                    sh.npick[par] = nj;
-                    sh.h[par][0].rmax = nrstar;             // (every wave picks the new bound up from here)
-                }
-            }
-            if (PROF) { t1 = now(); pc[3] += t1 - t0; t0 = t1; }
-            __syncthreads();
-            if (PROF) { t1 = now(); pc[4] += t1 - t0; t0 = t1; }
-            J = sh.npick[par];
-            rstar = sh.h[par][0].rmax;
-            sx = sh.pick[par][lane & (FM_CAP - 1)][0];
-            sy = sh.pick[par][lane & (FM_CAP - 1)][1];
-            sz = sh.pick[par][lane & (FM_CAP - 1)][2];
-            r += J;
-            if (r >= a.m) {
-                if (a0.prof && blockIdx.x == 0 && tid == 0) {       // development probe: rounds, samples
-                    a0.prof[0] = (unsigned long long)(round + 1);
-                    a0.prof[1] = (unsigned long long)r;
-                }
-                if (PROF && a0.prof && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1))
-                    for (int i = 0; i < 6; ++i)
-                        a0.prof[2 + wave * 6 + i] = pc[i];
-                if (J > 1)
-                    apply(J - 1);                       // every sample but the last one updates `temp`
-                break;
-            }
-        }
-    // final running distances, back in the caller's order
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const uint32_t key = key_of(j);
-        const float t = j < RREG ? pt[j < RREG ? j : 0] : pw[64 * (j < RREG ? 0 : j - RREG)];
-        if (key != 0xFFFFFFFFu)
-            a.temp[tpu3_fps_tiekey_to_index(key, lb)] = t;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same exact several-samples-per-round scheme with a LANE per bucket
-// ---------------------------------------------------------------------------------------------
-// rm_main_kernel keeps a 64-point row across the lanes of a wave: every row a sample reaches costs two
-// dependent wave-wide reductions (maximum, runner-up) plus a record write, ~700 cycles of latency each, and a
-// round re-scans 4 .. 5 rows per wave one after the other.  Here a LANE owns a bucket of R Morton-consecutive
-// points (1024 buckets per set): bucket maximum, runner-up and the winner's coordinates are per-lane register
-// state, a sample's box test covers 64 buckets per instruction, a reached wave updates its R x 64 distances with
-// plain per-lane arithmetic and re-derives the lanes' records once per round; only the wave's arg-max and
-// runner-up bound need cross-lane reductions -- two per ROUND instead of two per ROW.  Finer buckets (R = 25
-// instead of 64 points) also lower the runner-up bound R*, i.e. more candidates qualify per round.
-constexpr int RL_CAP = 32;          // candidates per round
+// The scheme of fm_main_kernel (exact: a candidate is a bucket whose maximum beats every bucket's runner-up
+// bound R*; the candidates in descending order ARE the next samples as long as none lies inside an earlier one's
+// update ball) with the whole set in the register file and a LANE per bucket: lane b of the 1024 owns the R
+// Morton-consecutive points [b R, b R + R) -- x, y and the running distance in registers, beyond 13 points per
+// lane z in LDS (read only: loads without a dependent store), like the 16-bit original indices (tie keys).  Bucket
+// maximum, runner-up and the winner's coordinates are per-lane register state, a sample's box test covers 64
+// buckets per instruction, a reached wave updates its R x 64 distances with plain per-lane arithmetic and
+// re-derives the lanes' records once per round; only the wave's arg-max and runner-up bound need cross-lane
+// reductions -- two per ROUND.  (Round 2's first form kept a 64-point row across the lanes of a wave: every row a
+// sample reached cost two dependent wave-wide reductions and a record write, ~700 cycles of latency each, 4 - 5
+// rows per wave and round one after the other; 25-point buckets also lower R*: 8.2 samples per round at 24 960
+// points against 6.1.)  Up to RL_WCAP candidates per wave enter a round; one barrier, then wave 0 ranks them (a
+// ranking repeated by all 16 waves would be issue-bound) while the others wait at a second barrier.
+constexpr int RL_EW = 8;            // words per candidate entry (5 used)
+constexpr int RL_CAP = 64;          // candidates per round
 template <int R> constexpr bool rl_zl() { return R > 13; }       // z coordinates in LDS (registers: x, y, distance)
 
 struct RlShared {
     FmHeader h[2][16];
-    uint32_t cand[2][RL_CAP * RM_EW];
+    uint32_t cand[2][RL_CAP * RL_EW];
     float pick[2][RL_CAP][4];
     int npick[2];
 };
@@ -1622,7 +1283,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     cm = __ballot(is_cand);
                 }
                 if (is_cand) {
-                    uint32_t *e = cl + (wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RM_EW;
+                    uint32_t *e = cl + (wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RL_EW;
                     e[0] = (uint32_t)mine; e[1] = rk;
                     e[2] = __float_as_uint(lbx); e[3] = __float_as_uint(lby); e[4] = __float_as_uint(lbz);
                 }
@@ -1635,7 +1296,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
             if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
             __syncthreads();
             if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
-            // wave 0 ranks the candidates (as in rm_main_kernel); the others wait at a second barrier
+            // wave 0 ranks the candidates; the others wait at a second barrier and read the round's samples from LDS
             const int left = a.m - r;
             if (wave == 0) {
                 const FmHeader &hh = sh.h[par][lane & 15];
@@ -1667,7 +1328,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
                     nj = 1;
                 } else {
-                    const uint32_t *e = cl + (lane & (RL_CAP - 1)) * RM_EW;
+                    const uint32_t *e = cl + (lane & (RL_CAP - 1)) * RL_EW;
                     const int cM = live ? (int)e[0] : (int)0x80000000;
                     const uint32_t cK = live ? e[1] : 0xFFFFFFFFu;
                     const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
@@ -1791,8 +1452,7 @@ using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 bool fb_plan(int b, int n, FbPlan &p)
 {
     p.rb_rows = 0;                  // rows per wave (16 waves)
-    static const int rb_max_n = getenv("TPU3_RB_MAX_N") ? atoi(getenv("TPU3_RB_MAX_N")) : RB_MAX_N;   // (tuning hook)
-    if (n <= rb_max_n) {
+    if (n <= RB_MAX_N) {
         const int rows = ((n + 63) / 64 + 15) / 16;
         for (int r : {4, 7, 10, 13, 16, 20, 25})
             if (r >= rows) {
@@ -1936,10 +1596,9 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
     }
     hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
-    // TPU3_RL (tuning hook): 0 = never, 1 (default) = sets of up to 13 312 points, 2 = also the largest sets (where
-    // 25 points per lane make a reached wave's update as slow as rm_main_kernel's row re-scans: 5.65 vs 5.36 ms)
+    // TPU3_RL=0 (tuning hook): without the lane-per-bucket kernel sets beyond 7 rows per wave take fm_main_kernel
     static const int use_rl = getenv("TPU3_RL") ? atoi(getenv("TPU3_RL")) : 1;
-    if (p.rb_rows && !prof && p.ppl == 1 && use_rl && n > 1024 * 4 && m >= 256 && (use_rl > 1 || n <= 1024 * 13)) {
+    if (p.rb_rows && !prof && p.ppl == 1 && use_rl && n > 1024 * 4 && m >= 256) {
         // a lane per bucket of R Morton-consecutive points (rl_main_kernel)
         a0.prof = g_level_stats;
         g_level_stats = nullptr;
@@ -1955,56 +1614,26 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         const int rr = (n + 1023) / 1024;
         if (rr <= 7) RL_LAUNCH(7, false)
         else if (rr <= 13) RL_LAUNCH(13, false)
+        else if (rr <= 19) RL_LAUNCH(19, false)
         else if (a0.prof) RL_LAUNCH(25, true)
         else RL_LAUNCH(25, false)
 #undef RL_LAUNCH
         return tpu3_launch_status();
     }
-    if (p.rb_rows && !prof && p.ppl == 1) {
-        // the set fits the register file: rows (= 64-point buckets) in VGPRs, no write-back pass
+    if (p.rb_rows && p.rb_rows <= 7 && !prof && p.ppl == 1) {
+        // small sets, one sample per round: rows (= 64-point buckets) in VGPRs, no write-back pass
         hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
-        const int rm_nw = 16;
-        a0.prof = g_level_stats;
-        g_level_stats = nullptr;
-        const size_t lds = rm_lds_bytes(p.rb_rows, rm_nw);
+        const size_t lds1 = rb_lds_bytes(p.rb_rows);
         hipError_t e = hipSuccess;
-#define RB_LAUNCH(RR, WW)                                                                                \
-    e = hipFuncSetAttribute((const void *)rm_main_kernel<RR, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                   \
-    if (e != hipSuccess) return (int)e;                                                                  \
-    hipLaunchKernelGGL((rm_main_kernel<RR, WW>), dim3(b), dim3(WW * 64), lds, s, a0)
-        // (sparse resampling of small sets yields ~1 candidate per round: below 8 rows per wave the plain
-        // one-sample-per-round kernel is faster -- 1.75 vs 2.28 ms for 384 sets of 6240 -> 1248)
-        if (p.rb_rows <= 7) {
-            const size_t lds1 = rb_lds_bytes(p.rb_rows);
-            if (p.rb_rows == 4) {
-                e = hipFuncSetAttribute((const void *)rb_main_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                if (e != hipSuccess) return (int)e;
-                hipLaunchKernelGGL(rb_main_kernel<4>, dim3(b), dim3(1024), lds1, s, a0);
-            } else {
-                e = hipFuncSetAttribute((const void *)rb_main_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                if (e != hipSuccess) return (int)e;
-                hipLaunchKernelGGL(rb_main_kernel<7>, dim3(b), dim3(1024), lds1, s, a0);
-            }
-            return tpu3_launch_status();
+        if (p.rb_rows == 4) {
+            e = hipFuncSetAttribute((const void *)rb_main_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(rb_main_kernel<4>, dim3(b), dim3(1024), lds1, s, a0);
+        } else {
+            e = hipFuncSetAttribute((const void *)rb_main_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(rb_main_kernel<7>, dim3(b), dim3(1024), lds1, s, a0);
         }
-        switch (p.rb_rows) {
-        case 10: RB_LAUNCH(10, 16); break;
-        case 13: RB_LAUNCH(13, 16); break;
-        case 16: RB_LAUNCH(16, 16); break;
-        case 20: RB_LAUNCH(20, 16); break;
-        default:
-            if (a0.prof) {      // development probe: per-phase cycle counters of waves 0 and 1
-                e = hipFuncSetAttribute((const void *)rm_main_kernel<25, 16, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
-                hipLaunchKernelGGL((rm_main_kernel<25, 16, true>), dim3(b), dim3(16 * 64), lds, s, a0);
-            } else {
-                RB_LAUNCH(25, 16);
-            }
-            break;
-        }
-#undef RB_LAUNCH
         return tpu3_launch_status();
     }
     hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);

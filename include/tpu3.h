@@ -317,8 +317,8 @@ int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr,
  * tpu3_debug_fps_bucket_profile: one cloud through the same kernel with per-phase cycle counters;
  * prof (device) = waves x 8 u64.
  * tpu3_debug_fps_level_stats: the NEXT FPS call that takes the register-resident multi-sample kernel (per-level
- * resampling, 6400 < n <= 25 600) writes (rounds, samples) of its first set to stats[0..1] and, for the largest sets, per-phase
- * cycle counters of waves 0 and 1 to stats[2..13] (14 device words).  One-shot. */
+ * resampling, 4096 < n <= 25 600) writes (rounds, samples) of its first set to stats[0..1] and, for the largest
+ * sets, per-phase cycle counters of waves 0 and 1 to stats[2..13] (14 device words).  One-shot. */
 int tpu3_debug_fps_bucket_events(void *start, void *stop);
 int tpu3_debug_fps_level_stats(unsigned long long *stats);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,

@@ -65,9 +65,10 @@ def test_fps_bucketed_kernel_bit_exact(orc, dev, b, n, m, dups):
 
 @pytest.mark.parametrize("n,m", [(4100, 300), (9000, 900), (16000, 1600), (20480, 700), (25600, 2600)])
 def test_fps_register_resident_bucketed_kernel(orc, dev, n, m):
-    """4096 <= n <= 25 600 with >= 256 samples: Morton rows held in registers, exact AABB pruning
-    per 64-point row (rb_main_kernel, every rows-per-wave instantiation).  A ragged batch with
-    duplicated points (ties), an element that continues from given distances, bit-exact indices."""
+    """4096 < n <= 25 600 with >= 256 samples: the whole set in the register file, a lane per bucket of
+    7 / 13 / 19 / 25 Morton-consecutive points, several samples per round (rl_main_kernel, every
+    instantiation).  A ragged batch with duplicated points (ties inside and across buckets), an element
+    that continues from given distances, bit-exact indices."""
     ops, L = pkg("network.operations"), pkg("_lib")
     rng = np.random.default_rng(n)
     b = 5
