@@ -1179,16 +1179,20 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     auto lane_scan = [&]() __attribute__((always_inline)) {
         int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
         float bx = 0.f, by = 0.f, bz = 0.f;
+        // maximum and runner-up: two instructions per point (run = the median of (best, t, run) as long as
+        // run <= best); then the winner's slot and coordinates by equality
+        rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
+            const int tb = __float_as_int(pt[decltype(jc)::value]);
+            asm("v_med3_i32 %0, %1, %2, %0" : "+v"(run) : "v"(best), "v"(tb));
+            best = max(best, tb);
+        });
         rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            const int tb = __float_as_int(pt[j]);
-            const bool gt = tb > best;
-            run = gt ? best : max(run, tb);
-            best = gt ? tb : best;
-            arg = gt ? j : arg;
-            bx = gt ? px[j] : bx; by = gt ? py[j] : by;
+            const bool eq = __float_as_int(pt[j]) == best;
+            arg = eq ? j : arg;
+            bx = eq ? px[j] : bx; by = eq ? py[j] : by;
             if constexpr (!ZL)
-                bz = gt ? pz[j] : bz;
+                bz = eq ? pz[j] : bz;
         });
         // equal maxima inside the bucket (duplicated points): the smallest tie key wins
         if (__ballot(run == best && best >= 0)) {
@@ -1211,6 +1215,16 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     };
     lane_scan();
     __syncthreads();
+    // the wave's box (uniform) and an upper bound of its lanes' maxima: a sample is first tested against these --
+    // all samples of the round in ONE evaluation, a lane per sample -- and only the few that may reach the wave
+    // go through the per-bucket test
+    auto uni = [](float v) __attribute__((always_inline)) {       // (wave-uniform: keep it in a scalar register)
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    };
+    const float wlx = uni(-tpu3_wave_max_f32(-blx)), wly = uni(-tpu3_wave_max_f32(-bly));
+    const float wlz = uni(-tpu3_wave_max_f32(-blz)), whx = uni(tpu3_wave_max_f32(bhx));
+    const float why = uni(tpu3_wave_max_f32(bhy)), whz = uni(tpu3_wave_max_f32(bhz));
+    int wbound = 0x7F800000;                        // +inf until the first selection has reduced the maxima
 
     if (tid == 0)
         a.idx[0] = 0;
@@ -1226,11 +1240,16 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     // lanes unconditionally; a wave no sample reaches does nothing.
     auto apply = [&](int nj) __attribute__((always_inline)) {
         bool touched = false;
-        for (int i = 0; i < nj; ++i) {
+        unsigned long long sm = __ballot(lane < nj && fb_dbox(sx, sy, sz, wlx, wly, wlz, whx, why, whz) <
+                                                          __int_as_float(wbound));
+        while (sm) {
+            const int i = __builtin_ctzll(sm);
+            sm &= sm - 1;
             const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);
             if (!__ballot(fb_dbox(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz) < __int_as_float(lmax)))
                 continue;
             touched = true;
+            if (PROF) pc[5] += 1;
             rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 pt[j] = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
@@ -1254,6 +1273,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
             {
                 const int wv = tpu3_wave_max_i32_fast(mine);
                 const int wr = tpu3_wave_max_i32_fast(lrun);
+                wbound = wv;
                 bool is_cand = mine > rstar;
                 unsigned long long tie = __ballot(mine == wv);
                 // keys are fetched by the lanes that need one: the wave's best (ties: all of them), the candidates
@@ -1399,6 +1419,10 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                 if (PROF && a0.prof && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1))
                     for (int i = 0; i < 6; ++i)
                         a0.prof[2 + wave * 6 + i] = pc[i];
+                if (PROF && a0.prof && blockIdx.x == 0 && lane == 0) {      // every wave: apply cycles, updates
+                    a0.prof[14 + wave * 2] = pc[0];
+                    a0.prof[15 + wave * 2] = pc[5];
+                }
                 if (J > 1) {                            // every sample but the last one updates `temp`
                     for (int i = 0; i + 1 < J; ++i) {
                         const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);

@@ -62,6 +62,43 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(int c, int n, int m,
     }
 }
 
+// ---- channel-last rows: out[b, j, :] = x[b, idx[b, j], :] and its transpose (atomic accumulation) -------------
+// (the differentiable neighbour gather of group_knn, reference network/operations.py:209-211, on (B,N,C) rows:
+// four channels per lane, a row of C <= 4 * 64 floats per wave pass)
+template <typename I>
+__global__ __launch_bounds__(256) void gather_rows_kernel(int n, long m, int c4, const float4 *__restrict__ x,
+                                                          const I *__restrict__ idx, float4 *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const float4 *X = x + (size_t)b * n * c4;
+    const I *J = idx + (size_t)b * m;
+    float4 *O = out + (size_t)b * m * c4;
+    const long total = m * c4;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long j = t / c4;
+        const int q = (int)(t - j * c4);
+        const long src = min(max((long)J[j], 0L), (long)n - 1);
+        O[t] = X[src * c4 + q];
+    }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int n, long m, int c, const float *__restrict__ g,
+                                                               const I *__restrict__ idx, float *__restrict__ dx)
+{
+    const int b = blockIdx.y;
+    const float *G = g + (size_t)b * m * c;
+    const I *J = idx + (size_t)b * m;
+    float *D = dx + (size_t)b * n * c;
+    const long total = m * c;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long j = t / c;
+        const int q = (int)(t - j * c);
+        const long dst = min(max((long)J[j], 0L), (long)n - 1);
+        atomicAdd(D + dst * c + q, G[t]);
+    }
+}
+
 inline dim3 gather_grid(int b, int c, int m)
 {
     int gx = (m + 255) / 256;
@@ -125,5 +162,44 @@ extern "C" int tpu3_gather_bwd(tpu3_stream_t stream, int b, int c, int n, int m,
     default:
         return TPU3_EINVAL;
     }
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_gather_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c, const float *x, const void *idx,
+                                    int idx_elem_size, float *out)
+{
+    if (b < 0 || n < 0 || m < 0 || c <= 0 || (idx_elem_size != 4 && idx_elem_size != 8)) return TPU3_EINVAL;
+    if (b == 0 || m == 0) return TPU3_OK;
+    if (!x || !idx || !out || n == 0) return TPU3_EINVAL;
+    if (c % 4 || (((uintptr_t)x | (uintptr_t)out) & 15) != 0) return TPU3_ELIMIT;
+    if (b > 65535) return TPU3_ELIMIT;
+    long gx = (m * (c / 4) + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    const dim3 g((unsigned)gx, b);
+    if (idx_elem_size == 8)
+        hipLaunchKernelGGL(gather_rows_kernel<long long>, g, dim3(256), 0, (hipStream_t)stream, n, m, c / 4,
+                           (const float4 *)x, (const long long *)idx, (float4 *)out);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<int32_t>, g, dim3(256), 0, (hipStream_t)stream, n, m, c / 4,
+                           (const float4 *)x, (const int32_t *)idx, (float4 *)out);
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_scatter_add_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c, const float *g,
+                                         const void *idx, int idx_elem_size, float *dx)
+{
+    if (b < 0 || n < 0 || m < 0 || c <= 0 || (idx_elem_size != 4 && idx_elem_size != 8)) return TPU3_EINVAL;
+    if (b == 0 || m == 0) return TPU3_OK;
+    if (!g || !idx || !dx || n == 0) return TPU3_EINVAL;
+    if (b > 65535) return TPU3_ELIMIT;
+    long gx = (m * c + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    const dim3 grid((unsigned)gx, b);
+    if (idx_elem_size == 8)
+        hipLaunchKernelGGL(scatter_add_rows_kernel<long long>, grid, dim3(256), 0, (hipStream_t)stream, n, m, c, g,
+                           (const long long *)idx, dx);
+    else
+        hipLaunchKernelGGL(scatter_add_rows_kernel<int32_t>, grid, dim3(256), 0, (hipStream_t)stream, n, m, c, g,
+                           (const int32_t *)idx, dx);
     return tpu3_launch_status();
 }

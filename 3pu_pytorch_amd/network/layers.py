@@ -50,6 +50,34 @@ class _SkinnyLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _GatherRows(torch.autograd.Function):
+    """knn_point = x[b, idx] (group_knn's differentiable gather, reference operations.py:209-211) with the backward
+    as ONE atomic scatter-add launch: torch's index backward sorts the 3e5 indices of every DenseEdgeConv block
+    first (nine rocPRIM merge passes + the accumulation kernel per call)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        out = operations.BACKEND.gather_rows(x, idx)
+        ctx.save_for_backward(idx)
+        ctx.n = x.size(1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return operations.BACKEND.scatter_add_rows(g, idx, ctx.n), None
+
+
+def gather_neighbours(x, idx):
+    """x (B,N,C), idx (B,N,k) -> (B,N,k,C), differentiable in x."""
+    be = operations.BACKEND
+    if (x.is_cuda and hasattr(be, "gather_rows") and x.dtype == torch.float32 and x.size(-1) % 4 == 0
+            and x.is_contiguous() and idx.is_contiguous() and (x.data_ptr() & 15) == 0):
+        return _GatherRows.apply(x, idx)
+    b = torch.arange(x.size(0), device=x.device).view(-1, 1, 1)
+    return x[b, idx]
+
+
 def linear_1x1(conv, x):
     """Apply a kernel-size-1 nn.Conv1d / nn.Conv2d to channel-last activations (..., C_in)."""
     w = conv.weight
@@ -101,8 +129,7 @@ class DenseEdgeConv(nn.Module):
         else:
             knn_point = None
         if knn_point is None or need_grad:
-            b = torch.arange(x.size(0), device=x.device).view(-1, 1, 1)
-            knn_point = x[b, idx]                      # differentiable gather (B,N,k,C)
+            knn_point = gather_neighbours(x, idx.contiguous())       # differentiable gather (B,N,k,C)
         center = x.unsqueeze(2).expand_as(knn_point)
         return torch.cat([center, knn_point - center], dim=-1), idx
 

@@ -322,6 +322,31 @@ class HipBackend(object):
                     "tpu3_linear_small_f32")
         return y
 
+    def gather_rows(self, x, idx):
+        """x (B,N,C) f32 contiguous, idx (B,...) int32 / int64 -> (B,...,C) rows, or None when not covered."""
+        B, N, C = x.shape
+        if (C % 4 or x.dtype != torch.float32 or not x.is_contiguous() or not idx.is_contiguous()
+                or idx.dtype not in (torch.int32, torch.int64) or idx.size(0) != B or (x.data_ptr() & 15)):
+            return None
+        m = idx.numel() // max(1, B)
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_gather_rows_f32(L.stream_of(x), B, N, m, C, L.ptr(x), L.ptr(idx), idx.element_size(),
+                                                 L.ptr(out)), "tpu3_gather_rows_f32")
+        return out
+
+    def scatter_add_rows(self, g, idx, n):
+        """Transpose of gather_rows: g (B,...,C) f32, idx (B,...) -> dx (B,n,C) with dx[b, idx[b,j]] += g[b,j]."""
+        B, C = g.size(0), g.size(-1)
+        g = g.contiguous()
+        idx = idx.contiguous()
+        m = idx.numel() // max(1, B)
+        dx = torch.zeros((B, n, C), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            L.check(L.lib().tpu3_scatter_add_rows_f32(L.stream_of(g), B, n, m, C, L.ptr(g), L.ptr(idx),
+                                                      idx.element_size(), L.ptr(dx)), "tpu3_scatter_add_rows_f32")
+        return dx
+
     def linear_wide(self, x, weight, bias):
         """Per-point linear layer with 128 outputs (the per-point half of up_layer1): x (..., C_in) contiguous,
         weight (128, C_in) with unit column stride (a column slice of a wider matrix is fine) -> (..., 128),

@@ -110,6 +110,9 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
     kt.wrap("linear_small", lambda x, w, b, relu, **kw: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
     kt.wrap("interlevel_skip", lambda xyz, feat, pxyz, pfeat, pts_of, idx, **kw: (feat.shape[0], feat.shape[1],
                                                                                   idx.shape[2], feat.shape[2]))
+    kt.wrap("linear_wide", lambda x, w, b: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
+    kt.wrap("linear_lift", lambda x, w, b, relu, **kw: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0],
+                                                        kw.get("also") is not None))
     kt.wrap("fps", lambda xyz, npoint, n_arr=None, m_arr=None: (xyz.shape[0], xyz.shape[1], npoint))
     kt.wrap("knn", lambda k, q, p, unique, *a, **kw: (q.shape[0], q.shape[1], p.shape[1], q.shape[2], k))
     try:
@@ -152,6 +155,24 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
                     "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                     "basis": "executed MFMA FLOPs (last layer padded 3 -> 16 rows)", "ms_per_step": ms,
                     "executed_flop_per_step": ex, "traffic": tr("regress_tail_kernel")})
+    ms, shp = kt.total("linear_wide")
+    if shp:
+        # executed: per 16 rows 17 slabs x 8 output tiles x 4 MFMAs (264 channels padded to 272)
+        ex = sum(-(-m // 16) * 17 * 8 * 4 * 2048.0 for m, cin, cout in shp)
+        ach = ex / (ms * 1e-3) / 1e12
+        out.append({"kernel": "linear_wide_kernel (up_layer1 per point, 264 -> 128, fp32 MFMA), %d launches/step" % len(shp),
+                    "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
+                    "basis": "executed v_mfma_f32_16x16x4 FLOPs (264 of 272 k slots useful)", "ms_per_step": ms,
+                    "executed_flop_per_step": ex, "traffic": tr("linear_wide_kernel")})
+    ms, shp = kt.total("linear_lift")
+    if shp:
+        byt = sum(m * 4.0 * (cin + cout * (2 if also else 1)) for m, cin, cout, also in shp)
+        ach = byt / (ms * 1e-3) / 1e9
+        out.append({"kernel": "linear_lift_kernel (layer0, 3 -> 24, also stored into the feature buffer), %d launches/step"
+                              % len(shp),
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "basis": "4*C_in B read, 4*C_out B written per destination and row", "ms_per_step": ms,
+                    "algorithmic_bytes_per_step": byt, "traffic": tr("linear_lift_kernel")})
     ms, shp = kt.total("linear_small")
     if shp:
         byt = sum(m * 4.0 * (cin + cout) for m, cin, cout in shp)
@@ -171,12 +192,14 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
     ms, shp = kt.total("fps", lambda s: s[2] >= 256)
     if shp:
         rounds = sum(m - 1 for _, _, m in shp)
-        out.append({"kernel": "rm_main_kernel / rb_main_kernel (per-level resampling FPS), %d launches/step" % len(shp),
-                    "bound": "latency", "us_per_round": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
-                    "sets_per_launch": [b for b, _, _ in shp], "basis": "dependent chain: one workgroup per set"})
+        out.append({"kernel": "rl_main_kernel (per-level resampling FPS, several samples per round), %d launches/step"
+                              % len(shp),
+                    "bound": "latency", "us_per_sample": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
+                    "sets_per_launch": [b for b, _, _ in shp],
+                    "basis": "dependent chain: one workgroup (= one compute unit) per set"})
     ms, shp = kt.total("knn")
     if shp:
-        out.append({"kernel": "knn_insert / knn_sort kernels (patch extraction, outlier filter, inter-level k=5), "
+        out.append({"kernel": "knn_insert / knn_select / knn_sort kernels (patch extraction, outlier filter, inter-level k=5), "
                               "%d launches/step" % len(shp), "bound": "valu", "ms_per_step": ms})
     return out
 

@@ -309,6 +309,17 @@ size_t tpu3_linear_wgrad_workspace_bytes(long m);
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
                        float *out, float *centroid, float *radius);
 
+/* The differentiable neighbour gather of group_knn (network/operations.py:209-211: torch.gather over the expanded
+ * point tensor; its backward is an index accumulation) on channel-last rows, training:
+ *   tpu3_gather_rows_f32       out[b, j, :] = x[b, idx[b, j], :]        x (b,n,c), idx (b,m) i32 / i64, out (b,m,c)
+ *   tpu3_scatter_add_rows_f32  dx[b, idx[b, j], :] += g[b, j, :]        (hardware float atomics; dx zeroed by the
+ *                              caller; the summation order of a row's contributions is not fixed)
+ * c % 4 == 0 and 16-byte aligned x / out for the gather (else TPU3_ELIMIT). */
+int tpu3_gather_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c, const float *x, const void *idx,
+                         int idx_elem_size, float *out);
+int tpu3_scatter_add_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c, const float *g, const void *idx,
+                              int idx_elem_size, float *dx);
+
 /* ---- measurement hooks (bench.py and tools/ only; a caller of the path never needs them) ------------
  * tpu3_debug_fps_bucket_events: the NEXT bucketed-FPS call (n beyond the register-resident limit)
  * records `start` / `stop` (hipEvent_t created by the caller) on ITS stream immediately before / after
@@ -318,7 +329,8 @@ int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr,
  * prof (device) = waves x 8 u64.
  * tpu3_debug_fps_level_stats: the NEXT FPS call that takes the register-resident multi-sample kernel (per-level
  * resampling, 4096 < n <= 25 600) writes (rounds, samples) of its first set to stats[0..1] and, for the largest
- * sets, per-phase cycle counters of waves 0 and 1 to stats[2..13] (14 device words).  One-shot. */
+ * sets, per-phase cycle counters of waves 0 and 1 to stats[2..13] and every wave's (update cycles, sample
+ * updates) to stats[14..45] (46 device words).  One-shot. */
 int tpu3_debug_fps_bucket_events(void *start, void *stop);
 int tpu3_debug_fps_level_stats(unsigned long long *stats);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,

@@ -648,6 +648,29 @@ def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
     assert (got.double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_gather_neighbours_forward_and_backward(dev, idx_dtype):
+    """The differentiable neighbour gather of the training path (tpu3_gather_rows_f32 / tpu3_scatter_add_rows_f32)
+    against torch's advanced indexing and its autograd: rows bit-equal, gradients to 1e-5 (atomic summation
+    order), repeated indices included."""
+    layers = pkg("network.layers")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N, k, C = 3, 200, 32, 24
+    x = torch.randn(B, N, C, generator=g).to(dev).requires_grad_(True)
+    idx = torch.randint(0, N, (B, N, k), generator=g).to(dev).to(idx_dtype)
+    idx[0, :, :4] = 7                                             # many contributions to one row
+    w = torch.randn(B, N, k, C, generator=g).to(dev)
+    y = layers.gather_neighbours(x, idx)
+    (y * w).sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    bsel = torch.arange(B, device=dev).view(-1, 1, 1)
+    y2 = x[bsel, idx.long()]
+    (y2 * w).sum().backward()
+    assert torch.equal(y, y2)
+    assert (gx - x.grad).abs().max() < 1e-4 * max(1.0, float(x.grad.abs().max()))
+
+
 @pytest.mark.parametrize("m,cin", [(5000, 264), (17, 264), (1, 260), (4099, 272)])
 def test_linear_wide_matches_torch(dev, m, cin):
     """tpu3_linear_wide_f32 (per-point half of up_layer1, 264 -> 128) against torch in fp64; the weight is a

@@ -28,7 +28,7 @@ with torch.no_grad():
     pipe.upsample(net, clouds, 312, 16, 3, final_fps=False, check_small=False)
 ops.BACKEND.fps = orig
 torch.cuda.synchronize()
-stats = torch.zeros(14, dtype=torch.int64, device=dev)
+stats = torch.zeros(46, dtype=torch.int64, device=dev)
 for n, (x, m, na, ma) in sorted(seen.items()):
     for nb in (x.size(0), 1):
         xs = x[:nb].contiguous()
@@ -47,7 +47,10 @@ for n, (x, m, na, ma) in sorted(seen.items()):
         print("n=%5d m=%4d sets=%3d: %7.3f ms  rounds %d samples %d (%.2f per round, %.2f us per round)"
               % (n, m, nb, min(ts), r, s, s / max(1, r), min(ts) * 1e3 / max(1, r)))
         pc = stats.cpu().numpy()
-        if pc[2:].any():
+        if pc[14:].any():
+            print("    apply cycles per round, waves 0..15: " + " ".join("%.0f" % (pc[14 + 2 * w] / max(1, r)) for w in range(16)))
+            print("    sample updates per round, waves 0..15: " + " ".join("%.2f" % (pc[15 + 2 * w] / max(1, r)) for w in range(16)))
+        if pc[2:14].any():
             for w in range(2):
                 print("    wave %d cycles per round: " % w + "  ".join(
                     "%s %.0f" % (nm, pc[2 + w * 6 + i] / max(1, r)) for i, nm in enumerate(("apply", "select", "barrier1", "rank", "barrier2", "-"))))

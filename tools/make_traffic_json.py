@@ -54,8 +54,8 @@ def find(tab, key):
 
 
 others, mfma = {}, {}
-for key in ("dec_fused_kernel", "knn_graph_key_kernel", "regress_tail_kernel", "linear_small_kernel", "skip_", "rb_main_kernel",
-            "rm_main_kernel", "knn_insert_kernel", "knn_dup_hash", "Cijk_"):
+for key in ("dec_fused_kernel", "knn_graph_key_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
+            "linear_lift_kernel", "skip_", "rl_main_kernel", "knn_insert_kernel", "knn_select_kernel", "knn_dup_lds"):
     f, w = find(F, key), find(Wr, key)
     if f and w:
         others[key] = {"launches_per_step": f["n"] / STEPS, "fetch_size_kib_per_step": f["FETCH_SIZE"] / STEPS,
