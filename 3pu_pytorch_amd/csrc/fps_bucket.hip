@@ -1226,6 +1226,12 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     const float why = uni(tpu3_wave_max_f32(bhy)), whz = uni(tpu3_wave_max_f32(bhz));
     int wbound = 0x7F800000;                        // +inf until the first selection has reduced the maxima
 
+    // pair (i < l) number `lane` of the l-major enumeration 0:(0,1) 1:(0,2) 2:(1,2) 3:(0,3) ... (wave 0's clearance test)
+    int pair_l = (int)((1.f + sqrtf(1.f + 8.f * (float)lane)) * 0.5f);
+    pair_l -= pair_l * (pair_l - 1) / 2 > lane ? 1 : 0;
+    pair_l += (pair_l + 1) * pair_l / 2 <= lane ? 1 : 0;
+    const int pair_i = lane - pair_l * (pair_l - 1) / 2;
+
     if (tid == 0)
         a.idx[0] = 0;
     // current samples: lane i < J holds sample i; start with point 0
@@ -1381,12 +1387,29 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
                     jmax = jmax < 1 ? 1 : jmax;
                     jmax = jmax < left ? jmax : left;
-                    for (int i = 0; i + 1 < jmax; ++i) {
-                        const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
-                        const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
-                        if (hit) {
-                            const int f = __builtin_ctzll(hit);
-                            jmax = f < jmax ? f : jmax;
+                    // longest prefix in which no member lies inside the update ball of an earlier member: the
+                    // smallest l with d(sample i, sample l) < M_l for some i < l.  Up to 11 candidates: all 55
+                    // pairs at once, a lane per pair (l-major, so the first hit has the smallest l).
+                    if (jmax <= 11) {
+                        const float lx = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qx)));
+                        const float ly = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qy)));
+                        const float lz = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qz)));
+                        const float ix = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qx)));
+                        const float iy = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qy)));
+                        const float iz = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qz)));
+                        const int lM = __builtin_amdgcn_ds_bpermute(pair_l * 4, sM);
+                        const float d = tpu3_sqdist3(lx - ix, ly - iy, lz - iz);
+                        const unsigned long long hit = __ballot(pair_l < jmax && d < __int_as_float(lM));
+                        if (hit)
+                            jmax = __builtin_amdgcn_readlane(pair_l, (int)__builtin_ctzll(hit));
+                    } else {
+                        for (int i = 0; i + 1 < jmax; ++i) {
+                            const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
+                            const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
+                            if (hit) {
+                                const int f = __builtin_ctzll(hit);
+                                jmax = f < jmax ? f : jmax;
+                            }
                         }
                     }
                     nj = jmax;
