@@ -16,7 +16,7 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL):
 The default (--gpus N, 32 clouds per GPU) is the throughput configuration of the 1-GPU line.
 
 One JSON line is printed by rank 0.  Besides the contract's keys it carries
-  roofline          dominant kernel (final FPS, fb_main_kernel): measured traffic / launch time against the
+  roofline          dominant kernel (final FPS, fm_main_kernel): measured traffic / launch time against the
                     HBM peak -- never above 1 -- plus us_per_round against a stated floor; the streaming
                     model of SURVEY 8d as `model_ratio` (the kernel skips >99 % of that model's bytes)
   rooflines_other   every other hand-written kernel of a step, timed with events on its launch stream:
@@ -196,7 +196,8 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic):
                               % len(shp),
                     "bound": "latency", "us_per_sample": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
                     "sets_per_launch": [b for b, _, _ in shp],
-                    "basis": "dependent chain: one workgroup (= one compute unit) per set"})
+                    "basis": "dependent chain: one workgroup (= one compute unit) per set, 256 sets at a time; "
+                             "us_per_sample = launch time / samples per SET (all sets of a launch share it)"})
     ms, shp = kt.total("knn")
     if shp:
         out.append({"kernel": "knn_insert / knn_select / knn_sort kernels (patch extraction, outlier filter, inter-level k=5), "
@@ -369,7 +370,7 @@ def main():
         clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
 
     timing = []
-    # HIP events placed by the library immediately around fb_main_kernel on ITS stream (the events
+    # HIP events placed by the library immediately around fm_main_kernel on ITS stream (the events
     # in `timing` bracket the whole final-FPS operator: Morton sort, bucket setup, kernel, write-back)
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
@@ -495,7 +496,7 @@ def main():
         if traffic and traffic.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
             tr = traffic.get("traffic_bytes_per_launch")
         model_bytes = 20.0 * CL * n_merged * (m_out - 1)
-        roof = {"kernel": "fb_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
+        roof = {"kernel": "fm_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tr,
                 "achieved": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
                 "basis": "measured fabric traffic of one launch (PMC, profiles/r02_traffic.json) / launch time (HIP events "
