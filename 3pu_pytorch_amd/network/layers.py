@@ -152,6 +152,52 @@ class DenseEdgeConv(nn.Module):
             return "DenseEdgeConv k=%d: the fused kernel covers k in {16, 32, 48, 64}" % self.k
         return None
 
+    # training: evaluate everything that depends on ONE point per point (see _forward_train_hoisted)
+    hoist_train = True
+
+    def _forward_train_hoisted(self, x, idx=None, layout=None):
+        """The block of reference :44-64 for autograd, with the same hoisting as the fused inference kernel: a
+        layer's input is [h_{i-1}, ..., h_0, x_i] (layer 0: [x_i, x_j - x_i]), so
+            W_0 [x_i, x_j - x_i] = (W_0a - W_0b) x_i + W_0b x_j        W_i [h.., x_i] = W_i^h [h..] + W_i^x x_i
+        and every x_i term (and z_j = W_0b x_j) is ONE (B*N, C) x (C, (n+1) g) product per block instead of
+        C-wide columns of the B*N*k edge tensors: the edge tensors are g .. (n-1) g channels wide instead of
+        2C .. C + (n-1) g, nothing of width C is concatenated per edge, and max over k commutes with the
+        channel concatenation.  Same mathematics, different summation order (fp32 reassociation)."""
+        B, N, C = x.shape
+        g, n, k = self.growth_rate, self.n, self.k
+        if idx is None:
+            _, idx = self.get_local_graph_idx(x, k, layout)
+        w = [m.weight.view(m.weight.size(0), -1) for m in self.mlps]
+        cols = [w[0][:, :C] - w[0][:, C:], w[0][:, C:]] + [w[i][:, i * g:] for i in range(1, n)]
+        bias = [self.mlps[0].bias, torch.zeros_like(self.mlps[0].bias)] + [self.mlps[i].bias for i in range(1, n)]
+        P = F.linear(x, torch.cat(cols, dim=0), torch.cat(bias, dim=0))          # (B,N,(n+1) g)
+        zg = gather_neighbours(P[..., g:2 * g].contiguous(), idx.contiguous())    # (B,N,k,g)
+        hs = [F.relu(P[..., :g].unsqueeze(2) + zg)]                               # layer 0: ReLU (:57)
+        for i in range(1, n):
+            inp = hs[0] if i == 1 else torch.cat(hs, dim=-1)                      # newest first, like the reference
+            wh = w[i][:, :i * g]
+            if (wh.size(0) <= 16 and wh.size(1) <= 64 and inp.is_cuda and inp.numel() // inp.size(-1) >= 16384
+                    and hasattr(operations.BACKEND, "linear_wgrad")):
+                h = _SkinnyLinear.apply(inp.contiguous(), wh.contiguous(), None)
+            else:
+                h = F.linear(inp, wh)
+            h = h + P[..., (i + 1) * g:(i + 2) * g].unsqueeze(2)
+            hs.insert(0, h if i == n - 1 else F.relu(h))                          # last layer: no ReLU (:59)
+        y = torch.cat([torch.max(h, dim=2)[0] for h in hs] + [x], dim=-1)
+        return y, idx
+
+    def get_local_graph_idx(self, x, k, layout=None):
+        """Neighbour indices only (the first of the k+1 dropped, reference :33-35): (None, idx (B,N,k))."""
+        full = None
+        if x.is_cuda and x.dtype == torch.float32 and hasattr(operations.BACKEND, "knn_graph"):
+            with torch.no_grad():
+                full = operations.BACKEND.knn_graph(k + 1, x.detach().contiguous(), layout, optimistic=False)
+        if full is None:
+            with torch.no_grad():
+                full, _, _ = operations.knn_query(k + 1, x.detach(), x.detach(), unique=True, layout=layout,
+                                                  want_dist=False, want_grouped=False)
+        return None, full.long()[:, :, 1:]
+
     def forward_cl(self, x, idx=None, layout=None, out=None):
         """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k).
         `out`: optional (B,N,C + n*growth_rate) view (unit channel stride) that receives y -- the
@@ -177,6 +223,12 @@ class DenseEdgeConv(nn.Module):
                                "call: %s" % (self.mlp_precision, why))
         if not torch.is_grad_enabled():
             operations.note_generic_path(why)
+        if torch.is_grad_enabled() and self.hoist_train:
+            y, idx = self._forward_train_hoisted(x, idx, layout)
+            if out is not None:
+                out.copy_(y)
+                y = out
+            return y, idx
         edge, idx = self.get_local_graph_cl(x, k, idx, layout)
         if torch.is_grad_enabled():
             # training: autograd-friendly concatenations, exactly the reference's dataflow (:53-61)
