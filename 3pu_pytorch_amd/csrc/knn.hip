@@ -1578,6 +1578,35 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
 // Self kNN graph without a de-duplication pre-pass (see knn_graph_kernel, mode 2): x (b,n,c) is both
 // query and point set; dup (b,n) and uws are scratch owned by the call (uws is zeroed here); workspace
 // = tpu3_knn_unique_workspace_bytes(b, n) bytes for the (rarely needed) hash tables.
+namespace {
+// The self graph's first (usually only) pass: one pass with the index in the key's low bits (n up to 2^13: >= 10
+// mantissa bits stay), the two-pass kernel beyond that and for n == k.  Either raises uws[2] when rows may be
+// duplicated.
+int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a)
+{
+    const int c = a.c, k = a.k;
+#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+#define KK1(CC, KK) hipLaunchKernelGGL((knn_graph_key_kernel<CC, KK>), g, dim3(threads), 0, s, a)
+    const bool onepass = a.n > k && a.n <= 8192;
+    if (k == 33) {
+        if (c == 3) { if (onepass) KK1(3, 33); else KG(3, 33); }
+        else if (c <= 8) { if (onepass) KK1(8, 33); else KG(8, 33); }
+        else if (c <= 16) { if (onepass) KK1(16, 33); else KG(16, 33); }
+        else if (c <= 24) { if (onepass) KK1(24, 33); else KG(24, 33); }
+        else { if (onepass) KK1(32, 33); else KG(32, 33); }
+    } else {
+        if (c == 3) { if (onepass) KK1(3, 17); else KG(3, 17); }
+        else if (c <= 8) { if (onepass) KK1(8, 17); else KG(8, 17); }
+        else if (c <= 16) { if (onepass) KK1(16, 17); else KG(16, 17); }
+        else if (c <= 24) { if (onepass) KK1(24, 17); else KG(24, 17); }
+        else { if (onepass) KK1(32, 17); else KG(32, 17); }
+    }
+#undef KG
+#undef KK1
+    return tpu3_launch_status();
+}
+} // namespace
+
 extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
                                        const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,
                                        void *workspace, size_t workspace_bytes)
@@ -1600,16 +1629,7 @@ extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c
     int threads = ((n + 63) / 64) * 64;
     if (threads > 512) threads = 256;
     const dim3 g((n + threads - 1) / threads, b);
-#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
-    if (k == 33) {
-        if (c == 3) KG(3, 33); else if (c <= 8) KG(8, 33); else if (c <= 16) KG(16, 33);
-        else if (c <= 24) KG(24, 33); else KG(32, 33);
-    } else {
-        if (c == 3) KG(3, 17); else if (c <= 8) KG(8, 17); else if (c <= 16) KG(16, 17);
-        else if (c <= 24) KG(24, 17); else KG(32, 17);
-    }
-#undef KG
-    int r = tpu3_launch_status();
+    int r = launch_graph_first_pass(s, g, threads, a);
     if (r) return r;
     // everything below runs only if some query saw a zero distance to another row (uws[2])
     const int tsize = knn_dup_table_size(n);
@@ -1655,27 +1675,7 @@ extern "C" int tpu3_knn_graph_self_optimistic_f32(tpu3_stream_t stream, int b, i
     int threads = ((n + 63) / 64) * 64;
     if (threads > 512) threads = 256;
     const dim3 g((n + threads - 1) / threads, b);
-    // one pass with the index in the key's low bits (n up to 2^13: >= 10 mantissa bits stay); the two-pass kernel
-    // beyond that and for n == k
-#define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
-#define KK1(CC, KK) hipLaunchKernelGGL((knn_graph_key_kernel<CC, KK>), g, dim3(threads), 0, s, a)
-    const bool onepass = n > k && n <= 8192;
-    if (k == 33) {
-        if (c == 3) { if (onepass) KK1(3, 33); else KG(3, 33); }
-        else if (c <= 8) { if (onepass) KK1(8, 33); else KG(8, 33); }
-        else if (c <= 16) { if (onepass) KK1(16, 33); else KG(16, 33); }
-        else if (c <= 24) { if (onepass) KK1(24, 33); else KG(24, 33); }
-        else { if (onepass) KK1(32, 33); else KG(32, 33); }
-    } else {
-        if (c == 3) { if (onepass) KK1(3, 17); else KG(3, 17); }
-        else if (c <= 8) { if (onepass) KK1(8, 17); else KG(8, 17); }
-        else if (c <= 16) { if (onepass) KK1(16, 17); else KG(16, 17); }
-        else if (c <= 24) { if (onepass) KK1(24, 17); else KG(24, 17); }
-        else { if (onepass) KK1(32, 17); else KG(32, 17); }
-    }
-#undef KG
-#undef KK1
-    return tpu3_launch_status();
+    return launch_graph_first_pass(s, g, threads, a);
 }
 
 extern "C" int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, const float *query,

@@ -78,6 +78,41 @@ def gather_neighbours(x, idx):
     return x[b, idx]
 
 
+class _FusedDECTrain(torch.autograd.Function):
+    """The (24, 12, 3, k = 32) DenseEdgeConv block as ONE autograd node (csrc/dec_train.hip): forward and backward
+    are one launch each; the weight gradients of the edge parts go through the streaming kernel
+    tpu3_linear_wgrad_f32 on column slices of the two edge tensors the backward kernel leaves behind, those of the
+    x_i parts and the biases come from the per-point sums S."""
+
+    @staticmethod
+    def forward(ctx, x, idx, idx_off, w0, b0, w1, b1, w2, b2):
+        weights = tuple(t.detach().contiguous().view(t.size(0), -1) if t.dim() > 1 else t.detach().contiguous()
+                        for t in (w0, b0, w1, b1, w2, b2))
+        x = x.contiguous()
+        y, arg = operations.BACKEND.dec_train_forward(x, idx, idx_off, weights)
+        ctx.save_for_backward(x, idx, arg, *weights)
+        ctx.idx_off = idx_off
+        ctx.shapes = (w0.shape, w1.shape, w2.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, idx, arg = ctx.saved_tensors[:3]
+        weights = ctx.saved_tensors[3:]
+        be = operations.BACKEND
+        gx, G, Z, S = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
+        # edge parts: dW = G_slice^T Z_slice (streaming MFMA kernel, deterministic)
+        g2h = be.linear_wgrad(Z[:, 0:24], G[:, 0:12])               # W_2[:, 0:24]  (inputs [h1, h0])
+        g1h = be.linear_wgrad(Z[:, 12:24], G[:, 12:24])             # W_1[:, 0:12]  (input h0)
+        g0b = be.linear_wgrad(Z[:, 24:48], G[:, 24:36])             # W_0[:, 24:48] (input x_j - x_i)
+        gxw = S.t().matmul(x.view(-1, x.size(-1)))                  # (36, 24): rows W_2x, W_1x, W_0a
+        gb = S.sum(dim=0)
+        gw0 = torch.cat([gxw[24:36], g0b], dim=1).view(ctx.shapes[0])
+        gw1 = torch.cat([g1h, gxw[12:24]], dim=1).view(ctx.shapes[1])
+        gw2 = torch.cat([g2h, gxw[0:12]], dim=1).view(ctx.shapes[2])
+        return gx, None, None, gw0, gb[24:36], gw1, gb[12:24], gw2, gb[0:12]
+
+
 def linear_1x1(conv, x):
     """Apply a kernel-size-1 nn.Conv1d / nn.Conv2d to channel-last activations (..., C_in)."""
     w = conv.weight
@@ -154,6 +189,32 @@ class DenseEdgeConv(nn.Module):
 
     # training: evaluate everything that depends on ONE point per point (see _forward_train_hoisted)
     hoist_train = True
+    # training on the device for the reference's shape: one launch per direction (csrc/dec_train.hip)
+    fused_train = True
+
+    def _fused_train_ok(self, x):
+        return (hasattr(operations.BACKEND, "dec_train_forward") and x.is_cuda and x.dtype == torch.float32
+                and (self.in_channels, self.growth_rate, self.n, self.k) == (24, 12, 3, 32)
+                and all(m.bias is not None for m in self.mlps))
+
+    def _forward_train_fused(self, x, idx=None, layout=None):
+        k = self.k
+        if idx is None:
+            full = None
+            if hasattr(operations.BACKEND, "knn_graph"):
+                with torch.no_grad():
+                    full = operations.BACKEND.knn_graph(k + 1, x.detach().contiguous(), layout, optimistic=False)
+            if full is None:
+                with torch.no_grad():
+                    full, _, _ = operations.knn_query(k + 1, x.detach(), x.detach(), unique=True, layout=layout,
+                                                      want_dist=False, want_grouped=False)
+                full = full.to(torch.int32)
+            idx32, off, idx = full.contiguous(), 1, full[:, :, 1:].long()
+        else:
+            idx32, off = idx.to(torch.int32).contiguous(), 0
+        m = self.mlps
+        y = _FusedDECTrain.apply(x, idx32, off, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[2].weight, m[2].bias)
+        return y, idx
 
     def _forward_train_hoisted(self, x, idx=None, layout=None):
         """The block of reference :44-64 for autograd, with the same hoisting as the fused inference kernel: a
@@ -223,6 +284,12 @@ class DenseEdgeConv(nn.Module):
                                "call: %s" % (self.mlp_precision, why))
         if not torch.is_grad_enabled():
             operations.note_generic_path(why)
+        if torch.is_grad_enabled() and self.fused_train and self._fused_train_ok(x):
+            y, idx = self._forward_train_fused(x, idx, layout)
+            if out is not None:
+                out.copy_(y)
+                y = out
+            return y, idx
         if torch.is_grad_enabled() and self.hoist_train:
             y, idx = self._forward_train_hoisted(x, idx, layout)
             if out is not None:

@@ -179,7 +179,7 @@ class HipBackend(object):
 
     def knn_graph(self, k, x, layout=None, optimistic=None):
         """Self kNN graph for the fused DenseEdgeConv: x (B,N,C) f32 -> idx int32 (B,N,k) holding the
-        exact top-k set (unique=True semantics), nearest in slot 0, the rest in index order.
+        exact top-k set (unique=True semantics), nearest in slot 0, the rest in no particular order.
         Returns None when the size is not covered by the two-pass kernel.
         optimistic (default: self.optimistic_graph): only the two-pass kernel runs and possible duplicated
         rows are reported through graph_dup_events() instead of being handled by gated fallback launches."""
@@ -321,6 +321,32 @@ class HipBackend(object):
                                                   L.ptr(bias), 1 if relu else 0, L.ptr(y), cout, int(mfma)),
                     "tpu3_linear_small_f32")
         return y
+
+    def dec_train_forward(self, x, idx, idx_off, weights):
+        """Training forward of the (24, 12, 3, k = 32) DenseEdgeConv block: x (P,N,24), idx (P,N,S) int32 with the
+        neighbours at [idx_off, idx_off + 32), weights = (w0, b0, w1, b1, w2, b2) -> y (P,N,60), arg (P,N,36) u8."""
+        P, N, _ = x.shape
+        y = torch.empty((P, N, 60), dtype=torch.float32, device=x.device)
+        arg = torch.empty((P, N, 36), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_dec_train_fwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
+                                                   *[L.ptr(w) for w in weights], L.ptr(y), L.ptr(arg)),
+                    "tpu3_dec_train_fwd_f32")
+        return y, arg
+
+    def dec_train_backward(self, x, idx, idx_off, weights, arg, gy):
+        """-> gx (P,N,24), G (P*N*32, 36), Z (P*N*32, 48), S (P*N, 36); see tpu3_dec_train_bwd_f32."""
+        P, N, _ = x.shape
+        dev = x.device
+        gx = torch.zeros((P, N, 24), dtype=torch.float32, device=dev)
+        G = torch.empty((P * N * 32, 36), dtype=torch.float32, device=dev)
+        Z = torch.empty((P * N * 32, 48), dtype=torch.float32, device=dev)
+        S = torch.empty((P * N, 36), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().tpu3_dec_train_bwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
+                                                   *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), L.ptr(gx),
+                                                   L.ptr(G), L.ptr(Z), L.ptr(S)), "tpu3_dec_train_bwd_f32")
+        return gx, G, Z, S
 
     def gather_rows(self, x, idx):
         """x (B,N,C) f32 contiguous, idx (B,...) int32 / int64 -> (B,...,C) rows, or None when not covered."""

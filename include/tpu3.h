@@ -179,12 +179,13 @@ int tpu3_knn_graph_f32(tpu3_stream_t stream, int b, int m, int n, int c, int k, 
  * pre-pass: identical rows have D == 0 exactly, so the kernel itself notices whether any row could
  * be duplicated; only then the hash de-duplication and the exact kernels run (device-side gates).
  * dup (b,n) u8 and uws (TPU3_KNN_UWS_WORDS(groups) u32) are scratch; workspace =
- * tpu3_knn_unique_workspace_bytes(b, n) bytes (n >= 128). */
+ * tpu3_knn_unique_workspace_bytes(b, n) bytes (n >= 128).  Slot 0 = the query's own row (the nearest), the other
+ * k-1 members of the exact top-k set in no particular order (k < n <= 8192: one pass with the index in the key). */
 int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
                             const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,
                             void *workspace, size_t workspace_bytes);
 
-/* Optimistic form of the call above: only the two-pass graph kernel -- no scratch, no gated fallback
+/* Optimistic form of the call above: only its first pass -- no scratch, no gated fallback
  * launches behind it.  If some query saw a second zero distance (rows may be duplicated) events[2] is set to 1
  * and the result of THAT call is not guaranteed: recompute it with tpu3_knn_graph_self_f32.  events: 4 u32
  * device words zeroed once by the caller and shared by any number of calls (events[0] must stay 0); the caller
@@ -308,6 +309,23 @@ size_t tpu3_linear_wgrad_workspace_bytes(long m);
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
                        float *out, float *centroid, float *radius);
+
+/* DenseEdgeConv block for TRAINING (network/layers.py:44-64 under autograd, model.py:53-66) for the reference's
+ * shape: 24 input channels, growth 12, three layers, k = 32 neighbours (else TPU3_ELIMIT: callers then use their
+ * autograd formulation).  x (p,n,24), idx (p,n,idx_stride) i32 with the 32 neighbours of a point at
+ * idx_off .. idx_off+31, w0 (12,48) / w1 (12,36) / w2 (12,48) = the convolution weights, b* (12).
+ *   fwd: y (p,n,60) = [max_k h2 | max_k h1 | max_k h0 | x_i], arg (p,n,36) u8 = the neighbour slot attaining each max.
+ *   bwd: gy (p,n,60) -> gx (p,n,24) ACCUMULATED with hardware float atomics (zeroed by the caller),
+ *        G (p*n*32, 36) = [g2 | g1 | g0] and Z (p*n*32, 48) = [h1 | h0 | x_j - x_i] per edge (the operands of the
+ *        weight gradients of the edge parts: tpu3_linear_wgrad_f32 on column slices), S (p*n, 36) = G summed over
+ *        a point's edges (weight gradients of the x_i parts = S^T X, bias gradients = column sums of S). */
+int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
+                           int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
+                           const float *b1, const float *w2, const float *b2, float *y, uint8_t *arg);
+int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
+                           int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
+                           const float *b1, const float *w2, const float *b2, const uint8_t *arg, const float *gy,
+                           float *gx, float *G, float *Z, float *S);
 
 /* The differentiable neighbour gather of group_knn (network/operations.py:209-211: torch.gather over the expanded
  * point tensor; its backward is an index accumulation) on channel-last rows, training:

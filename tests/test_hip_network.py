@@ -648,6 +648,34 @@ def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
     assert (got.double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("given_idx", [False, True])
+def test_dense_edge_conv_fused_training_matches_autograd(dev, given_idx):
+    """csrc/dec_train.hip (one launch per direction) against the autograd formulation of the same block
+    (reference layers.py:44-64): output, input gradient and all six parameter gradients, on several patches
+    with a non-multiple-of-8 point count."""
+    layers = pkg("network.layers")
+    torch.manual_seed(11)
+    blk = layers.DenseEdgeConv(24, growth_rate=12, n=3, k=32).to(dev)
+    P, N = 5, 101
+    x0 = torch.randn(P, N, 24, device=dev)
+    idx = torch.randint(0, N, (P, N, 32), device=dev) if given_idx else None
+    w = torch.randn(P, N, 60, device=dev)
+    res = []
+    for fused in (True, False):
+        blk.fused_train, blk.hoist_train = fused, False
+        blk.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y, used = blk.forward_cl(x, idx)
+        (y * w).sum().backward()
+        res.append((y.detach(), x.grad.detach(), [p.grad.detach().clone() for p in blk.parameters()], used))
+    (ya, gxa, gpa, ia), (yb, gxb, gpb, ib) = res
+    assert torch.equal(ia, ib)
+    assert (ya - yb).abs().max() < 1e-4
+    assert (gxa - gxb).abs().max() < 1e-3 * max(1.0, float(gxb.abs().max()))
+    for a, b in zip(gpa, gpb):
+        assert a.shape == b.shape and (a - b).abs().max() < 1e-3 * max(1.0, float(b.abs().max()))
+
+
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
 def test_gather_neighbours_forward_and_backward(dev, idx_dtype):
     """The differentiable neighbour gather of the training path (tpu3_gather_rows_f32 / tpu3_scatter_add_rows_f32)
