@@ -358,8 +358,7 @@ __device__ __forceinline__ float fb_dbox(float qx, float qy, float qz, float lx,
 // may be accepted.  The re-scans of a round are listed first and then run several buckets at a time with
 // all their loads in flight.
 // ---------------------------------------------------------------------------------------------
-constexpr int FM_WCAP = 8;          // candidates a wave may enter per round
-constexpr int FM_CAP = 32;          // = 4 waves x FM_WCAP: a 32-bit sample mask per bucket
+constexpr int FM_CAP = 32;          // candidates per round (FM_CAP / NW per wave): a 32-bit sample mask per bucket
 constexpr int FM_EW = 8;            // words per candidate entry (5 used)
 
 struct FmHeader {                   // one per wave and buffer
@@ -372,7 +371,7 @@ struct FmHeader {                   // one per wave and buffer
 };
 
 struct FmShared {
-    FmHeader h[2][4];
+    FmHeader h[2][8];
     uint32_t stat[8];               // PROF: rounds, samples, capped rounds, tie rounds, ...
 };
 
@@ -395,7 +394,8 @@ template <int NW, int PPL, bool PROF = false, bool L3 = false>
 __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
 {
     static_assert(!L3 || PPL == 1, "leaf buckets are 64 points");
-    static_assert(NW == 4, "candidate slots are laid out for four waves");
+    static_assert(NW == 4 || NW == 8, "candidate slots: FM_CAP / NW per wave");
+    constexpr int WCAP = FM_CAP / NW;      // candidates a wave may enter per round
     constexpr int W = NW * 64;
     constexpr int GT = W;                           // group-table entries (owner order), one per lane
     static_assert(2 * FM_CAP * FM_EW + 2 * NW * 64 * 2 <= 6 * GT, "lists must fit the setup-only box area");
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             bool is_cand = gmax > rstar;
             unsigned long long cm = __ballot(is_cand);
             int drop = (int)0x80000000;
-            if (__builtin_popcountll(cm) > FM_WCAP) {
+            if (__builtin_popcountll(cm) > WCAP) {
                 // keep the wave's FM_WCAP best; the best one left out limits what may be accepted this round
                 int lrank = 0;
                 for (unsigned long long mm = cm; mm;) {
@@ -785,13 +785,13 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                     const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)gk, i);
                     lrank += (mi > gmax || (mi == gmax && ki < gk)) ? 1 : 0;
                 }
-                const bool keep = is_cand && lrank < FM_WCAP;
+                const bool keep = is_cand && lrank < WCAP;
                 drop = tpu3_wave_max_i32_fast(is_cand && !keep ? gmax : (int)0x80000000);
                 is_cand = keep;
                 cm = __ballot(is_cand);
             }
             if (is_cand) {
-                const int pos = wave * FM_WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                const int pos = wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
                 uint32_t *e = cl + pos * FM_EW;
                 e[0] = (uint32_t)gmax; e[1] = gk;
                 e[2] = __float_as_uint(g_x[tid]); e[3] = __float_as_uint(g_y[tid]); e[4] = __float_as_uint(g_z[tid]);
@@ -815,8 +815,8 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
         rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
         const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
         // candidate `lane` of the list: wave lane / FM_WCAP, entry lane % FM_WCAP
-        const int cw = (lane >> 3) & (NW - 1);
-        const bool live = lane < FM_CAP && (lane & (FM_WCAP - 1)) < sh.h[par][cw].count;
+        const int cw = (lane / WCAP) & (NW - 1);
+        const bool live = lane < FM_CAP && (lane % WCAP) < sh.h[par][cw].count;
         const unsigned long long lm = __ballot(live);
         const int total = __builtin_popcountll(lm);
         const int left = a.m - r;
@@ -1484,7 +1484,6 @@ struct FbPlan {
     size_t total;
 };
 
-constexpr int FB_NW = 4;            // waves per workgroup (one per SIMD)
 constexpr int FB_NB_MAX = 4096;     // buckets: 32 B of LDS each
 constexpr int FB_SORT_BITS = 31;    // 30 Morton bits + the dead-slot bit of ragged elements
 
@@ -1515,12 +1514,18 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.l3 = p.nb > FB_NB_MAX;
     if (p.l3 && p.nb > FB_NB_MAX * FB_GS)
         return false;
-    const int unit = FB_GS * FB_NW * (p.l3 ? FB_GS : 1);                            // whole groups per wave
-    p.nbpad = (p.nb + unit - 1) / unit * unit;
-    p.ncell = p.l3 ? p.nbpad / FB_GS : p.nbpad;
+    // waves per workgroup: 8 (two per SIMD: a round's re-scans spread over twice the waves: 103 -> 84 ms for
+    // 239 616 -> 80 000) when the LDS tables fit next to eight waves' work lists, else 4.  TPU3_FM_NW=4 (tuning hook).
+    static const int fm_nw = getenv("TPU3_FM_NW") ? atoi(getenv("TPU3_FM_NW")) : 8;
+    for (p.nw = fm_nw == 4 ? 4 : 8;; p.nw = 4) {
+        const int unit = FB_GS * p.nw * (p.l3 ? FB_GS : 1);                         // whole groups per wave
+        p.nbpad = (p.nb + unit - 1) / unit * unit;
+        p.ncell = p.l3 ? p.nbpad / FB_GS : p.nbpad;
+        if (p.nw == 4 || fm_lds_bytes(p.ncell, p.nw) <= 160 * 1024)
+            break;
+    }
     p.ng = p.ncell / FB_GS;
     p.npad = p.nb * bsz;
-    p.nw = FB_NW;
     p.ngpt = (p.ng + p.nw * 64 - 1) / (p.nw * 64);          // 1 for ng <= 256
     p.ks = align256(sizeof(uint32_t) * (size_t)n);
     p.ps = align256(sizeof(float) * (size_t)p.npad);
@@ -1566,15 +1571,16 @@ int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
 {
     if (p.ngpt != 1)
         return TPU3_ELIMIT;
-    const size_t lds = fm_lds_bytes(p.ncell, FB_NW);
-    auto kern = p.l3 ? fm_main_kernel<FB_NW, PPL, PROF, true> : fm_main_kernel<FB_NW, PPL, PROF, false>;
+    const size_t lds = fm_lds_bytes(p.ncell, p.nw);
+    auto kern = p.nw == 8 ? (p.l3 ? fm_main_kernel<8, PPL, PROF, true> : fm_main_kernel<8, PPL, PROF, false>)
+                          : (p.l3 ? fm_main_kernel<4, PPL, PROF, true> : fm_main_kernel<4, PPL, PROF, false>);
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
     const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (e0) (void)hipEventRecord(e0, s);
-    hipLaunchKernelGGL(kern, dim3(b), dim3(FB_NW * 64), lds, s, a0);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(p.nw * 64), lds, s, a0);
     if (e1) (void)hipEventRecord(e1, s);
     return tpu3_launch_status();
 }
