@@ -17,7 +17,7 @@ The default (--gpus N, 32 clouds per GPU) is the throughput configuration of the
 
 One JSON line is printed by rank 0.  Besides the contract's keys it carries
   roofline          dominant kernel (final FPS, fm_main_kernel): measured traffic / launch time against the
-                    HBM peak -- never above 1 -- plus us_per_round against a stated floor; the streaming
+                    HBM peak -- never above 1 -- plus us_per_sample next to a stated per-round floor; the streaming
                     model of SURVEY 8d as `model_ratio` (the kernel skips >99 % of that model's bytes)
   rooflines_other   every other hand-written kernel of a step, timed with events on its launch stream:
                     MFMA kernels on EXECUTED matrix-core FLOPs, the kNN graph on the (2C+3) VALU model
@@ -502,11 +502,12 @@ def main():
                 "basis": "measured fabric traffic of one launch (PMC, profiles/r02_traffic.json) / launch time (HIP events "
                          "on the kernel's stream)",
                 "launch_ms": fps_ms, "operator_ms": op_ms,
-                "us_per_round": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
+                "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
                 "us_per_round_floor": 0.9,
-                "floor_note": "a round is one dependent chain per cloud on ONE compute unit: L2-hit load of the winner's "
-                              "bucket group (~320 cycles) -> distance update + row arg-max (DPP) -> one barrier -> broadcast; "
-                              "~2200 cycles = 0.9 us at 2.4 GHz with every load hitting L2",
+                "floor_note": "a round (~8 samples of a cloud) is one dependent chain on ONE compute unit: L2-hit load of "
+                              "the reached bucket groups (~320 cycles) -> distance update + row arg-max (DPP) -> one "
+                              "barrier -> ranking; ~2200 cycles = 0.9 us at 2.4 GHz with every load hitting L2; "
+                              "us_per_sample = launch time / samples per cloud (the clouds of a launch run side by side)",
                 "model_bytes_per_launch": model_bytes,
                 "model_ratio": (model_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fps_ms else None,
                 "compulsory_bytes_per_launch": float(CL) * (12.0 * n_merged + 4.0 * m_out)}
