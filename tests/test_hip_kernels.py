@@ -102,6 +102,24 @@ def test_fps_register_resident_bucketed_kernel(orc, dev, n, m):
     np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp2)
 
 
+def test_fps_level_stats_probe_counts_every_sample(dev):
+    """tpu3_debug_fps_level_stats (the probe tools/fps_real_level_probe.py reads): the register-resident
+    multi-sample kernel reports rounds and samples of its first set -- every sample is accounted for, and a
+    round yields several."""
+    ops, L = pkg("network.operations"), pkg("_lib")
+    x = _t(sphere(77, 12480, 2), dev)
+    stats = torch.zeros(46, dtype=torch.int64, device=dev)
+    L.lib().tpu3_debug_fps_level_stats(stats.data_ptr())
+    ops.fps(x, 2496)
+    torch.cuda.synchronize()
+    rounds, samples = int(stats[0]), int(stats[1])
+    assert samples == 2496 and 0 < rounds < samples // 2
+    stats.zero_()
+    ops.fps(x, 2496)                                   # one-shot: the next call does not write
+    torch.cuda.synchronize()
+    assert int(stats[0]) == 0
+
+
 def test_fps_bucketed_continues_from_given_temp(orc, dev):
     """temp is in/out: a second call that starts from the first call's distances must behave like
     the plain algorithm started from them (the bucket table is built from the caller's temp)."""
