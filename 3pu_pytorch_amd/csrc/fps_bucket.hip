@@ -1127,6 +1127,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     constexpr bool ZL = rl_zl<R>();
     auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2
+    unsigned long long pr[5] = {0, 0, 0, 0, 0}, r0 = 0, r1 = 0;        // PROF, wave 0: ranking phases, candidates
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t *i16 = (uint16_t *)smem;                               // original index of [wave][j][lane]
     float *zl = (float *)(smem + (size_t)1024 * R * 2);             // (ZL) z of [wave][j][lane]
@@ -1338,6 +1339,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                 const bool live = lane < RL_CAP && (lane % WCAP) < sh.h[par][(lane / WCAP) & 15].count;
                 const unsigned long long lm = __ballot(live);
                 const int total = __builtin_popcountll(lm);
+                if (PROF) { r0 = now(); pr[0] += r0 - t0; pr[4] += (unsigned long long)total; }
                 float qx, qy, qz;
                 uint32_t okey;
                 int nj;
@@ -1377,6 +1379,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                             rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
                         }
                     }
+                    if (PROF) { r1 = now(); pr[1] += r1 - r0; r0 = r1; }
                     const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
                     const int dst = (live ? rank : deadpos) * 4;
                     qx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cx)));
@@ -1413,6 +1416,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                         }
                     }
                     nj = jmax;
+                    if (PROF) { r1 = now(); pr[2] += r1 - r0; r0 = r1; }
                 }
                 nj = nj < left ? nj : left;
                 if (lane < RL_CAP) {
@@ -1442,6 +1446,9 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                 if (PROF && a0.prof && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1))
                     for (int i = 0; i < 6; ++i)
                         a0.prof[2 + wave * 6 + i] = pc[i];
+                if (PROF && a0.prof && blockIdx.x == 0 && tid == 0)
+                    for (int i = 0; i < 5; ++i)
+                        a0.prof[46 + i] = pr[i];
                 if (PROF && a0.prof && blockIdx.x == 0 && lane == 0) {      // every wave: apply cycles, updates
                     a0.prof[14 + wave * 2] = pc[0];
                     a0.prof[15 + wave * 2] = pc[5];

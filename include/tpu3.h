@@ -348,7 +348,8 @@ int tpu3_scatter_add_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c,
  * tpu3_debug_fps_level_stats: the NEXT FPS call that takes the register-resident multi-sample kernel (per-level
  * resampling, 4096 < n <= 25 600) writes (rounds, samples) of its first set to stats[0..1] and, for the largest
  * sets, per-phase cycle counters of waves 0 and 1 to stats[2..13] and every wave's (update cycles, sample
- * updates) to stats[14..45] (46 device words).  One-shot. */
+ * updates) to stats[14..45], wave 0's ranking phases and candidate count to stats[46..50] (52 device words).
+ * One-shot. */
 int tpu3_debug_fps_bucket_events(void *start, void *stop);
 int tpu3_debug_fps_level_stats(unsigned long long *stats);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,

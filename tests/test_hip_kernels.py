@@ -108,7 +108,7 @@ def test_fps_level_stats_probe_counts_every_sample(dev):
     round yields several."""
     ops, L = pkg("network.operations"), pkg("_lib")
     x = _t(sphere(77, 12480, 2), dev)
-    stats = torch.zeros(46, dtype=torch.int64, device=dev)
+    stats = torch.zeros(52, dtype=torch.int64, device=dev)
     L.lib().tpu3_debug_fps_level_stats(stats.data_ptr())
     ops.fps(x, 2496)
     torch.cuda.synchronize()

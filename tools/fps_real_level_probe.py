@@ -28,7 +28,7 @@ with torch.no_grad():
     pipe.upsample(net, clouds, 312, 16, 3, final_fps=False, check_small=False)
 ops.BACKEND.fps = orig
 torch.cuda.synchronize()
-stats = torch.zeros(46, dtype=torch.int64, device=dev)
+stats = torch.zeros(52, dtype=torch.int64, device=dev)
 for n, (x, m, na, ma) in sorted(seen.items()):
     for nb in (x.size(0), 1):
         xs = x[:nb].contiguous()
@@ -50,6 +50,9 @@ for n, (x, m, na, ma) in sorted(seen.items()):
         if pc[14:].any():
             print("    apply cycles per round, waves 0..15: " + " ".join("%.0f" % (pc[14 + 2 * w] / max(1, r)) for w in range(16)))
             print("    sample updates per round, waves 0..15: " + " ".join("%.2f" % (pc[15 + 2 * w] / max(1, r)) for w in range(16)))
+        if pc[46:].any():
+            print("    wave 0 ranking per round: headers+live %.0f  rank loops %.0f  permute+clearance %.0f  | candidates %.1f"
+                  % (pc[46] / max(1, r), pc[47] / max(1, r), pc[48] / max(1, r), pc[50] / max(1, r)))
         if pc[2:14].any():
             for w in range(2):
                 print("    wave %d cycles per round: " % w + "  ".join(
