@@ -1362,12 +1362,17 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
                     int rank = 0;
                     bool tie = false;
+                    // (two candidates per step: the scalar bit scan -> readlane -> compare chain of one candidate
+                    // costs ~175 cycles in a lone wave; two independent chains overlap)
                     for (unsigned long long mm = lm; mm;) {
                         const int i = __builtin_ctzll(mm);
                         mm &= mm - 1;
+                        const int i2 = mm ? __builtin_ctzll(mm) : i;        // (a repeat of i adds nothing below)
+                        mm &= mm - 1;
                         const int mi = __builtin_amdgcn_readlane(cM, i);
-                        rank += mi > cM ? 1 : 0;
-                        tie |= (mi == cM && i != lane);
+                        const int mi2 = __builtin_amdgcn_readlane(cM, i2);
+                        rank += (mi > cM ? 1 : 0) + (i2 != i && mi2 > cM ? 1 : 0);
+                        tie |= (mi == cM && i != lane) || (mi2 == cM && i2 != lane);
                     }
                     if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
                         rank = 0;
