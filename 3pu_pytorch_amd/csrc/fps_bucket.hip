@@ -372,6 +372,7 @@ struct FmHeader {                   // one per wave and buffer
 
 struct FmShared {
     FmHeader h[2][8];
+    int nwk[8];                     // entries on each wave's re-scan list this round (two-level form)
     uint32_t stat[8];               // PROF: rounds, samples, capped rounds, tie rounds, ...
 };
 
@@ -572,16 +573,18 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     // ---- re-scan the first `nwork` buckets of the wave's work list (entry = bucket, set of samples that
     // reach it), CH at a time with all their loads in flight together.  (Fetching the next CH while the current
     // ones are worked on was tried through a two-buffer struct: the compiler put it in scratch, 200 vs 103 ms.)
-    auto rescan = [&](const uint32_t *list, int nwork) __attribute__((always_inline)) {
-        for (int w0 = 0; w0 < nwork; w0 += CH) {
+    // `at(e)` = the two words of entry e; the wave takes entries first, first + 1, .. first + CH - 1, then `step` on
+    auto rescan_at = [&](auto at, int nwork, int first, int step) __attribute__((always_inline)) {
+        for (int w0 = first; w0 < nwork; w0 += step) {
             FbBucket<PPL> bk[CH];
             int tb[CH];
             uint32_t pmv[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int e = w0 + u < nwork ? w0 + u : w0;         // a short tail repeats the first (idempotent)
-                tb[u] = __builtin_amdgcn_readfirstlane((int)list[2 * e]);
-                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[2 * e + 1]);
+                const uint32_t *ent = at(e);
+                tb[u] = __builtin_amdgcn_readfirstlane((int)ent[0]);
+                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[1]);
                 fb_load<PPL>(bk[u], sp, skey, tb[u], lane);
             }
             FbCand c[CH];
@@ -636,6 +639,9 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                     fb_store<PPL>(bk[u], sp, tb[u], lane);     // stores last
         }
     };
+    auto rescan = [&](const uint32_t *list, int nwork) __attribute__((always_inline)) {
+        rescan_at([&](int e) __attribute__((always_inline)) { return list + 2 * e; }, nwork, 0, CH);
+    };
 
     // ---- work off the first `nwork` entries of the wave's list (cell or bucket, set of samples reaching it) ----
     auto flush = [&](int nwork) __attribute__((always_inline)) {
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                            __int_as_float(gmax) ? (1u << i) : 0u;
         const unsigned long long gmask = __ballot(gpm != 0);
         if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
-        if (!gmask)
+        if (L3 && !gmask)
             return;
         // 2. children tests, four touched groups (one per DPP row) at a time: every reached bucket goes on
         //    the wave's work list together with the set of samples that reach it
@@ -739,7 +745,36 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
         }
         if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
         // 3. the re-scans
-        flush(nwork);
+        if constexpr (L3) {
+            flush(nwork);
+        } else {
+            // A sample's neighbourhood is one or two groups, i.e. one or two WAVES' lists: the round's re-scans are
+            // dealt out over all waves -- the lists stay where they are, every wave reads the others' lengths after a
+            // barrier and takes every NW-th chunk of CH entries of their concatenation; a second barrier before the
+            // owners rebuild their group entries from the bucket table.  (Two more barriers per round, but the slowest
+            // wave's re-scan time was twice the average.)
+            if (lane == 0)
+                sh.nwk[wave] = nwork;
+            __syncthreads();
+            int pre[NW + 1];
+            pre[0] = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                pre[w + 1] = pre[w] + __builtin_amdgcn_readfirstlane(sh.nwk[w]);
+            rescan_at([&](int e) __attribute__((always_inline)) {
+                int ws = 0, base = 0;
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const bool ge = e >= pre[w];
+                    ws = ge ? w : ws;
+                    base = ge ? pre[w] : base;
+                }
+                return (const uint32_t *)(work + ws * 128 + 2 * (e - base));
+            }, pre[NW], wave * CH, NW * CH);
+            __syncthreads();
+            if (!gmask)
+                return;
+        }
         if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
         // 4. rebuild the touched groups' entries
         for (unsigned long long mask = gmask; mask;) {
