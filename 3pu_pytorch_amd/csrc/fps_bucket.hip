@@ -644,16 +644,16 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     };
 
     // ---- work off the first `nwork` entries of the wave's list (cell or bucket, set of samples reaching it) ----
-    auto flush = [&](int nwork) __attribute__((always_inline)) {
-        if constexpr (!L3) {
-            rescan(wl, nwork);
-        } else {
-            for (int w0 = 0; w0 < nwork; w0 += 4) {
+    // L3: entries = cells; `at(e)` as for rescan_at (evaluated per lane: the four rows look at four entries)
+    auto flush_cells = [&](auto at, int nwork, int first, int step) __attribute__((always_inline)) {
+        if constexpr (L3) {
+            for (int w0 = first; w0 < nwork; w0 += step) {
                 // four listed cells at a time, one per DPP row; lane `col` looks at leaf `col` of its row's cell
                 const int e = w0 + row;
                 const bool valid = e < nwork;
-                const int cell = valid ? (int)wl[2 * e] : -1;
-                uint32_t rem = valid ? wl[2 * e + 1] : 0u;
+                const uint32_t *ent = at(valid ? e : w0);
+                const int cell = valid ? (int)ent[0] : -1;
+                uint32_t rem = valid ? ent[1] : 0u;
                 const int leaf = valid ? cell * FB_GS + col : 0;
                 const uint32_t w0b = a.ib[5 * LS + leaf], w1b = a.ib[6 * LS + leaf], w2b = a.ib[7 * LS + leaf];
                 const float tm = __int_as_float((int)a.ib[0 * LS + leaf]);
@@ -683,6 +683,12 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             }
         }
     };
+    auto flush = [&](int nwork) __attribute__((always_inline)) {
+        if constexpr (!L3)
+            rescan(wl, nwork);
+        else
+            flush_cells([&](int e) __attribute__((always_inline)) { return (const uint32_t *)(wl + 2 * e); }, nwork, 0, 4);
+    };
 
     // ---- fold the first `nj` current samples into everything they reach -------------------------------
     auto apply = [&](int nj) __attribute__((always_inline)) {
@@ -695,8 +701,6 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                            __int_as_float(gmax) ? (1u << i) : 0u;
         const unsigned long long gmask = __ballot(gpm != 0);
         if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
-        if (L3 && !gmask)
-            return;
         // 2. children tests, four touched groups (one per DPP row) at a time: every reached bucket goes on
         //    the wave's work list together with the set of samples that reach it
         int nwork = 0;
@@ -745,9 +749,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
         }
         if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
         // 3. the re-scans
-        if constexpr (L3) {
-            flush(nwork);
-        } else {
+        {
             // A sample's neighbourhood is one or two groups, i.e. one or two WAVES' lists: the round's re-scans are
             // dealt out over all waves -- the lists stay where they are, every wave reads the others' lengths after a
             // barrier and takes every NW-th chunk of CH entries of their concatenation; a second barrier before the
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
 #pragma unroll
             for (int w = 0; w < NW; ++w)
                 pre[w + 1] = pre[w] + __builtin_amdgcn_readfirstlane(sh.nwk[w]);
-            rescan_at([&](int e) __attribute__((always_inline)) {
+            auto at = [&](int e) __attribute__((always_inline)) {
                 int ws = 0, base = 0;
 #pragma unroll
                 for (int w = 1; w < NW; ++w) {
@@ -770,7 +772,11 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
                     base = ge ? pre[w] : base;
                 }
                 return (const uint32_t *)(work + ws * 128 + 2 * (e - base));
-            }, pre[NW], wave * CH, NW * CH);
+            };
+            if constexpr (L3)
+                flush_cells(at, pre[NW], wave * 4, NW * 4);         // (three levels: the entries are cells)
+            else
+                rescan_at(at, pre[NW], wave * CH, NW * CH);
             __syncthreads();
             if (!gmask)
                 return;
