@@ -33,20 +33,19 @@ class LossLog(object):
     update(name, value, count): mean += (value - mean) / count with a 0-d device tensor `value`
     (the reference's rule, :74-76, where count = step + 1)."""
 
+    ROWS = 64                    # fixed: captured graphs hold views into the table, so it must never move
+
     def __init__(self):
         self._slot = {}          # name -> row in the device table
-        self._table = None       # (rows,) float32 on the device of the first update
+        self._table = None       # (ROWS,) float32 on the device of the first update
 
     def _row(self, name, like):
         if name not in self._slot:
-            self._slot[name] = len(self._slot)
-            need = len(self._slot)
+            if len(self._slot) >= self.ROWS:
+                raise RuntimeError("LossLog: more than %d distinct keys" % self.ROWS)
             if self._table is None:
-                self._table = torch.zeros((max(8, need),), dtype=torch.float32, device=like.device)
-            elif need > self._table.numel():
-                grown = torch.zeros((2 * need,), dtype=torch.float32, device=self._table.device)
-                grown[:self._table.numel()] = self._table
-                self._table = grown
+                self._table = torch.zeros((self.ROWS,), dtype=torch.float32, device=like.device)
+            self._slot[name] = len(self._slot)
         return self._slot[name]
 
     def update(self, name, value, count):
@@ -154,7 +153,8 @@ class Model(object):
             self.error_log = LossLog()
             self.chamfer_criteria = ChamferLoss()
             self.lr = self.old_lr = opt.lr_init
-            self.graph_steps = bool(getattr(opt, "graph_steps", False) or os.environ.get("TPU3_GRAPH_STEPS"))
+            self.graph_steps = bool(getattr(opt, "graph_steps", False)
+                                    or os.environ.get("TPU3_GRAPH_STEPS", "").strip().lower() not in ("", "0", "false", "no"))
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=opt.lr_init, betas=(0.9, 0.999),
                                               capturable=self.graph_steps)
             self._captured = {}
@@ -190,7 +190,12 @@ class Model(object):
         """One optimisation step on the tensors given to set_input."""
         self.net.train()
         if self.graph_steps and self.input.is_cuda:
-            key = (self.up_ratio, tuple(self.input.shape), tuple(self.gt.shape))
+            # threshold and forward weight are scalar launch arguments, i.e. frozen into a captured graph:
+            # main.py's curriculum toggles the threshold mid-training (set_threshold / unset_threshold), so
+            # they are part of the key -- a toggle captures (once) a second graph instead of being ignored
+            crit = self.chamfer_criteria
+            key = (self.up_ratio, tuple(self.input.shape), tuple(self.gt.shape),
+                   crit._threshold, float(crit.forward_weight))
             step = self._captured.get(key)
             if step is None:
                 step = self._captured[key] = _CapturedStep(self, self.input, self.up_ratio, self.gt)

@@ -48,11 +48,13 @@ class HipBackend(object):
 
     COMPACT_MIN_N = 1024      # unique=True: point sets this large get a first-occurrence list
 
-    # Self kNN graphs run optimistically: only the two-pass kernel, which raises a device-side event when a
-    # query saw a second zero distance (rows may be duplicated: the exact path is then required).  Whoever
-    # drives the network reads `graph_dup_events()` at its synchronisation point and recomputes with
-    # `optimistic_graph = False` (pipeline.upsample does; bench.py asserts the count is zero).
-    optimistic_graph = True
+    # Self kNN graphs can run optimistically: only the one-pass kernel, which raises a device-side event when a
+    # query saw a second zero distance (rows may be duplicated: the exact path is then required).  OFF by
+    # default: direct callers (net(x) in eval mode, pipeline.pc_prediction, Model.test_model) get the exact
+    # gated form, whose result needs no check.  A driver that owns a synchronisation point opts in, reads
+    # `graph_dup_events()` there and recomputes with the exact form (pipeline.upsample does; bench.py opts in
+    # and asserts the count is zero).
+    optimistic_graph = False
 
     def _events(self, dev):
         ev = getattr(self, "_event_words", None)

@@ -55,9 +55,10 @@ class Net(torch.nn.Module):
                                     torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
                     torch.nn.init.zeros_(m.bias)
                     torch.nn.init.ones_(m.weight)
-        # per eval call and level: number of clouds whose outlier-filtered size was below one patch
-        # (0-d device tensors, appended without a synchronisation; see small_cloud_events)
-        self._small_cloud_counts = []
+        # number of (cloud, level) pairs whose outlier-filtered size was below one patch: one device scalar per
+        # (device, stream) that produced them, accumulated in place without a synchronisation (bounded by the
+        # number of streams, however many eval calls are made; see small_cloud_events)
+        self._small_cloud_counts = {}
         # optional list: when set, the eval path appends one dict per level
         # (patch_xyz (P,3,k) un-normalised inputs, out_norm (P,3,k*r) level output, patch_num)
         self.trace = None
@@ -125,7 +126,7 @@ class Net(torch.nn.Module):
         # patch_num = int(num_point / k * 5) per cloud, in double like Python (:76)
         P = int(N / k * 5)
         patch_num = torch.floor(count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
-        self._small_cloud_counts.append((count < k).sum())
+        self._note_small_clouds((count < k).sum())
         kk = min(k, N)
         seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
         slot = torch.minimum(_arange_like(P, xyz_cl).view(1, P), (patch_num - 1).view(B, 1).long())
@@ -135,21 +136,36 @@ class Net(torch.nn.Module):
                                              layout=dict(n_arr=count), want_dist=False)
         return patches, patch_num
 
+    def _note_small_clouds(self, n):
+        """n: 0-d device tensor.  Added to the scalar of the current (device, stream): kernels of different
+        streams never update the same word."""
+        key = (n.device.type, n.device.index, torch.cuda.current_stream(n.device).cuda_stream if n.is_cuda else 0)
+        cell = self._small_cloud_counts.get(key)
+        if cell is None:
+            self._small_cloud_counts[key] = n.to(torch.int64).clone()
+        else:
+            cell.add_(n)
+
     @property
     def small_cloud_events(self):
         """Number of (cloud, level) pairs since the last reset whose filtered cloud had fewer points
-        than a patch.  The batched eval path keeps k = num_point there (the reference shrinks k to the
-        filtered size, :75-78), so such a cloud's result is NOT the reference's: callers that care
-        (pipeline.upsample(check_small=True), bench.py) read this after their synchronisation and
-        raise.  Reading synchronises the device (the counts live on whatever streams produced them)."""
+        than a patch.  The reference shrinks k to the filtered size there (:75-78); the batched path keeps
+        k = num_point and reports.  The case is unreachable for finite input without wholesale duplication:
+        the filter keeps d_i < 5 * mean(d), and by Markov's inequality at most N/5 of N non-negative values
+        reach five times their mean, so N' >= 0.8 N >= 1.6 k (a level's input has step_ratio >= 2 times the
+        patch size).  It takes NaN / Inf coordinates or a cloud in which every point has a twin (all d = 0:
+        nothing passes `0 < 0`) -- inputs on which the reference itself fails (empty FPS / torch.cat).
+        Callers that care (pipeline.upsample(check_small=True), bench.py) read this after their
+        synchronisation and raise.  Reading synchronises the device."""
         if not self._small_cloud_counts:
             return 0
-        if any(c.is_cuda for c in self._small_cloud_counts):
+        cells = list(self._small_cloud_counts.values())
+        if any(c.is_cuda for c in cells):
             torch.cuda.synchronize()
-        return int(sum(int(c) for c in self._small_cloud_counts))
+        return int(sum(int(c) for c in cells))
 
     def reset_small_cloud_events(self):
-        self._small_cloud_counts = []
+        self._small_cloud_counts = {}
 
     def set_mlp_precision(self, precision):
         """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):

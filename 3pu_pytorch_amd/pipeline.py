@@ -86,39 +86,70 @@ def shard_range(total, rank, world):
     return ids, per
 
 
+def _any_rank(flag, device):
+    """True on every rank if `flag` is true on any rank (one MAX all-reduce of a single word; no-op without a
+    process group).  Decisions that change the NUMBER of collectives a rank issues must be taken on this."""
+    rank, world = _world()
+    if world == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-             timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, check_small=None):
-    """See _upsample.  check_small: after enqueueing, synchronise, (i) recompute with the exact kNN-graph form if
-    an optimistic graph call reported possibly duplicated feature rows, and (ii) raise if the outlier filter left
-    some cloud with fewer points than a patch at some level (the batched path does not reproduce the
-    reference's shrunken k there, network/upsampler.py:75-78).  Default: on for plain calls, off when
-    the caller overlaps work on side streams (fps_stream / net_streams) -- such callers (bench.py)
-    check `net.small_cloud_events` themselves at their own synchronisation point."""
+             timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, check_small=None,
+             optimistic_graph=None):
+    """See _upsample.
+    check_small: after enqueueing, synchronise, (i) recompute with the exact kNN-graph form if an optimistic graph
+    call reported possibly duplicated feature rows, and (ii) raise if the outlier filter left some cloud with fewer
+    points than a patch at some level (unreachable for finite input, see Net.small_cloud_events).  Default: on for
+    plain calls, off when the caller overlaps work on side streams (fps_stream / net_streams) -- such callers
+    (bench.py) read `net.small_cloud_events` and `BACKEND.graph_dup_events()` at their own synchronisation point.
+    optimistic_graph: run the feature-space kNN graphs in their one-pass self-checking form (the backend's default
+    is the exact gated form).  Default: exactly when this call also performs the check (check_small); a caller that
+    passes True with check_small=False owns the check.
+    Sharded calls: every rank takes the SAME decision (one MAX all-reduce of the event flags), so no rank issues
+    collectives the others do not."""
     if check_small is None:
         check_small = fps_stream is None and not net_streams
+    if optimistic_graph is None:
+        optimistic_graph = bool(check_small)
     if check_small and hasattr(net, "reset_small_cloud_events"):
         net.reset_small_cloud_events()
     be = operations.BACKEND
-    if check_small and hasattr(be, "graph_dup_events"):
+    has_events = hasattr(be, "graph_dup_events")
+    if check_small and has_events:
         be.graph_dup_events(reset=True)
-    out = _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
-                    net_streams, sub_batch, fps_offset)
-    if check_small and hasattr(be, "graph_dup_events") and be.graph_dup_events(reset=True):
-        # an optimistic feature-space kNN graph met (possibly) duplicated rows: recompute with the exact form
-        saved = be.optimistic_graph
-        be.optimistic_graph = False
+    n_timing = len(timing) if timing is not None else 0
+
+    def run(optimistic):
+        saved = getattr(be, "optimistic_graph", None)
+        if saved is not None:
+            be.optimistic_graph = bool(optimistic)
         try:
-            out = _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
-                            net_streams, sub_batch, fps_offset)
+            return _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
+                             net_streams, sub_batch, fps_offset)
         finally:
-            be.optimistic_graph = saved
+            if saved is not None:
+                be.optimistic_graph = saved
+
+    out = run(optimistic_graph)
+    sharded = shard is not None
+    if check_small and optimistic_graph and has_events:
+        hit = bool(be.graph_dup_events(reset=True))
+        if _any_rank(hit, clouds.device) if sharded else hit:
+            # an optimistic feature-space kNN graph met (possibly) duplicated rows: recompute with the exact form
+            if timing is not None:
+                del timing[n_timing:]                   # the first pass's events are not this call's result
+            out = run(False)
     if check_small and hasattr(net, "small_cloud_events"):
         bad = net.small_cloud_events
-        if bad:
-            raise RuntimeError("%d cloud/level pairs were smaller than num_point=%d after the outlier filter; "
-                               "the batched pipeline does not cover that case (use a smaller --num_point)"
-                               % (bad, num_point))
+        if _any_rank(bad, clouds.device) if sharded else bad:
+            raise RuntimeError("%d cloud/level pairs on this rank were smaller than num_point=%d after the outlier "
+                               "filter (NaN / Inf coordinates, or every point duplicated?); the batched pipeline does "
+                               "not cover that case" % (bad, num_point))
     return out
 
 

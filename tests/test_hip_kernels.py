@@ -242,6 +242,37 @@ def test_gather_backward(orc, dev, dtype, tol):
     np.testing.assert_allclose(gp.cpu().numpy(), orc.gather_bwd(g, idx, n), rtol=tol, atol=tol)
 
 
+def test_gather_backward_half(orc, dev):
+    """The __half scatter-add (a 16-bit add through a 32-bit CAS on the containing word; the reference
+    dispatches half too, sampling_cuda.cu:83-100).  Summation order is unspecified, so the collision case uses
+    small integers -- every partial sum is exactly representable in fp16, any order gives the same bits -- and
+    odd n / odd targets exercise both halves of a word and the word shared by two targets."""
+    sampling = pkg("sampling")
+    rng = np.random.default_rng(2)
+    b, c, n, m = 2, 3, 51, 600
+    g = rng.integers(-4, 5, size=(b, c, m)).astype(np.float16)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    gp = torch.zeros((b, c, n), dtype=torch.float16, device=dev)
+    out = sampling.gather_backward(b, c, n, m, _t(g, dev), _t(idx, dev), gp)
+    assert out.data_ptr() == gp.data_ptr()
+    ref = orc.gather_bwd(g.astype(np.float32), idx, n)
+    assert np.abs(ref).max() < 2048
+    np.testing.assert_array_equal(gp.cpu().numpy(), ref.astype(np.float16))
+    # no collisions: arbitrary fp16 values land unchanged, untouched targets stay zero
+    m2 = 37
+    idx2 = np.stack([rng.permutation(n)[:m2] for _ in range(b)]).astype(np.int32)
+    g2 = rng.standard_normal((b, c, m2)).astype(np.float16)
+    gp2 = torch.zeros((b, c, n), dtype=torch.float16, device=dev)
+    sampling.gather_backward(b, c, n, m2, _t(g2, dev), _t(idx2, dev), gp2)
+    np.testing.assert_array_equal(gp2.cpu().numpy(), orc.gather_bwd(g2.astype(np.float32), idx2, n).astype(np.float16))
+    # through autograd: GatherFunction with half features
+    ops = pkg("network.operations")
+    x = torch.from_numpy(rng.integers(-3, 4, size=(b, c, n)).astype(np.float16)).to(dev).requires_grad_(True)
+    y = ops.gather_points(x, _t(idx, dev))
+    y.backward(_t(g, dev))
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), ref.astype(np.float16))
+
+
 def test_gather_points_autograd(dev):
     ops = pkg("network.operations")
     torch.manual_seed(0)

@@ -12,6 +12,11 @@ from conftest import golden, pkg, sphere
 pytestmark = pytest.mark.gpu
 
 
+# measured on MI355X in round 3 (GPU run log in profiles/r03_parity.txt): thresholds = measured with <= 2x slack
+TH_NET16_SET = 0.90
+TH_NET16_CHAMFER = 1e-6
+
+
 def _net(dev):
     ups = pkg("network.upsampler")
     net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
@@ -61,24 +66,36 @@ def test_net_eval_on_device(orc, dev, ratio):
     elif ratio == 4:
         # rocBLAS sums in another order than the CPU BLAS the fixture came from: 1e-6-level
         # differences can re-order the level-2 FPS sequence, so compare as point SETS
-        assert _set_close(orc, y, ref) >= 0.97
-        assert float(orc.chamfer_loss(y, ref)) < 1e-4
+        frac, cd = _set_close(orc, y, ref), float(orc.chamfer_loss(y, ref))
+        print("net eval 4x on device vs reference fixture: set_close_1e-5 = %.4f, chamfer = %.3e" % (frac, cd))
+        assert frac >= 0.97 and cd < 1e-4
     else:
-        # 4 levels deep with random-init (non-contractive) weights the discrete choices (feature
-        # kNN, FPS resampling, patch seeds) diverge between ANY two GEMM summation orders, and from
-        # level 3 on the patches themselves differ; the clouds can then only agree statistically:
-        # nearest-neighbour distances to the reference's cloud well below the cloud's own spacing
-        # (measured: median 0.036 vs 0.082).  Exactness is pinned level by level elsewhere
-        # (test_level_forward_on_device, test_dense_edge_conv_fused_matches_unfused, CPU suite).
-        a = np.ascontiguousarray(y.transpose(0, 2, 1))
-        b = np.ascontiguousarray(ref.transpose(0, 2, 1))
-        d1, _, d2, _ = orc.nmdistance_fwd(a, b)
-        ds, _, _, _ = orc.nmdistance_fwd(b, np.ascontiguousarray(b[:, ::2]))
-        spacing = float(np.sqrt(np.median(ds[ds > 0])))
-        assert np.sqrt(np.median(d1)) < 0.6 * spacing and np.sqrt(np.median(d2)) < 0.6 * spacing
-        assert np.sqrt(np.percentile(d1, 99)) < 1.5 * spacing
+        # 16x: four levels of discrete choices (feature kNN, FPS resampling, patch seeds).  Every level is pinned
+        # on its own (test_level_teacher_forced_on_device: 1-5 one-ulp feature-graph flips per 12 480 queries);
+        # end to end the cloud is compared as a point SET and in Chamfer distance, with the measured numbers:
+        frac = _set_close(orc, y, ref)
+        cd = float(orc.chamfer_loss(y, ref))
+        print("net eval 16x on device vs reference fixture: set_close_1e-5 = %.4f, chamfer = %.3e" % (frac, cd))
+        assert frac >= TH_NET16_SET and cd < TH_NET16_CHAMFER
     if ratio == 2:
         assert float(orc.chamfer_loss(y, ref)) < 1e-10
+
+
+@pytest.mark.parametrize("ratio", [2, 4, 8])
+def test_net_eval_input_smaller_than_a_patch_on_device(orc, dev, ratio):
+    """300-point input: k = min(num_point, 312) = 300 in every re-patching (reference upsampler.py:120-128)."""
+    net = _net(dev)
+    g = golden("net_small.npz")
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["patch"]).to(dev), ratio=ratio).cpu().numpy()
+    ref = g["x%d" % ratio]
+    assert y.shape == ref.shape
+    assert int(net.small_cloud_events) == 0
+    if ratio == 2:
+        np.testing.assert_allclose(y, ref, rtol=0, atol=1e-5)
+    else:
+        assert _set_close(orc, y, ref) >= 0.97
+        assert float(orc.chamfer_loss(y, ref)) < 1e-6
 
 
 def _teacher(level):
@@ -428,12 +445,17 @@ def test_pipeline_recomputes_when_an_optimistic_graph_reports_duplicates(orc, de
     finally:
         del be.knn_graph
     assert True in calls and False in calls                  # optimistic first, exact on the recomputation
-    be.optimistic_graph = False
-    try:
-        ref = pipe.upsample(net, x, 312, 2, 3)
-    finally:
-        be.optimistic_graph = True
+    assert be.optimistic_graph is False                      # the backend's default is restored: exact form
+    ref = pipe.upsample(net, x, 312, 2, 3, optimistic_graph=False)
     assert torch.equal(out, ref)
+    # direct callers (no synchronisation point of their own) get the exact form without asking
+    calls.clear()
+    be.knn_graph = spy
+    try:
+        pipe.pc_prediction(net, x, 312, 2, 3)
+    finally:
+        del be.knn_graph
+    assert calls and not any(calls)
 
 
 def test_pipeline_concurrent_sub_batches_and_side_stream(orc, dev):
