@@ -24,6 +24,8 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
   cpu_baseline      config C1 in full on the host cores (oracle/cpu_baseline.py), per-stage times
   parity            config C1 through the HIP path and through the oracle-driven CPU path on the same cloud:
                     chamfer_vs_oracle, set_close_1e-5  ("Chamfer vs ref" half of the metric)
+  parity_c2         the metric's OWN configuration (C2, 16x, 5000 -> 80000) through the HIP path against the output of
+                    the reference's own Python driver for the same cloud and weights (tests/golden/c2_x16.npz)
   extras            latency_ms_1cloud, train_step_ms (C3: B = 32, ratio 16), chamfer_80k_ms, c5 (stress) ...
 """
 import argparse
@@ -573,6 +575,13 @@ def main():
             base, cpu_out = cpu_baseline.measure_c1()
             line["cpu_baseline"] = base
             line["parity"] = parity_block(ops, pipe, ups, dev, cpu_out)
+            try:
+                # the metric's own configuration against the reference-driven fixture (tests/golden/c2_x16.npz: data)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import test_c2_parity
+                line["parity_c2"] = test_c2_parity.c2_parity(dev)
+            except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
+                line["parity_c2"] = "failed: %s" % (str(e).splitlines()[0][:160])
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

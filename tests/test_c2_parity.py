@@ -102,12 +102,17 @@ def test_c2_end_to_end_against_the_reference_driver(dev):
     print("C2 parity: %r" % (r,))
     assert r["final_shape"] == [1, 3, 80000]
     assert r["outer_seeds_bit_exact"]
-    # measured on MI355X (round 3): see DESIGN section 2 for the table; thresholds = measured with <= 2x slack
-    assert r["merged_chamfer_vs_ref"] < 6e-5
-    assert r["merged_set_close_1e-5"] > 0.70
-    assert r["final_chamfer_vs_ref"] < 7e-4
-    assert r["final_chamfer_vs_ref"] < 0.6 * r["ref_output_spacing_sq_median"]
-    assert r["final_set_close_1e-5"] > 0.25
+    # Measured on MI355X (round 3, profiles/r03_parity.txt): merged (239 616 points before the final FPS) Chamfer
+    # 3.19e-5, 77.5 % of the points coincide with a reference point within 1e-5; final 80 000 points Chamfer 3.53e-4 =
+    # 0.51 x the squared point spacing (6.9e-4), 37.5 % coincide -- the final FPS picks one third of a cloud whose
+    # other points differ in a quarter of the positions, so its choices decorrelate.  The oracle-driven CPU path of
+    # the same host logic scores 2.60e-5 / 81.3 % / 3.44e-4 / 39.8 % against the same fixture: the distance is
+    # between ANY two fp32 evaluations of this pipeline, not between HIP and CPU.  Thresholds: measured, <= 2x slack.
+    assert r["merged_chamfer_vs_ref"] < 6.4e-5
+    assert r["merged_set_close_1e-5"] > 0.60
+    assert r["final_chamfer_vs_ref"] < 7.0e-4
+    assert r["final_chamfer_vs_ref"] < 1.0 * r["ref_output_spacing_sq_median"]
+    assert r["final_set_close_1e-5"] > 0.30
 
 
 def test_c1_hip_path_against_the_oracle_driven_path(dev):
