@@ -36,6 +36,9 @@
 // Summation order differs from a BLAS GEMM (documented tolerance 1e-5 on the network outputs).
 #include "tpu3_dev.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -75,6 +78,21 @@ __device__ __forceinline__ float dec_relu(float v)
 {
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// running maximum as ONE v_max_f32 (fmaxf() canonicalises both operands first: three instructions)
+__device__ __forceinline__ float dec_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float dec_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -430,6 +448,357 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 flavour, second form (round 3): a LANE per point, v_mfma_f32_4x4x1_16b_f32.
+//
+// The 16x16x4 form above pays for padding twice: 12 output channels occupy 16 MFMA rows and the 12 hidden
+// channels 16 k slots (4 lane groups x 4 steps, one group idle) -- 56 % of the executed FLOPs of an edge are
+// useful.  v_mfma_f32_4x4x1 computes 16 independent 4x4 outer products per instruction at the same FLOP rate
+// (512 FLOP in 8 cycles): block b = lanes 4b..4b+3, A_b[i] from lane 4b+i, B_b[j] from lane 4b+j, lane 4b+j
+// receives column j of its block's 4x4 result.  With
+//     B = channel k of the LANE'S OWN (point, slot) pair,     A = W[4 rg + (lane & 3)][k]  (the same in every block),
+// one instruction adds the contribution of input channel k to output channels 4rg..4rg+3 of 64 pairs: 3 row
+// groups x K instructions per layer, NO padding anywhere (layer 1: 36, layer 2: 72 instructions of 8 cycles per
+// 64 edges = 13.5 cycles per edge against 24 of the 16x16x4 form), and everything an edge needs and produces is
+// lane-local: its input is the lane's own registers, the running maximum over the k slots is per lane, no
+// shuffles, no LDS hand-offs, no DPP.  108 distinct A operands would not fit the register file as one VGPR each, and
+// need not: the instruction's A-BROADCAST control (cbsz = 4, abid = b) takes the four A values of block b and uses
+// them for all 16 blocks, so ONE VGPR carries 16 different (row group, k) operands -- lane 4b + i holds
+// W[4 rg_b + i][k_b] -- and the 108 operands of both edge layers live in 7 registers, selected per instruction by
+// an immediate.  (A first version read them from LDS, 27 ds_read_b128 per slot: 0.71 ms per launch, slower than the
+// 16x16x4 form, every MFMA group waiting on its read.)  The per-POINT products (centre terms, z table) are 6 % of
+// the work and read their operands from a 6 KB LDS table.
+// The sums run over k in ascending order: one fp32 fma chain per output, i.e. the plain dot-product order.
+// W2c x_i + b2 does not depend on the slot and the last layer has no ReLU, so it is added to the maximum at
+// the end (max_j (c + v_j) = c + max_j v_j; the rounding of the sum differs by one ulp from seeding the chain).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DEC4_MAXW = 8;                 // waves per workgroup (at most)
+// LDS tables of A operands, float4 entries [rg][kq][lane & 3] = W[4 rg + i][4 kq .. 4 kq + 3]
+constexpr int DEC4_T_W1A = 0;                // 3 x 3 x 4   W1[:, 0:12]            (h0 -> h1)
+constexpr int DEC4_T_W2 = 36;                // 3 x 6 x 4   W2[:, 0:24]            ([h1 | h0] -> h2)
+constexpr int DEC4_T_C0 = 108;               // 3 x 6 x 4   W0[:, 0:24] - W0[:, 24:48]   (x_i -> centre of layer 0)
+constexpr int DEC4_T_C1 = 180;               // 3 x 6 x 4   W1[:, 12:36]           (x_i -> centre of layer 1)
+constexpr int DEC4_T_C2 = 252;               // 3 x 6 x 4   W2[:, 24:48]           (x_i -> centre of layer 2)
+constexpr int DEC4_T_Z = 324;                // 3 x 6 x 4   W0[:, 24:48]           (x_j -> z table)
+constexpr int DEC4_T_END = 396;              // float4 entries; then the biases [3][12] (+ 12 pad), then the z table
+constexpr int DEC4_BIAS = DEC4_T_END * 4;    // float offset
+constexpr int DEC4_ZTAB = DEC4_BIAS + 48;    // float offset
+
+__device__ __forceinline__ f32x4 mfma411(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void dec4_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dec4_static_for<I + 1, N>(f);
+    }
+}
+
+// operand Q of the packed edge-layer weights: register Q / 16, block Q % 16 broadcast to all blocks
+template <int Q>
+__device__ __forceinline__ f32x4 mfma411_bc(const float (&wp)[7], float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(wp[Q / 16], b, c, 4, Q % 16, 0);
+}
+
+// acc[rg] += W[4 rg .. 4 rg + 3][4 kq .. 4 kq + 3] in[0..3]  for the three row groups (tab = table + kq block)
+template <int KQ>
+__device__ __forceinline__ void dec4_step(const f32x4 *tab, int li, int kq, float i0, float i1, float i2, float i3,
+                                          f32x4 (&acc)[3])
+{
+    const f32x4 a0 = tab[(0 * KQ + kq) * 4 + li], a1 = tab[(1 * KQ + kq) * 4 + li], a2 = tab[(2 * KQ + kq) * 4 + li];
+    acc[0] = mfma411(a0[0], i0, acc[0]); acc[1] = mfma411(a1[0], i0, acc[1]); acc[2] = mfma411(a2[0], i0, acc[2]);
+    acc[0] = mfma411(a0[1], i1, acc[0]); acc[1] = mfma411(a1[1], i1, acc[1]); acc[2] = mfma411(a2[1], i1, acc[2]);
+    acc[0] = mfma411(a0[2], i2, acc[0]); acc[1] = mfma411(a1[2], i2, acc[1]); acc[2] = mfma411(a2[2], i2, acc[2]);
+    acc[0] = mfma411(a0[3], i3, acc[0]); acc[1] = mfma411(a1[3], i3, acc[1]); acc[2] = mfma411(a2[3], i3, acc[2]);
+}
+
+// 12 outputs of a 24-channel input row held in six float4 registers
+__device__ __forceinline__ void dec4_mm24(const f32x4 *tab, int li, const f32x4 (&x)[6], f32x4 (&acc)[3])
+{
+#pragma unroll
+    for (int kq = 0; kq < 6; ++kq)
+        dec4_step<6>(tab, li, kq, x[kq][0], x[kq][1], x[kq][2], x[kq][3], acc);
+}
+
+// The workgroup's operand tables, built in LDS from the raw weights: the 1620 weight and bias floats are first
+// copied into LDS with coalesced loads (ONE global round trip; `raw` may alias the z table, which is written later),
+// then re-arranged LDS -> LDS.  (Gathering the table entries straight from the weight matrices cost 20 us of
+// dependent global loads per workgroup; a per-launch blob built by a one-block kernel needs a stream-ordered
+// allocation per call, which serialised the eight network streams of the bench: 341 vs 311 ms per step.)
+constexpr int DEC4_RAW_W0 = 0, DEC4_RAW_W1 = 576, DEC4_RAW_W2 = 1008, DEC4_RAW_B = 1584, DEC4_RAW_FLOATS = 1620;
+
+__device__ __forceinline__ void dec4_setup(const DecArgs &a, float *lds, float *raw, float (&wp)[7])
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < DEC4_RAW_FLOATS; t += blockDim.x)
+        raw[t] = t < DEC4_RAW_W1 ? a.w0[t] : t < DEC4_RAW_W2 ? a.w1[t - DEC4_RAW_W1]
+               : t < DEC4_RAW_B ? a.w2[t - DEC4_RAW_W2]
+               : (t < DEC4_RAW_B + 12 ? a.b0 : t < DEC4_RAW_B + 24 ? a.b1 : a.b2)[(t - DEC4_RAW_B) % 12];
+    __syncthreads();
+    const float *w0 = raw + DEC4_RAW_W0, *w1 = raw + DEC4_RAW_W1, *w2 = raw + DEC4_RAW_W2;
+    // table entry e = (rg, kq, i): row 4 rg + i, columns 4 kq .. 4 kq + 3 of the table's matrix slice
+    for (int e = tid; e < DEC4_T_END; e += blockDim.x) {
+        const int base = e < DEC4_T_W2 ? DEC4_T_W1A : DEC4_T_W2 + (e - DEC4_T_W2) / 72 * 72;
+        const int KQ = e < DEC4_T_W2 ? 3 : 6;
+        const int r = e - base, i = r & 3, kq = (r >> 2) % KQ, rg = (r >> 2) / KQ;
+        const int row = 4 * rg + i, c = 4 * kq;
+        // source matrix, row length, first column, and (layer-0 centre term only) the column block to subtract
+        const float *src;
+        int ld, col, sub = -1;
+        if (base == DEC4_T_W1A) { src = w1; ld = 36; col = 0; }
+        else if (base == DEC4_T_W2) { src = w2; ld = 48; col = 0; }
+        else if (base == DEC4_T_C0) { src = w0; ld = 48; col = 0; sub = 24; }
+        else if (base == DEC4_T_C1) { src = w1; ld = 36; col = 12; }
+        else if (base == DEC4_T_C2) { src = w2; ld = 48; col = 24; }
+        else { src = w0; ld = 48; col = 24; }
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float w = src[row * ld + col + c + q];
+            v[q] = sub >= 0 ? w - src[row * ld + sub + c + q] : w;
+        }
+        ((f32x4 *)lds)[e] = v;
+    }
+    if (tid < 48)
+        lds[DEC4_BIAS + tid] = tid < 36 ? raw[DEC4_RAW_B + tid] : 0.f;
+    // packed A operands of the two edge layers: operand q < 36: (rg, k) = (q / 12, q % 12) of W1[:, 0:12];
+    // 36 <= q < 108: (rg, k) = ((q - 36) / 24, (q - 36) % 24) of W2[:, 0:24]; lane 4b + i of register v holds
+    // operand q = 16 v + b for row 4 rg + i
+#pragma unroll
+    for (int v = 0; v < 7; ++v) {
+        const int q = 16 * v + (lane >> 2), i = lane & 3;
+        float w = 0.f;
+        if (q < 36)
+            w = w1[(4 * (q / 12) + i) * 36 + q % 12];
+        else if (q < 108)
+            w = w2[(4 * ((q - 36) / 24) + i) * 48 + (q - 36) % 24];
+        wp[v] = w;
+    }
+    __syncthreads();            // `raw` may be overwritten from here on
+}
+
+// U = neighbour slots per loop iteration.  U = 2 folds two slots into one v_max3 per channel (18 instead of 36
+// running-maximum instructions per slot) at the price of 36 more live registers (3 instead of 4 waves per SIMD).
+template <bool IDX64, int U>
+__global__ __launch_bounds__(DEC4_MAXW * 64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 4 : 3, U == 1 ? 4 : 3)))
+void dec_fused4_kernel(DecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int li = lane & 3;
+    const int n = a.n, k = a.k;
+    const float *X = a.x + (size_t)blockIdx.x * n * DEC_C;
+    float *O = a.out + (size_t)blockIdx.x * n * a.out_stride;
+    f32x4 *tab = (f32x4 *)lds;
+    float *bias = lds + DEC4_BIAS;
+    float *zl = lds + DEC4_ZTAB;                 // z_p  = W0b x_p            (n x 12)
+    float *c2l = zl + (size_t)n * DEC_ZS;        // c2_p = W2c x_p + b2       (n x 12)
+
+    float wp[7];
+    dec4_setup(a, lds, zl, wp);
+
+    const int nstep = (n + 63) >> 6;
+    // ---- phase A, per point (lane = point): the z table and the slot-independent part of the last layer into LDS,
+    // the x_i part of the output row straight from the registers.  The wave's steps are walked LAST FIRST, so the
+    // input rows of its first step are still in registers when phase B starts.
+    f32x4 x[6];
+    {
+        int st = wave;
+        while (st + nwave < nstep)
+            st += nwave;
+        for (; st >= 0; st -= nwave) {
+            int tofs = 0;                       // (opaque zero: keeps the A-operand reads inside the loop, see phase B)
+            asm volatile("" : "+v"(tofs));
+            const f32x4 *tabs = tab + tofs;
+            const int p = st * 64 + lane;
+            const f32x4 *xr = (const f32x4 *)(X + (size_t)min(p, n - 1) * DEC_C);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                x[q] = xr[q];
+            f32x4 z[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, c2[3];
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                c2[rg] = *(const f32x4 *)(bias + 24 + 4 * rg);
+            dec4_mm24(tabs + DEC4_T_Z, li, x, z);
+            dec4_mm24(tabs + DEC4_T_C2, li, x, c2);
+            if (p < n) {
+                f32x4 *zr = (f32x4 *)(zl + p * DEC_ZS), *cr = (f32x4 *)(c2l + p * DEC_ZS);
+                zr[0] = z[0]; zr[1] = z[1]; zr[2] = z[2];
+                cr[0] = c2[0]; cr[1] = c2[1]; cr[2] = c2[2];
+                f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);       // [36, 60): one 96-byte run
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    orow[9 + q] = x[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: the wave's 64-point steps ---------------------------------------------------------------------
+    for (int st = wave; st < nstep; st += nwave) {
+        // (opaque zero: keeps the table reads of this step inside the loop -- hoisted, the loop-invariant A operands of
+        // the centre terms would occupy 144 registers)
+        int tofs = 0;
+        asm volatile("" : "+v"(tofs));
+        const f32x4 *tabs = tab + tofs;
+        const int p = st * 64 + lane;
+        const int pc = min(p, n - 1);
+        if (st != wave) {
+            const f32x4 *xr = (const f32x4 *)(X + (size_t)pc * DEC_C);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                x[q] = xr[q];
+        }
+        f32x4 c0[3], c1[3];
+#pragma unroll
+        for (int rg = 0; rg < 3; ++rg) {
+            c0[rg] = *(const f32x4 *)(bias + 4 * rg);
+            c1[rg] = *(const f32x4 *)(bias + 12 + 4 * rg);
+        }
+        dec4_mm24(tabs + DEC4_T_C0, li, x, c0);
+        dec4_mm24(tabs + DEC4_T_C1, li, x, c1);
+        // neighbour slots; index and z row of the following slots are requested before this iteration's MFMAs
+        const size_t ibase = ((size_t)blockIdx.x * n + pc) * a.idx_stride + a.idx_off;
+        const int zmax = (n - 1) * (int)(DEC_ZS * sizeof(float));
+        auto nbr = [&](int s) __attribute__((always_inline)) {     // byte offset of the neighbour's z row
+            const int j = IDX64 ? (int)((const long long *)a.idx)[ibase + s] : ((const int *)a.idx)[ibase + s];
+            return min(max(j * (int)(DEC_ZS * sizeof(float)), 0), zmax);
+        };
+        const char *zb = (const char *)zl;
+        const float ninf = -__builtin_inff();
+        f32x4 m0[3], m1[3], m2[3];
+#pragma unroll
+        for (int rg = 0; rg < 3; ++rg)
+            m0[rg] = m1[rg] = m2[rg] = (f32x4){ninf, ninf, ninf, ninf};
+        int jn[U];
+        f32x4 zn[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4 *zr = (const f32x4 *)(zb + nbr(min(u, k - 1)));
+            zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
+            jn[u] = nbr(min(U + u, k - 1));
+        }
+#pragma unroll 1
+        for (int s = 0; s < k; s += U) {
+            f32x4 h0[U][3], h1[U][3], h2[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg) {
+                    const f32x4 pre = c0[rg] + zn[u][rg];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h0[u][rg][r] = dec_relu(pre[r]);
+                }
+            // requests for the following iteration (clamped at the end: a repeated slot is harmless)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 *zr = (const f32x4 *)(zb + jn[u]);
+                zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
+                jn[u] = nbr(min(s + 2 * U + u, k - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg)
+                    h1[u][rg] = c1[rg];
+            // layer 1: input channel kk of h0; the row groups (and slots) are independent accumulator chains
+            dec4_static_for<0, 12>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kc)::value;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float b = h0[u][kk / 4][kk % 4];
+                    h1[u][0] = mfma411_bc<0 * 12 + kk>(wp, b, h1[u][0]);
+                    h1[u][1] = mfma411_bc<1 * 12 + kk>(wp, b, h1[u][1]);
+                    h1[u][2] = mfma411_bc<2 * 12 + kk>(wp, b, h1[u][2]);
+                }
+            });
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h1[u][rg][r] = dec_relu(h1[u][rg][r]);
+                    h2[u][rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            // layer 2: [h1 | h0]
+            dec4_static_for<0, 24>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kc)::value;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float b = kk < 12 ? h1[u][(kk % 12) / 4][kk % 4] : h0[u][(kk % 12) / 4][kk % 4];
+                    h2[u][0] = mfma411_bc<36 + 0 * 24 + kk>(wp, b, h2[u][0]);
+                    h2[u][1] = mfma411_bc<36 + 1 * 24 + kk>(wp, b, h2[u][1]);
+                    h2[u][2] = mfma411_bc<36 + 2 * 24 + kk>(wp, b, h2[u][2]);
+                }
+            });
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (U == 2) {
+                        m0[rg][r] = dec_max3(m0[rg][r], h0[0][rg][r], h0[1][rg][r]);
+                        m1[rg][r] = dec_max3(m1[rg][r], h1[0][rg][r], h1[1][rg][r]);
+                        m2[rg][r] = dec_max3(m2[rg][r], h2[0][rg][r], h2[1][rg][r]);
+                    } else {
+                        m0[rg][r] = dec_max(m0[rg][r], h0[0][rg][r]);
+                        m1[rg][r] = dec_max(m1[rg][r], h1[0][rg][r]);
+                        m2[rg][r] = dec_max(m2[rg][r], h2[0][rg][r]);
+                    }
+                }
+        }
+        // ---- write-out: [max h2 + c2 | max h1 | max h0] = floats [0, 36) of the lane's own row, nine back-to-back
+        // 16-byte stores (staging 16 rows at a time through LDS so that 15 consecutive lanes write one row was
+        // measured: no faster, and the tile costs the LDS of another workgroup per compute unit)
+        if (p < n) {
+            const f32x4 *cr = (const f32x4 *)(c2l + p * DEC_ZS);
+            f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                orow[rg] = m2[rg] + cr[rg];
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                orow[3 + rg] = m1[rg];
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                orow[6 + rg] = m0[rg];
+        }
+    }
+}
+
+constexpr size_t dec4_lds_bytes(int n)
+{
+    const size_t tables = 2 * (size_t)n * DEC_ZS + 4;          // z and c2 tables; the raw weights alias them during setup
+    return ((size_t)DEC4_ZTAB + (tables > (size_t)DEC4_RAW_FLOATS ? tables : (size_t)DEC4_RAW_FLOATS)) * sizeof(float);
+}
+
+int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
+{
+    // FOUR waves per workgroup, the 64-point steps dealt round-robin: with a wave per step a 312-point patch is
+    // 5 waves on 4 SIMDs -- two of them share a SIMD, run at half speed and hold the workgroup's LDS and register
+    // slots while three SIMDs wait.  With four, the wave that takes two steps runs alone on its SIMD as long as the
+    // others, and the slots of the finished ones go to the next workgroup.  TPU3_DEC_NW / TPU3_DEC_U: tuning hooks.
+    static const int nw_env = getenv("TPU3_DEC_NW") ? atoi(getenv("TPU3_DEC_NW")) : 4;
+    static const int u_env = getenv("TPU3_DEC_U") ? atoi(getenv("TPU3_DEC_U")) : 1;
+    const int nw = min(min(DEC4_MAXW, max(1, nw_env)), (a.n + 63) / 64);
+    const size_t lds = dec4_lds_bytes(a.n);
+    const bool u2 = u_env == 2 && (a.k % 2) == 0;
+    void (*kern)(DecArgs) =
+        a.idx64 ? (u2 ? dec_fused4_kernel<true, 2> : dec_fused4_kernel<true, 1>)
+                : (u2 ? dec_fused4_kernel<false, 2> : dec_fused4_kernel<false, 1>);
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+        return (int)e;
+    hipLaunchKernelGGL(kern, dim3(patches), dim3(nw * 64), lds, s, a);
+    return tpu3_launch_status();
+}
+
 constexpr size_t DEC_LDS_TILE_BYTES = ((size_t)DEC_NW * 16 * DEC_TS + 48) * sizeof(float);    // tiles + bias table
 
 template <bool F16>
@@ -484,5 +853,12 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (patches > 65535 * 0 + 2147483647 / (n > 0 ? n : 1)) return TPU3_ELIMIT;       // patches * n must fit an int
     DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr};
     hipStream_t s = (hipStream_t)stream;
-    return mfma == TPU3_MFMA_F16 ? dec_launch<true>(s, patches, a) : dec_launch<false>(s, patches, a);
+    if (mfma == TPU3_MFMA_F16)
+        return dec_launch<true>(s, patches, a);
+    // fp32: the lane-per-point 4x4x1 form whenever the patch's z table fits LDS (n <= ~3270 points); larger patches
+    // take the 16x16x4 form with the table in global memory.  TPU3_DEC_FORM=16 (tuning hook) forces the latter.
+    static const int form = getenv("TPU3_DEC_FORM") ? atoi(getenv("TPU3_DEC_FORM")) : 4;
+    if (form == 4 && dec4_lds_bytes(n) <= 160 * 1024)
+        return dec4_launch(s, patches, a);
+    return dec_launch<false>(s, patches, a);
 }

@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 # measured on MI355X in round 3 (GPU run log in profiles/r03_parity.txt): thresholds = measured with <= 2x slack
-# net eval 16x of one patch vs the reference fixture: measured set_close 0.9984 (8 of 4992 points off), Chamfer 2.3e-10
+# net eval 16x of one patch vs the reference fixture: measured set_close 0.9998 (1 of 4992 points off), Chamfer 3.9e-10
+# (0.9984 / 2.3e-10 with round 2's DenseEdgeConv kernel; the oracle-driven CPU path scores 0.9998 / 3.9e-10 too)
 TH_NET16_SET = 0.9968
-TH_NET16_CHAMFER = 5e-10
+TH_NET16_CHAMFER = 8e-10
 
 
 def _net(dev):
@@ -152,12 +153,14 @@ def test_level_teacher_forced_on_device(dev, level, monkeypatch):
           "inter-level sets flipped: %d of %d; feature graphs flipped per block: %s of %d"
           % (level, frac, err.size, bad_patches, P, flips, total, gflips, total))
     assert flips == 0, (flips, total)
-    # measured (MI355X, rounds 2 and 3; identical on the CPU stand-in): level 3 -- no flip, every point within 1e-5;
-    # level 4 -- 1 / 1 / 1 / 5 of 12 480 queries per block, 2 of 40 patches touched, 0.9923 of the points within 1e-5
-    measured = {3: ([0, 0, 0, 0], 0, 1.0), 4: ([1, 1, 1, 5], 2, 0.9923)}[level]
+    # measured (MI355X, round 3, lane-per-point DenseEdgeConv: plain ascending-k fma chains): level 3 -- one flip in
+    # block 4 (none with round 2's 16x16x4 kernel, whose chains ran in another order: the flips ARE summation-order
+    # noise), 0.9998 of the points within 1e-5; level 4 -- 1 / 1 / 1 / 5 of 12 480 queries per block, 2 of 40 patches
+    # touched, 0.9923 of the points within 1e-5
+    measured = {3: ([0, 0, 0, 1], 1, 0.9998), 4: ([1, 1, 1, 5], 2, 0.9923)}[level]
     assert all(f <= m + 1 for f, m in zip(gflips, measured[0])), gflips            # exact flip counts + 1
     assert bad_patches <= min(sum(gflips), measured[1] + 1), (bad_patches, gflips)  # a patch without a flip is exact
-    assert frac >= (1.0 if level == 3 else 0.99), frac
+    assert frac >= (0.999 if level == 3 else 0.99), frac
 
 
 @pytest.mark.parametrize("level", [3, 4])
