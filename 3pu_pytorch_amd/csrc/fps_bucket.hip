@@ -801,78 +801,85 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
     for (int round = 0;; ++round) {
         apply(J);
         // ---- select the next samples ---------------------------------------------------------------
-        const int par = round & 1;                  // double-buffered hand-off areas
+        // (r3) With a FRESH bound.  Until round 2 the candidates were picked against the R* of the PREVIOUS round
+        // (the waves' runner-up maxima travelled through the same barrier as their candidates): valid -- bounds only
+        // fall -- but the groups sampled in a round are exactly those whose runner-up was about to become their
+        // maximum, so the stale bound sat just above the next candidates: 8.0 samples per round against 13-17 with
+        // the fresh one (simulation on the metric's merged cloud, tools/fps_cells_sim.py).  Now every wave reads
+        // ALL group entries after one barrier (8 per lane), derives R*, the candidate set and its order itself: no
+        // per-wave candidate quota, no second hand-off.
         unsigned long long s0 = 0, s1 = 0;
         if (PROF) s0 = now();
-        gmax = g_max[tid];
-        const uint32_t gk = g_key[tid];
-        const int gr = g_r[tid];
-        uint32_t *cl = cand + par * (FM_CAP * FM_EW);
-        {
-            int wlane;
-            const int wmax = tpu3_wave_argmax(gmax, gk, wlane);
-            const int wr = tpu3_wave_max_i32_fast(gr);
-            // candidates: groups whose best beats every runner-up bound (rstar is one round old: bounds only fall)
-            bool is_cand = gmax > rstar;
-            unsigned long long cm = __ballot(is_cand);
-            int drop = (int)0x80000000;
-            if (__builtin_popcountll(cm) > WCAP) {
-                // keep the wave's FM_WCAP best; the best one left out limits what may be accepted this round
-                int lrank = 0;
-                for (unsigned long long mm = cm; mm;) {
-                    const int i = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const int mi = __builtin_amdgcn_readlane(gmax, i);
-                    const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)gk, i);
-                    lrank += (mi > gmax || (mi == gmax && ki < gk)) ? 1 : 0;
+        __syncthreads();                                                    // every wave's group entries are final
+        if (PROF) { s1 = now(); pc[5] += s1 - s0; s0 = s1; }
+        gmax = g_max[tid];                                                  // own group: the prune test of apply()
+        int gm[NW];
+        int rs = (int)0x80000000;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            gm[i] = g_max[i * 64 + lane];
+            rs = max(rs, g_r[i * 64 + lane]);
+        }
+        rstar = tpu3_wave_max_i32_fast(rs);
+        // candidates: groups whose best beats every group's runner-up bound, at most FM_CAP of them (a sample mask is
+        // 32 bits).  More than that qualify in a quarter of the rounds: the threshold is then raised -- any threshold
+        // >= R* is valid, the groups left out are all below the ones entered -- by a few bisection steps between R*
+        // and the largest maximum.
+        auto count_above = [&](int thr) __attribute__((always_inline)) {
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                c += __builtin_popcountll(__ballot(gm[i] > thr));
+            return c;
+        };
+        int thr = rstar;
+        int total = count_above(thr);
+        if (total > FM_CAP) {
+            int mx = gm[0];
+#pragma unroll
+            for (int i = 1; i < NW; ++i)
+                mx = max(mx, gm[i]);
+            int lo = thr, hi = tpu3_wave_max_i32_fast(mx), chi = 0;        // count(lo) > FM_CAP >= count(hi) = chi
+            for (int it = 0; it < 6 && hi - lo > 1; ++it) {
+                const int mid = lo + ((hi - lo) >> 1);
+                const int c = count_above(mid);
+                if (c > FM_CAP) {
+                    lo = mid;
+                } else {
+                    hi = mid; chi = c;
                 }
-                const bool keep = is_cand && lrank < WCAP;
-                drop = tpu3_wave_max_i32_fast(is_cand && !keep ? gmax : (int)0x80000000);
-                is_cand = keep;
-                cm = __ballot(is_cand);
             }
-            if (is_cand) {
-                const int pos = wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
-                uint32_t *e = cl + pos * FM_EW;
-                e[0] = (uint32_t)gmax; e[1] = gk;
-                e[2] = __float_as_uint(g_x[tid]); e[3] = __float_as_uint(g_y[tid]); e[4] = __float_as_uint(g_z[tid]);
-            }
-            if (lane == wlane) {
-                FmHeader &h = sh.h[par][wave];
-                h.best = wmax; h.key = gk; h.x = g_x[tid]; h.y = g_y[tid]; h.z = g_z[tid];
-                h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
+            thr = hi; total = chi;
+            if (PROF && tid == 0) sh.stat[2] += 1;
+        }
+        uint32_t *cl = cand + wave * FM_CAP;                                // entry numbers of the candidates, entry order
+        {
+            int base = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const bool c = gm[i] > thr;
+                const unsigned long long cm = __ballot(c);
+                if (c)
+                    cl[base + __builtin_popcountll(cm & ((1ull << lane) - 1ull))] = (uint32_t)(i * 64 + lane);
+                base += __builtin_popcountll(cm);
             }
         }
         if (PROF) { s1 = now(); pc[4] += s1 - s0; s0 = s1; }
-        __syncthreads();                                                    // the round's ONE barrier
-        if (PROF) { s1 = now(); pc[5] += s1 - s0; s0 = s1; }
-        const FmHeader &hh = sh.h[par][lane & (NW - 1)];
-        const int sd = lane < NW ? hh.best : (int)0x80000000;
-        const uint32_t sk = lane < NW ? hh.key : 0xFFFFFFFFu;
-        const int sr = lane < NW ? hh.rmax : (int)0x80000000;
-        const int sdrop = lane < NW ? hh.drop : (int)0x80000000;
-        const float sx = hh.x, sy = hh.y, sz = hh.z;
-        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-        rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
-        const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
-        // candidate `lane` of the list: wave lane / FM_WCAP, entry lane % FM_WCAP
-        const int cw = (lane / WCAP) & (NW - 1);
-        const bool live = lane < FM_CAP && (lane % WCAP) < sh.h[par][cw].count;
+        const bool live = lane < total;
         const unsigned long long lm = __ballot(live);
-        const int total = __builtin_popcountll(lm);
         const int left = a.m - r;
         uint32_t okey;                              // tie key of sample `lane` of this round (lanes < J)
-        bool multi = total >= 2;
+        bool multi = total >= 1;                    // (a single candidate is the unique global maximum)
         int cM = (int)0x80000000;
         uint32_t cK = 0xFFFFFFFFu;
         float cx = 0.f, cy = 0.f, cz = 0.f;
         int rank = 0;
         if (multi) {
             // every wave ranks the candidate list on its own (no further synchronisation)
-            const uint32_t *e = cl + (lane & (FM_CAP - 1)) * FM_EW;
             if (live) {
-                cM = (int)e[0]; cK = e[1];
-                cx = __uint_as_float(e[2]); cy = __uint_as_float(e[3]); cz = __uint_as_float(e[4]);
+                const int e = (int)cl[lane];
+                cM = g_max[e]; cK = g_key[e];
+                cx = g_x[e]; cy = g_y[e]; cz = g_z[e];
             }
             bool tie = false;
             for (unsigned long long mm = lm; mm;) {
@@ -896,18 +903,23 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             }
         }
         if (!multi) {
-            // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
-            unsigned long long who = __ballot(lane < NW && sd == gbest);
-            if (__builtin_popcountll(who) != 1) {
-                const uint32_t rk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
-                const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)rk, 0);
-                who = __ballot(lane < NW && sd == gbest && sk == win);
+            // no group beats R* (ties at the top: duplicated points): the plain arg-max over all groups with the
+            // reference's tie rule -- the lane's best entry first, then across the wave
+            int bm = gm[0], be = lane;
+            uint32_t bk = g_key[lane];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) {
+                const uint32_t ki = g_key[i * 64 + lane];
+                if (gm[i] > bm || (gm[i] == bm && ki < bk)) {
+                    bm = gm[i]; bk = ki; be = i * 64 + lane;
+                }
             }
-            const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
-            px = rl(sx, ww); py = rl(sy, ww); pz = rl(sz, ww);
-            okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
+            int wl_;
+            (void)tpu3_wave_argmax(bm, bk, wl_);
+            const int we = __builtin_amdgcn_readlane(be, wl_);
+            px = g_x[we]; py = g_y[we]; pz = g_z[we];
+            okey = g_key[we];
             J = 1;
-            if (PROF && tid == 0 && total >= 2) sh.stat[3] += 1;
         } else {
             // into rank order: lane `rank` receives this candidate (dead lanes keep to themselves, behind)
             const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
@@ -916,11 +928,7 @@ __global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
             px = perm(cx); py = perm(cy); pz = perm(cz);
             okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
             const int sM = __builtin_amdgcn_ds_permute(dst, cM);
-            // candidates below the best one a wave had to leave out cannot be accepted
-            int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
-            if (PROF && tid == 0 && jmax < total) sh.stat[2] += 1;
-            jmax = jmax < 1 ? 1 : jmax;
-            jmax = jmax < left ? jmax : left;
+            int jmax = total < left ? total : left;
             // longest prefix in which no member's best point lies inside the update ball of an earlier member
             // (then that point keeps its distance, and every other point of its cell can only fall)
             for (int i = 0; i + 1 < jmax; ++i) {
