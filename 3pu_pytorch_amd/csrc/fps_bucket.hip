@@ -1162,6 +1162,10 @@ struct RlShared {
     uint32_t cand[2][RL_CAP * RL_EW];
     float pick[2][RL_CAP][4];
     int npick[2];
+    uint32_t pkey[2][RL_CAP];       // tie keys of the picks (rank order)
+    int mrow[RL_CAP];               // the candidates' maxima, compact (wave 0's ranking reads them back as broadcasts)
+    int ncand[2];                   // candidates appended this round (may exceed RL_CAP: the surplus is not stored ...)
+    int drop[2];                    // ... and the best of the surplus caps what may be accepted
 };
 
 constexpr size_t rl_lds_bytes(int r, bool zl)
@@ -1172,7 +1176,7 @@ constexpr size_t rl_lds_bytes(int r, bool zl)
 template <int R, bool PROF = false>
 __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
 {
-    constexpr int NW = 16, WCAP = RL_CAP / NW;
+    constexpr int NW = 16;
     constexpr bool ZL = rl_zl<R>();
     auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2
@@ -1264,6 +1268,10 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
         lmax = best; lrun = run; larg = arg; lbx = bx; lby = by; lbz = bz;
     };
     lane_scan();
+    if (tid < 2) {
+        sh.ncand[tid] = 0;
+        sh.drop[tid] = (int)0x80000000;
+    }
     __syncthreads();
     // the wave's box (uniform) and an upper bound of its lanes' maxima: a sample is first tested against these --
     // all samples of the round in ONE evaluation, a lane per sample -- and only the few that may reach the wave
@@ -1323,53 +1331,59 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
             apply(J);
             if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
             // ---- select the next samples -------------------------------------------------------------
+            // (r3) against a FRESH bound R*: the waves' runner-up maxima cross a barrier of their own before anybody
+            // picks candidates (one more barrier per round; until round 2 the previous round's R* was used: valid, but
+            // it sits just above the next candidates -- 9.3 samples per round against 14.2 on a level-4 set,
+            // tools/fps_cells_sim.py).  Candidates are appended to ONE list through an LDS counter: no per-wave quota.
             const int par = round & 1;
             uint32_t *cl = sh.cand[par];
             const int mine = lmax;
+            uint32_t rk = 0xFFFFFFFFu;
             {
                 const int wv = tpu3_wave_max_i32_fast(mine);
                 const int wr = tpu3_wave_max_i32_fast(lrun);
                 wbound = wv;
-                bool is_cand = mine > rstar;
                 unsigned long long tie = __ballot(mine == wv);
-                // keys are fetched by the lanes that need one: the wave's best (ties: all of them), the candidates
-                const bool multi = __builtin_popcountll(tie) != 1;
-                uint32_t rk = 0xFFFFFFFFu;
-                if (is_cand || mine == wv)
+                // the wave's best (ties: the smallest key) for the single-sample fall-back
+                if (mine == wv)
                     rk = key_at(larg);
-                if (multi) {
+                if (__builtin_popcountll(tie) != 1) {
                     const uint32_t kmin = tpu3_wave_min_u32(mine == wv ? rk : 0xFFFFFFFFu);
                     tie = __ballot(mine == wv && rk == kmin);
                 }
-                const int wlane = __builtin_ctzll(tie);
-                unsigned long long cm = __ballot(is_cand);
-                int drop = (int)0x80000000;
-                if (__builtin_popcountll(cm) > WCAP) {
-                    int lrank = 0;
-                    for (unsigned long long mm = cm; mm;) {
-                        const int i = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const int mi = __builtin_amdgcn_readlane(mine, i);
-                        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)rk, i);
-                        lrank += (mi > mine || (mi == mine && ki < rk)) ? 1 : 0;
-                    }
-                    const bool keep = is_cand && lrank < WCAP;
-                    drop = tpu3_wave_max_i32_fast(is_cand && !keep ? mine : (int)0x80000000);
-                    is_cand = keep;
-                    cm = __ballot(is_cand);
-                }
-                if (is_cand) {
-                    uint32_t *e = cl + (wave * WCAP + __builtin_popcountll(cm & ((1ull << lane) - 1ull))) * RL_EW;
-                    e[0] = (uint32_t)mine; e[1] = rk;
-                    e[2] = __float_as_uint(lbx); e[3] = __float_as_uint(lby); e[4] = __float_as_uint(lbz);
-                }
-                if (lane == wlane) {
+                if (lane == (int)__builtin_ctzll(tie)) {
                     FmHeader &h = sh.h[par][wave];
                     h.best = wv; h.key = rk; h.x = lbx; h.y = lby; h.z = lbz;
-                    h.rmax = wr; h.count = __builtin_popcountll(cm); h.drop = drop;
+                    h.rmax = wr;
                 }
             }
             if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
+            __syncthreads();
+            {
+                const int sr = lane < 16 ? sh.h[par][lane].rmax : (int)0x80000000;
+                rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+                const bool is_cand = mine > rstar;
+                const unsigned long long cm = __ballot(is_cand);
+                if (cm) {
+                    int base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&sh.ncand[par], (int)__builtin_popcountll(cm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                    if (is_cand && pos < RL_CAP) {
+                        if (mine != wbound)
+                            rk = key_at(larg);
+                        uint32_t *e = cl + pos * RL_EW;
+                        e[0] = (uint32_t)mine; e[1] = rk;
+                        e[2] = __float_as_uint(lbx); e[3] = __float_as_uint(lby); e[4] = __float_as_uint(lbz);
+                    }
+                    if (base + (int)__builtin_popcountll(cm) > RL_CAP) {
+                        const int d = tpu3_wave_max_i32_fast(is_cand && pos >= RL_CAP ? mine : (int)0x80000000);
+                        if (lane == 0)
+                            atomicMax(&sh.drop[par], d);
+                    }
+                }
+            }
             __syncthreads();
             if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
             // wave 0 ranks the candidates; the others wait at a second barrier and read the round's samples from LDS
@@ -1378,21 +1392,25 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                 const FmHeader &hh = sh.h[par][lane & 15];
                 const int sd = lane < 16 ? hh.best : (int)0x80000000;
                 const uint32_t sk = lane < 16 ? hh.key : 0xFFFFFFFFu;
-                const int sr = lane < 16 ? hh.rmax : (int)0x80000000;
-                const int sdrop = lane < 16 ? hh.drop : (int)0x80000000;
                 const float hx = hh.x, hy = hh.y, hz = hh.z;
                 const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-                const int nrstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
-                const int gdrop = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sdrop), 0);
-                // candidate `lane` of the list: wave lane / WCAP, entry lane % WCAP
-                const bool live = lane < RL_CAP && (lane % WCAP) < sh.h[par][(lane / WCAP) & 15].count;
+                const int nc = __builtin_amdgcn_readfirstlane(sh.ncand[par]);
+                const int gdrop = nc > RL_CAP ? __builtin_amdgcn_readfirstlane(sh.drop[par]) : (int)0x80000000;
+                const int total = nc < RL_CAP ? nc : RL_CAP;
+                const bool live = lane < total;
                 const unsigned long long lm = __ballot(live);
-                const int total = __builtin_popcountll(lm);
+                if (lane == 0) {                            // the other buffer's counters: next round starts from zero
+                    sh.ncand[par ^ 1] = 0;
+                    sh.drop[par ^ 1] = (int)0x80000000;
+                }
                 if (PROF) { r0 = now(); pr[0] += r0 - t0; pr[4] += (unsigned long long)total; }
                 float qx, qy, qz;
                 uint32_t okey;
                 int nj;
-                if (total < 2) {
+                // (position-based surplus: if even the best listed candidate is below a dropped one, fall back)
+                const int cM0 = live ? (int)cl[(lane & (RL_CAP - 1)) * RL_EW] : (int)0x80000000;
+                const bool usable = total >= 1 && __ballot(live && cM0 > gdrop) != 0;
+                if (!usable) {
                     // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
                     unsigned long long who = __ballot(lane < 16 && sd == gbest);
                     if (__builtin_popcountll(who) != 1) {
@@ -1409,63 +1427,71 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     const int cM = live ? (int)e[0] : (int)0x80000000;
                     const uint32_t cK = live ? e[1] : 0xFFFFFFFFu;
                     const float cx = __uint_as_float(e[2]), cy = __uint_as_float(e[3]), cz = __uint_as_float(e[4]);
+                    // rank = number of candidates ahead of this one.  The list is read back as wave-uniform LDS
+                    // broadcasts (the scalar bit scan -> readlane -> compare chain cost ~150 cycles per candidate in
+                    // this lone wave: 2.7 k cycles per round at 18 candidates)
                     int rank = 0;
                     bool tie = false;
-                    // (two candidates per step: the scalar bit scan -> readlane -> compare chain of one candidate
-                    // costs ~175 cycles in a lone wave; two independent chains overlap)
-                    for (unsigned long long mm = lm; mm;) {
-                        const int i = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const int i2 = mm ? __builtin_ctzll(mm) : i;        // (a repeat of i adds nothing below)
-                        mm &= mm - 1;
-                        const int mi = __builtin_amdgcn_readlane(cM, i);
-                        const int mi2 = __builtin_amdgcn_readlane(cM, i2);
-                        rank += (mi > cM ? 1 : 0) + (i2 != i && mi2 > cM ? 1 : 0);
-                        tie |= (mi == cM && i != lane) || (mi2 == cM && i2 != lane);
+                    sh.mrow[lane & (RL_CAP - 1)] = cM;      // (dead lanes: INT_MIN, never ahead of anybody)
+                    for (int c0 = 0; c0 < total; c0 += 16) {
+                        int4 mv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            mv[u] = *(const int4 *)(sh.mrow + c0 + 4 * u);      // four broadcast reads in flight
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int m4[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w};
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                rank += m4[v] > cM ? 1 : 0;
+                                tie |= m4[v] == cM && c0 + 4 * u + v != lane;
+                            }
+                        }
                     }
                     if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
                         rank = 0;
-                        for (unsigned long long mm = lm; mm;) {
-                            const int i = __builtin_ctzll(mm);
-                            mm &= mm - 1;
-                            const int mi = __builtin_amdgcn_readlane(cM, i);
-                            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
+                        for (int i = 0; i < total; ++i) {
+                            const int mi = (int)cl[i * RL_EW];
+                            const uint32_t ki = cl[i * RL_EW + 1];
                             rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
                         }
                     }
                     if (PROF) { r1 = now(); pr[1] += r1 - r0; r0 = r1; }
-                    const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
-                    const int dst = (live ? rank : deadpos) * 4;
-                    qx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cx)));
-                    qy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cy)));
-                    qz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(cz)));
-                    okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
-                    const int sM = __builtin_amdgcn_ds_permute(dst, cM);
+                    // into rank order through LDS: pick[rank] = (x, y, z, M), pkey[rank]
+                    if (live) {
+                        *(float4 *)sh.pick[par][rank] = make_float4(cx, cy, cz, __int_as_float(cM));
+                        sh.pkey[par][rank] = cK;
+                    }
+                    const float4 mine4 = *(const float4 *)sh.pick[par][lane & (RL_CAP - 1)];
+                    qx = mine4.x; qy = mine4.y; qz = mine4.z;
+                    okey = sh.pkey[par][lane & (RL_CAP - 1)];
+                    const int sM = __float_as_int(mine4.w);
                     int jmax = __builtin_popcountll(__ballot(lane < total && sM > gdrop));
                     jmax = jmax < 1 ? 1 : jmax;
                     jmax = jmax < left ? jmax : left;
                     // longest prefix in which no member lies inside the update ball of an earlier member: the
-                    // smallest l with d(sample i, sample l) < M_l for some i < l.  Up to 11 candidates: all 55
-                    // pairs at once, a lane per pair (l-major, so the first hit has the smallest l).
-                    if (jmax <= 11) {
-                        const float lx = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qx)));
-                        const float ly = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qy)));
-                        const float lz = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_l * 4, __float_as_int(qz)));
-                        const float ix = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qx)));
-                        const float iy = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qy)));
-                        const float iz = __int_as_float(__builtin_amdgcn_ds_bpermute(pair_i * 4, __float_as_int(qz)));
-                        const int lM = __builtin_amdgcn_ds_bpermute(pair_l * 4, sM);
-                        const float d = tpu3_sqdist3(lx - ix, ly - iy, lz - iz);
-                        const unsigned long long hit = __ballot(pair_l < jmax && d < __int_as_float(lM));
-                        if (hit)
-                            jmax = __builtin_amdgcn_readlane(pair_l, (int)__builtin_ctzll(hit));
-                    } else {
-                        for (int i = 0; i + 1 < jmax; ++i) {
-                            const float d = tpu3_sqdist3(qx - rl(qx, i), qy - rl(qy, i), qz - rl(qz, i));
-                            const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
+                    // smallest l with d(sample i, sample l) < M_l for some i < l.  All pairs (i < l < jmax), 64 per
+                    // pass, a lane per pair in l-major order (0:(0,1) 1:(0,2) 2:(1,2) 3:(0,3) ...): the first pass
+                    // with a hit holds the smallest l.
+                    {
+                        const int npair = jmax * (jmax - 1) / 2;
+                        for (int t0 = 0; t0 < npair; t0 += 64) {
+                            int pl = pair_l, pi = pair_i;
+                            if (t0) {
+                                const int t = t0 + lane;
+                                pl = (int)((1.f + sqrtf(1.f + 8.f * (float)t)) * 0.5f);
+                                pl -= pl * (pl - 1) / 2 > t ? 1 : 0;
+                                pl += (pl + 1) * pl / 2 <= t ? 1 : 0;
+                                pi = t - pl * (pl - 1) / 2;
+                            }
+                            const bool ok = pl < jmax;
+                            const float4 L4 = *(const float4 *)sh.pick[par][ok ? pl : 0];
+                            const float4 I4 = *(const float4 *)sh.pick[par][ok ? pi : 0];
+                            const float d = tpu3_sqdist3(L4.x - I4.x, L4.y - I4.y, L4.z - I4.z);
+                            const unsigned long long hit = __ballot(ok && d < L4.w);
                             if (hit) {
-                                const int f = __builtin_ctzll(hit);
-                                jmax = f < jmax ? f : jmax;
+                                jmax = __builtin_amdgcn_readlane(pl, (int)__builtin_ctzll(hit));
+                                break;
                             }
                         }
                     }
@@ -1473,21 +1499,18 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                     if (PROF) { r1 = now(); pr[2] += r1 - r0; r0 = r1; }
                 }
                 nj = nj < left ? nj : left;
-                if (lane < RL_CAP) {
-                    sh.pick[par][lane][0] = qx; sh.pick[par][lane][1] = qy; sh.pick[par][lane][2] = qz;
+                if (!usable && lane == 0) {
+                    sh.pick[par][0][0] = qx; sh.pick[par][0][1] = qy; sh.pick[par][0][2] = qz;
                 }
                 if (lane < nj)
                     a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
-                if (lane == 0) {
+                if (lane == 0)
                     sh.npick[par] = nj;
-                    sh.h[par][0].rmax = nrstar;             // (every wave picks the new bound up from here)
-                }
             }
             if (PROF) { t1 = now(); pc[3] += t1 - t0; t0 = t1; }
             __syncthreads();
             if (PROF) { t1 = now(); pc[4] += t1 - t0; t0 = t1; }
             J = sh.npick[par];
-            rstar = sh.h[par][0].rmax;
             sx = sh.pick[par][lane & (RL_CAP - 1)][0];
             sy = sh.pick[par][lane & (RL_CAP - 1)][1];
             sz = sh.pick[par][lane & (RL_CAP - 1)][2];
