@@ -116,6 +116,81 @@ __global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
     }
 }
 
+// fp16-operand flavour for WIDE layers (32 < cout <= 128: the per-point half of up_layer1, 264 -> 128, in
+// mlp_precision "f16" -- a library fp16 GEMM until round 2).  Same tiling and k-slot permutation as
+// linear_small_f16_kernel; the weights are converted ONCE per workgroup and staged in LDS as fp16
+// ([16 TOUT][cin + 8] halves: 70 KB for 128 x 264, two workgroups per compute unit), so the A operand of a
+// v_mfma_f32_16x16x32_f16 is two 8-byte LDS reads and no conversions.  fp32 accumulate, fp32 rows in memory.
+template <int TOUT>
+__global__ __launch_bounds__(256) void linear_wide_f16_kernel(LinArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    _Float16 *wh = (_Float16 *)wl;                                   // [16 * TOUT][S]
+    const int S = a.cin + 8;
+    for (int i = threadIdx.x; i < 16 * TOUT * (a.cin >> 2); i += blockDim.x) {
+        const int o = i / (a.cin >> 2), c4 = i - o * (a.cin >> 2);
+        const v4f v = o < a.cout ? ld4(a.w + (size_t)o * a.cin + 4 * c4) : (v4f){0.f, 0.f, 0.f, 0.f};
+        h4 h;
+        h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+        *(h4 *)(wh + o * S + 4 * c4) = h;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const int nslab = (a.cin + 15) >> 4;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const h4 hzero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 16 + pt;
+        const float *xr = a.x + (row < a.m ? row : a.m - 1) * a.xs;
+        v4f acc[TOUT];
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t)
+            acc[t] = zero;
+        for (int s0 = 0; s0 < nslab; s0 += 8) {
+            v4f bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = 16 * (s0 + u) + 4 * q;
+                bv[u] = ld4(xr + (ch < a.cin ? ch : 0));        // cin % 4 == 0
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const int ch0 = 16 * (s0 + u) + 4 * q, ch1 = ch0 + 16;
+                const bool ok0 = ch0 < a.cin, ok1 = ch1 < a.cin;
+                const h8 b = cat_h8(ok0 ? bv[u] : zero, ok1 ? bv[u + 1] : zero);
+#pragma unroll
+                for (int t = 0; t < TOUT; ++t) {
+                    const _Float16 *wr = wh + (16 * t + pt) * S;
+                    const h4 a0 = ok0 ? *(const h4 *)(wr + ch0) : hzero, a1 = ok1 ? *(const h4 *)(wr + ch1) : hzero;
+                    h8 av;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        av[j] = a0[j];
+                        av[4 + j] = a1[j];
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) {
+            const int o = 16 * t + 4 * q;                       // cout % 4 == 0
+            if (o < a.cout && row < a.m) {
+                v4f v = acc[t];
+                if (a.b)
+                    v += ld4(a.b + o);
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(v4f *)(a.y + row * a.ys + o) = v;
+            }
+        }
+    }
+}
+
 template <int TOUT>
 __global__ __launch_bounds__(256) void linear_small_kernel(LinArgs a)
 {
@@ -660,7 +735,10 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
 {
     if (mfma != TPU3_MFMA_F32 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
     if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
-    if (cout > 32 || cin > LS_CIN_MAX || cin % 4 || cout % 4 || x_stride % 4 || y_stride % 4) return TPU3_ELIMIT;
+    // fp32 operands: cout <= 32 (wider layers: tpu3_linear_wide_f32); fp16 operands: cout <= 128
+    if (cout > (mfma == TPU3_MFMA_F16 ? 128 : 32) || cin > LS_CIN_MAX || cin % 4 || cout % 4 || x_stride % 4 ||
+        y_stride % 4)
+        return TPU3_ELIMIT;
     if (x_stride < cin || y_stride < cout) return TPU3_EINVAL;
     if (m == 0) return TPU3_OK;
     if (!x || !w || !y) return TPU3_EINVAL;
@@ -668,6 +746,15 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
     LinArgs a{m, cin, cout, x_stride, y_stride, relu, x, w, bias, y};
     const long tiles = (m + 15) / 16;
     long blocks = (tiles + 3) / 4;
+    if (cout > 32) {            // fp16 operands, wide: weights as fp16 in LDS, two persistent workgroups per CU
+        const size_t ldsw = (size_t)128 * (cin + 8) * sizeof(_Float16);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_wide_f16_kernel<8>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+        if (e != hipSuccess) return (int)e;
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(linear_wide_f16_kernel<8>, dim3((unsigned)blocks), dim3(256), ldsw, (hipStream_t)stream, a);
+        return tpu3_launch_status();
+    }
     if (blocks > 256 * 8) blocks = 256 * 8;       // persistent: the weights are staged once per workgroup
     const int tout = cout <= 16 ? 1 : 2;
     const size_t lds = (size_t)16 * tout * (cin + 4) * sizeof(float);

@@ -297,11 +297,12 @@ class HipBackend(object):
         return feat
 
     def linear_small(self, x, weight, bias, relu, mfma=L.MFMA_F32):
-        """Per-point linear layer with <= 32 outputs on channel-last rows: x (..., C_in) with unit
-        channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),
+        """Per-point linear layer with <= 32 outputs (fp16 operands: <= 128) on channel-last rows: x (..., C_in)
+        with unit channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),
         weight (C_out, C_in) -> (..., C_out), or None when the shape is not covered."""
         cin, cout = x.size(-1), weight.size(0)
-        if cout > 32 or cin > 320 or cin % 4 or cout % 4 or x.stride(-1) != 1 or x.dtype != torch.float32:
+        if (cout > (128 if int(mfma) == int(L.MFMA_F16) else 32) or cin > 320 or cin % 4 or cout % 4
+                or x.stride(-1) != 1 or x.dtype != torch.float32):
             return None
         rs = x.stride(-2)
         lead = x.shape[:-1]

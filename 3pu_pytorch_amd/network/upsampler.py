@@ -437,8 +437,13 @@ class Level(torch.nn.Module):
             w = up1.conv.weight.view(up1.conv.weight.size(0), -1)
             cin = x.size(-1)
             f16 = getattr(self, "mlp_precision", "f32") == "f16"
-            if f16:     # the per-point half of up_layer1 as an fp16 GEMM (hipBLASLt -> MFMA), fp32 result
-                a = torch.nn.functional.linear(x.half(), w[:, :cin].half(), up1.conv.bias.half()).float()
+            if f16:     # the per-point half of up_layer1 on fp16-operand MFMA (csrc/mlp.hip, linear_wide_f16_kernel)
+                a = None
+                if x.is_cuda and hasattr(operations.BACKEND, "linear_small"):
+                    a = operations.BACKEND.linear_small(x, w[:, :cin], up1.conv.bias, False, mfma=operations.L.MFMA_F16)
+                if a is None:
+                    raise RuntimeError("mlp_precision='f16': up_layer1 with %d inputs / %d outputs is not covered by "
+                                       "the fp16-operand kernel" % (cin, w.size(0)))
             else:
                 a = None
                 if x.is_cuda and hasattr(operations.BACKEND, "linear_wide"):

@@ -51,7 +51,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TF = 157.3           # fp32 vector = fp32 MFMA dense peak
 F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA peak
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def pkg(sub=None):
@@ -146,18 +146,21 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
 
     ms, shp, spread = kt.total("dense_edge_conv")
     if shp:
-        # executed matrix-core work: per 16 points 24 MFMAs (centre terms + z table), per 16 (point, slot)
-        # pairs 12 MFMAs, each v_mfma_f32_16x16x4_f32 = 2048 FLOP; 12 of the 16 output rows are channels
-        ex = sum(p * -(-n // 16) * (12 * k + 24) * 2048.0 for p, n, k in shp)
+        # executed matrix-core work of the lane-per-point kernel (csrc/dense_edge_conv.hip, dec_fused4_kernel): per
+        # 64-point step 108 v_mfma_f32_4x4x1 (512 FLOP each) per neighbour slot + 288 per-point ones (centre terms, z
+        # and c2 tables); no padded rows or k slots -- the only padding is the lanes beyond n in a patch's last step
+        steps = lambda n: -(-n // 64)
+        ex = sum(p * steps(n) * (108 * k + 288) * 512.0 for p, n, k in shp)
+        useful = sum(p * n * (108 * k + 288) * 8.0 for p, n, k in shp)           # 512 / 64 lanes = 8 FLOP per lane
         alg = sum(p * n * k * 3168.0 for p, n, k in shp)               # SURVEY 8a a9 (un-hoisted formulation)
         ach = ex / (ms * 1e-3) / 1e12
-        out.append({"kernel": "dec_fused_kernel (DenseEdgeConv, fp32 MFMA), %d launches/step" % len(shp),
+        out.append({"kernel": "dec_fused4_kernel (DenseEdgeConv, fp32 MFMA 4x4x1, lane per point), %d launches/step" % len(shp),
                     "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
-                    "useful_frac": 0.75 * ach / FP32_PEAK_TF,
-                    "basis": "executed v_mfma_f32_16x16x4 FLOPs; 12 of the 16 output rows are channels, the rest padding: "
-                             "useful_frac = 0.75 x frac",
-                    "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex, "survey_model_flop_per_step": alg,
-                    "traffic": tr("dec_fused_kernel")})
+                    "useful_frac": useful / ex * ach / FP32_PEAK_TF,
+                    "basis": "executed v_mfma_f32_4x4x1 FLOPs (hoisted formulation); useful_frac discounts the idle lanes of a "
+                             "patch's last 64-point step (312 of 320)",
+                    "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex,
+                    "survey_model_flop_per_step": alg, "traffic": tr("dec_fused")})
     ms, shp, spread = kt.total("knn_graph")
     if shp:
         flop = sum(p * n * n * (2.0 * c + 3.0) for p, n, c, k in shp)   # B*M*N*(2C+3), M = N
@@ -526,8 +529,9 @@ def main():
         roof = {"kernel": "fm_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tr,
                 "achieved": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
-                "basis": "measured fabric traffic of one launch (PMC, profiles/r02_traffic.json) / launch time (HIP events "
+                "basis": "measured fabric traffic of one launch (PMC, profiles/r03_traffic.json) / launch time (HIP events "
                          "on the kernel's stream)",
+                "traffic_provenance": (traffic or {}).get("provenance"),
                 "launch_ms": fps_ms, "operator_ms": op_ms,
                 "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
                 "us_per_round_floor": 0.9,

@@ -1,6 +1,6 @@
-"""Derive profiles/r02_traffic.json (read by bench.py) from the PMC passes of tools/collect_profiles.sh.
+"""Derive profiles/r03_traffic.json (read by bench.py) from the PMC passes of tools/collect_profiles.sh.
 
-usage: python tools/make_traffic_json.py <dir with pmc_*_by_kernel.txt and pmc_*_fm_main.csv> <clouds per launch>
+usage: python tools/make_traffic_json.py <dir with pmc_*_by_kernel.txt and pmc_*_fm_main.csv> <clouds per launch> [out.json] [commit]
   traffic of the dominant kernel (fm_main_kernel, final FPS): mean over the bench's launches (the dispatches
       with the large counter values; the small ones are the input thinning) of FETCH_SIZE x 2 (gfx950: 128-byte
       requests are tallied at 64 B for 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE,
@@ -54,7 +54,7 @@ def find(tab, key):
 
 
 others, mfma = {}, {}
-for key in ("dec_fused_kernel", "knn_graph_key_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
+for key in ("dec_fused", "knn_graph_key_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
             "linear_lift_kernel", "skip_", "rl_main_kernel", "knn_insert_kernel", "knn_select_kernel", "knn_dup_lds"):
     f, w = find(F, key), find(Wr, key)
     if f and w:
@@ -82,7 +82,11 @@ out = {
     "mfma_note": "busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); "
                  "v_mfma_f32_16x16x4_f32 counts 32 busy cycles, v_mfma_f32_4x4x1 8",
 }
-json.dump(out, open("profiles/r02_traffic.json", "w"), indent=1)
+import subprocess, datetime
+out["provenance"] = {"commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+                               or (sys.argv[4] if len(sys.argv) > 4 else "unknown"),
+                     "date": datetime.date.today().isoformat(), "collected_by": "tools/collect_profiles.sh on a gpurun MI355X box"}
+json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r03_traffic.json", "w"), indent=1)
 print(json.dumps({"traffic_GB_per_launch": out["traffic_bytes_per_launch"] / 1e9,
                   "mfma": {k: round(v["mfma_busy_frac"], 3) for k, v in mfma.items()},
                   "others_GB_per_step": {k: round(v["traffic_bytes_per_step"] / 1e9, 1) for k, v in others.items()}}, indent=1))
