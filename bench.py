@@ -304,6 +304,19 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
             res["network_stages_ms" if not final else "total_ms"] = dt * 1e3
         assert tuple(out.shape) == (1, 3, 1280000) and bool(torch.isfinite(out).all())
         res["points_per_s"] = 1280000 / (res["total_ms"] * 1e-3)
+        # the fp16-operand cloud against the fp32 cloud of the same weights (every 16th point of the 3.83 M merged ones)
+        m16 = pipe.upsample(net, c5, 1024, 16, 3, final_fps=False, check_small=False, optimistic_graph=True)
+        net.set_mlp_precision("f32")
+        m32 = pipe.upsample(net, c5, 1024, 16, 3, final_fps=False, check_small=False, optimistic_graph=True)
+        net.set_mlp_precision("f16")
+        s16 = m16.transpose(2, 1)[:, ::16].contiguous()
+        s32 = m32.transpose(2, 1)[:, ::16].contiguous()
+        d1, _, d2, _ = pkg("network.model_loss").nndistance(s16, s32)
+        _, dself, _ = ops.knn_query(2, s32[:, :20000].contiguous(), s32[:, :20000].contiguous(), unique=False,
+                                    want_grouped=False)
+        res["chamfer_f16_vs_f32"] = float(d1.mean() + d2.mean())
+        res["f32_cloud_spacing_sq_median"] = float(dself[:, :, 1].clamp_min(0).median())
+        del m16, m32
         res["config"] = "C5: 1 cloud x 80000 pts, num_point=1024, up_ratio=16, fp16-operand MFMA feature MLPs, 1 GPU"
         ex["c5_stress"] = res
     except Exception as e:                                               # noqa: BLE001

@@ -257,9 +257,10 @@ size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
  * nn.Conv1d / nn.Conv2d on channel-last data, network/layers.py:115-204):
  *   y[i, 0..cout) = act(W x[i, 0..cin) + bias),  x (m, x_stride) rows, y (m, y_stride) rows,
  *   w (cout, cin) row-major = the convolution weight, bias (cout) or NULL, relu != 0 -> ReLU.
- * cout <= 32; cin, cout and both strides multiples of 4, 16-byte aligned bases (else TPU3_ELIMIT:
- * callers then use their generic GEMM path).  mfma = TPU3_MFMA_F32 / TPU3_MFMA_F16 (fp16 operands, fp32
- * accumulate; rows stay fp32 in memory). */
+ * cout <= 32 (TPU3_MFMA_F16: <= 128 -- in that mode the per-point half of up_layer1, 264 -> 128, runs here too);
+ * cin <= 320; cin, cout and both strides multiples of 4, 16-byte aligned bases (else TPU3_ELIMIT: callers then use
+ * their generic GEMM path).  mfma = TPU3_MFMA_F32 / TPU3_MFMA_F16 (fp16 operands, fp32 accumulate; rows stay fp32
+ * in memory). */
 int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                           const float *w, const float *bias, int relu, float *y, int y_stride, int mfma);
 
