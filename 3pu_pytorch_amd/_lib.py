@@ -62,9 +62,12 @@ SIGNATURES = {
     "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i]),
+    "tpu3_dense_edge_conv_fold_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 MFMA_F32, MFMA_F16 = 0, 1        # TPU3_MFMA_* of include/tpu3.h
+EINVAL, ELIMIT = -1, -2          # TPU3_EINVAL / TPU3_ELIMIT
 
 _lib = None
 

@@ -65,6 +65,13 @@ struct DecArgs {
     float *out;                  // (P, n, out_stride): y written at channels [0,60)
     int out_stride;
     float *zg;                   // (P, n, 12) z table in global memory (patches too large for LDS), else null
+    // (r3) the next prep convolutions folded into this block's write-out (lane-per-point kernel only), see
+    // tpu3_dense_edge_conv_fold_f32: fold_n in {0, 24, 48, 72} outputs over the block's 60-channel row
+    int fold_n;
+    const float *fold_w, *fold_b;    // (fold_n, 60) row-major; (fold_n) or null = the sums continue from `acc`
+    float *acc;                      // (P, n, acc_stride) partial sums of the later prep convolutions
+    int acc_stride, seed_off, store_off;
+    float *xnext;                    // (P, n, 24): relu of the first 24 outputs = the next block's input rows
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -80,6 +87,14 @@ __device__ __forceinline__ float dec_relu(float v)
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
 }
+
+// The same single instructions for values that come straight out of a BUILTIN MFMA: inline asm is invisible to
+// hipcc's hazard recognizer, so a v_max in an asm statement may be issued inside the wait states an MFMA result
+// needs before a VALU instruction reads it (stale accumulator: the lane-per-point kernel produced wrong maxima in
+// one of its instantiations).  v_med3_f32 with an infinite third operand IS max (and clamps at zero for ReLU), one
+// instruction like v_max, and the compiler sees it.
+__device__ __forceinline__ float dec_relu_c(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+__device__ __forceinline__ float dec_max_c(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 
 // running maximum as ONE v_max_f32 (fmaxf() canonicalises both operands first: three instructions)
 __device__ __forceinline__ float dec_max(float a, float b)
@@ -165,7 +180,7 @@ struct DecW32 {
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                h1[u][r] = dec_relu(h1[u][r]);
+                h1[u][r] = dec_relu_c(h1[u][r]);
             h2[u] = c2;
         }
 #pragma unroll
@@ -237,7 +252,7 @@ struct DecW16 {
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                h1[u][r] = dec_relu(h1[u][r]);
+                h1[u][r] = dec_relu_c(h1[u][r]);
             const f16x4 h1h = to_h4(h1[u]);
             f16x8 b;
 #pragma unroll
@@ -584,7 +599,7 @@ __device__ __forceinline__ void dec4_setup(const DecArgs &a, float *lds, float *
 
 // U = neighbour slots per loop iteration.  U = 2 folds two slots into one v_max3 per channel (18 instead of 36
 // running-maximum instructions per slot) at the price of 36 more live registers (3 instead of 4 waves per SIMD).
-template <bool IDX64, int U>
+template <bool IDX64, int U, bool FOLD>
 __global__ __launch_bounds__(DEC4_MAXW * 64) __attribute__((amdgpu_waves_per_eu(U == 1 ? 4 : 3, U == 1 ? 4 : 3)))
 void dec_fused4_kernel(DecArgs a)
 {
@@ -598,9 +613,19 @@ void dec_fused4_kernel(DecArgs a)
     float *bias = lds + DEC4_BIAS;
     float *zl = lds + DEC4_ZTAB;                 // z_p  = W0b x_p            (n x 12)
     float *c2l = zl + (size_t)n * DEC_ZS;        // c2_p = W2c x_p + b2       (n x 12)
+    // (FOLD) A operands of the folded prep convolutions behind the two tables: float4 entries
+    // [chunk of 24 outputs][row group 6][kq 15][i 4] = fold_w[24 chunk + 4 rg + i][4 kq .. 4 kq + 3]
+    f32x4 *ftab = (f32x4 *)(c2l + (size_t)n * DEC_ZS + 4);
 
     float wp[7];
     dec4_setup(a, lds, zl, wp);
+    if constexpr (FOLD) {
+        for (int e = tid; e < a.fold_n * 15; e += blockDim.x) {
+            const int i = e & 3, kq = (e >> 2) % 15, rgc = (e >> 2) / 15;          // rgc = 6 chunk + rg
+            ftab[e] = *(const f32x4 *)(a.fold_w + (size_t)(4 * rgc + i) * 60 + 4 * kq);
+        }
+        // (visible after the barrier behind phase A)
+    }
 
     const int nstep = (n + 63) >> 6;
     // ---- phase A, per point (lane = point): the z table and the slot-independent part of the last layer into LDS,
@@ -693,7 +718,7 @@ void dec_fused4_kernel(DecArgs a)
                     const f32x4 pre = c0[rg] + zn[u][rg];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h0[u][rg][r] = dec_relu(pre[r]);
+                        h0[u][rg][r] = dec_relu_c(pre[r]);
                 }
             // requests for the following iteration (clamped at the end: a repeated slot is harmless)
 #pragma unroll
@@ -724,7 +749,7 @@ void dec_fused4_kernel(DecArgs a)
                 for (int rg = 0; rg < 3; ++rg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h1[u][rg][r] = dec_relu(h1[u][rg][r]);
+                        h1[u][rg][r] = dec_relu_c(h1[u][rg][r]);
                     h2[u][rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             // layer 2: [h1 | h0]
@@ -743,25 +768,31 @@ void dec_fused4_kernel(DecArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if constexpr (U == 2) {
+                        // (h2 comes straight out of the MFMAs: its first read is a compiler-visible instruction)
                         m0[rg][r] = dec_max3(m0[rg][r], h0[0][rg][r], h0[1][rg][r]);
                         m1[rg][r] = dec_max3(m1[rg][r], h1[0][rg][r], h1[1][rg][r]);
-                        m2[rg][r] = dec_max3(m2[rg][r], h2[0][rg][r], h2[1][rg][r]);
+                        m2[rg][r] = dec_max_c(m2[rg][r], dec_max_c(h2[0][rg][r], h2[1][rg][r]));
                     } else {
                         m0[rg][r] = dec_max(m0[rg][r], h0[0][rg][r]);
                         m1[rg][r] = dec_max(m1[rg][r], h1[0][rg][r]);
-                        m2[rg][r] = dec_max(m2[rg][r], h2[0][rg][r]);
+                        m2[rg][r] = dec_max_c(m2[rg][r], h2[0][rg][r]);
                     }
                 }
         }
         // ---- write-out: [max h2 + c2 | max h1 | max h0] = floats [0, 36) of the lane's own row, nine back-to-back
         // 16-byte stores (staging 16 rows at a time through LDS so that 15 consecutive lanes write one row was
         // measured: no faster, and the tile costs the LDS of another workgroup per compute unit)
+        {
+            const f32x4 *cr = (const f32x4 *)(c2l + min(p, n - 1) * DEC_ZS);
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                m2[rg] = m2[rg] + cr[rg];
+        }
         if (p < n) {
-            const f32x4 *cr = (const f32x4 *)(c2l + p * DEC_ZS);
             f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg)
-                orow[rg] = m2[rg] + cr[rg];
+                orow[rg] = m2[rg];
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg)
                 orow[3 + rg] = m1[rg];
@@ -769,13 +800,69 @@ void dec_fused4_kernel(DecArgs a)
             for (int rg = 0; rg < 3; ++rg)
                 orow[6 + rg] = m0[rg];
         }
+        if constexpr (FOLD) {
+            // ---- the next prep convolutions, folded: they are linear in the concatenated feature row, so this block's
+            // 60 channels contribute W[:, their columns] . row to each of them NOW, while the row is in registers --
+            // the level's feature buffer is then never re-read by a prep convolution (84 / 144 / 204 channels per
+            // point and layer before).  Outputs in chunks of 24 (six accumulators); the first chunk completes the
+            // NEXT block's input: ReLU, contiguous rows; the others are partial sums for the blocks after it.
+            const f32x4 *xr2 = (const f32x4 *)(X + (size_t)pc * DEC_C);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                x[q] = xr2[q];
+            float *arow = a.acc + ((size_t)blockIdx.x * n + pc) * a.acc_stride;
+#pragma unroll 1
+            for (int ch = 0; ch < a.fold_n / 24; ++ch) {
+                asm volatile("" : "+v"(tofs));
+                const f32x4 *ft = ftab + tofs + ch * (6 * 15 * 4);
+                f32x4 acc[6];
+#pragma unroll
+                for (int rg = 0; rg < 6; ++rg)
+                    acc[rg] = a.fold_b ? *(const f32x4 *)(a.fold_b + 24 * ch + 4 * rg)
+                                       : *(const f32x4 *)(arow + a.seed_off + 24 * ch + 4 * rg);
+                auto step15 = [&](int kq, const f32x4 &v) __attribute__((always_inline)) {
+                    f32x4 lo3[3] = {acc[0], acc[1], acc[2]}, hi3[3] = {acc[3], acc[4], acc[5]};
+                    dec4_step<15>(ft, li, kq, v[0], v[1], v[2], v[3], lo3);
+                    dec4_step<15>(ft + 3 * 15 * 4, li, kq, v[0], v[1], v[2], v[3], hi3);
+                    acc[0] = lo3[0]; acc[1] = lo3[1]; acc[2] = lo3[2];
+                    acc[3] = hi3[0]; acc[4] = hi3[1]; acc[5] = hi3[2];
+                };
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    step15(g3, m2[g3]);
+                    step15(3 + g3, m1[g3]);
+                    step15(6 + g3, m0[g3]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    step15(9 + q, x[q]);
+                if (p < n) {
+                    if (ch == 0) {
+                        f32x4 *xn = (f32x4 *)(a.xnext + ((size_t)blockIdx.x * n + p) * DEC_C);
+#pragma unroll
+                        for (int rg = 0; rg < 6; ++rg) {
+                            f32x4 v = acc[rg];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                v[r] = dec_relu_c(v[r]);
+                            xn[rg] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int rg = 0; rg < 6; ++rg)
+                            *(f32x4 *)(arow + a.store_off + 24 * (ch - 1) + 4 * rg) = acc[rg];
+                    }
+                }
+            }
+        }
     }
 }
 
-constexpr size_t dec4_lds_bytes(int n)
+constexpr size_t dec4_lds_bytes(int n, int fold_n = 0)
 {
     const size_t tables = 2 * (size_t)n * DEC_ZS + 4;          // z and c2 tables; the raw weights alias them during setup
-    return ((size_t)DEC4_ZTAB + (tables > (size_t)DEC4_RAW_FLOATS ? tables : (size_t)DEC4_RAW_FLOATS)) * sizeof(float);
+    return ((size_t)DEC4_ZTAB + (tables > (size_t)DEC4_RAW_FLOATS ? tables : (size_t)DEC4_RAW_FLOATS) +
+            (size_t)fold_n * 60) * sizeof(float);
 }
 
 int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
@@ -787,11 +874,15 @@ int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
     static const int nw_env = getenv("TPU3_DEC_NW") ? atoi(getenv("TPU3_DEC_NW")) : 4;
     static const int u_env = getenv("TPU3_DEC_U") ? atoi(getenv("TPU3_DEC_U")) : 2;   // 294.9 vs 298.5 ms per bench step
     const int nw = min(min(DEC4_MAXW, max(1, nw_env)), (a.n + 63) / 64);
-    const size_t lds = dec4_lds_bytes(a.n);
+    const size_t lds = dec4_lds_bytes(a.n, a.fold_n);
     const bool u2 = u_env == 2 && (a.k % 2) == 0;
-    void (*kern)(DecArgs) =
-        a.idx64 ? (u2 ? dec_fused4_kernel<true, 2> : dec_fused4_kernel<true, 1>)
-                : (u2 ? dec_fused4_kernel<false, 2> : dec_fused4_kernel<false, 1>);
+    void (*kern)(DecArgs);
+    if (a.fold_n)
+        kern = a.idx64 ? (u2 ? dec_fused4_kernel<true, 2, true> : dec_fused4_kernel<true, 1, true>)
+                       : (u2 ? dec_fused4_kernel<false, 2, true> : dec_fused4_kernel<false, 1, true>);
+    else
+        kern = a.idx64 ? (u2 ? dec_fused4_kernel<true, 2, false> : dec_fused4_kernel<true, 1, false>)
+                       : (u2 ? dec_fused4_kernel<false, 2, false> : dec_fused4_kernel<false, 1, false>);
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
@@ -851,7 +942,8 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return TPU3_EINVAL;
     if (((uintptr_t)out % 16) != 0 || ((uintptr_t)x % 16) != 0) return TPU3_EINVAL;
     if (patches > 65535 * 0 + 2147483647 / (n > 0 ? n : 1)) return TPU3_ELIMIT;       // patches * n must fit an int
-    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr};
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr,
+              0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
     hipStream_t s = (hipStream_t)stream;
     if (mfma == TPU3_MFMA_F16)
         return dec_launch<true>(s, patches, a);
@@ -861,4 +953,30 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (form == 4 && dec4_lds_bytes(n) <= 160 * 1024)
         return dec4_launch(s, patches, a);
     return dec_launch<false>(s, patches, a);
+}
+
+extern "C" int tpu3_dense_edge_conv_fold_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                             const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                             const float *w0, const float *b0, const float *w1, const float *b1,
+                                             const float *w2, const float *b2, float *out, int out_stride, int fold_n,
+                                             const float *fold_w, const float *fold_b, float *acc, int acc_stride,
+                                             int seed_off, int store_off, float *xnext)
+{
+    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
+    if (fold_n != 24 && fold_n != 48 && fold_n != 72) return TPU3_EINVAL;
+    if (seed_off < 0 || store_off < 0 || (acc_stride % 4) || (seed_off % 4) || (store_off % 4)) return TPU3_EINVAL;
+    if (!fold_b && acc_stride < seed_off + fold_n) return TPU3_EINVAL;
+    if (fold_n > 24 && acc_stride < store_off + fold_n - 24) return TPU3_EINVAL;
+    if (patches == 0) return TPU3_OK;
+    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out || !fold_w || !xnext) return TPU3_EINVAL;
+    if ((fold_n > 24 || !fold_b) && !acc) return TPU3_EINVAL;
+    if ((((uintptr_t)out | (uintptr_t)x | (uintptr_t)fold_w | (uintptr_t)fold_b | (uintptr_t)acc | (uintptr_t)xnext) & 15) != 0)
+        return TPU3_EINVAL;
+    if (patches > 2147483647 / n) return TPU3_ELIMIT;
+    if (dec4_lds_bytes(n, fold_n) > 160 * 1024) return TPU3_ELIMIT;        // (callers then run the layers unfolded)
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr,
+              fold_n, fold_w, fold_b, acc, acc_stride, seed_off, store_off, xnext};
+    return dec4_launch((hipStream_t)stream, patches, a);
 }

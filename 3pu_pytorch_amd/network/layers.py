@@ -259,10 +259,14 @@ class DenseEdgeConv(nn.Module):
                                                   want_dist=False, want_grouped=False)
         return None, full.long()[:, :, 1:]
 
-    def forward_cl(self, x, idx=None, layout=None, out=None):
+    def forward_cl(self, x, idx=None, layout=None, out=None, fold=None):
         """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k).
         `out`: optional (B,N,C + n*growth_rate) view (unit channel stride) that receives y -- the
-        Level passes a slice of its concatenated feature buffer so that no copy is needed."""
+        Level passes a slice of its concatenated feature buffer so that no copy is needed.
+        `fold` (inference, fused fp32 kernel only): dict(w (F,60), b (F,)|None, acc (B,N,S)|None, seed_off,
+        store_off, xnext (B,N,24)) -- the later prep convolutions' share of this block's rows is added while the
+        rows are in registers (HipBackend.dense_edge_conv_fold); fold["done"] is set when that happened, the
+        caller runs the prep convolution itself otherwise."""
         B, N, C = x.shape
         g, n, k = self.growth_rate, self.n, self.k
         why = self.fused_reason(x) if idx is None else "caller-supplied neighbour indices"
@@ -276,6 +280,13 @@ class DenseEdgeConv(nn.Module):
                                                       want_dist=False, want_grouped=False)
             if out is None:
                 out = x.new_empty((B, N, C + n * g))
+            if (fold is not None and self.mlp_precision == "f32" and (C, g, n) == (24, 12, 3)
+                    and hasattr(operations.BACKEND, "dense_edge_conv_fold")):
+                fold["done"] = operations.BACKEND.dense_edge_conv_fold(
+                    x, full_idx, 1, k, self.mlps, out, fold["w"], fold.get("b"), fold.get("acc"),
+                    fold.get("seed_off", 0), fold.get("store_off", 0), fold["xnext"])
+                if fold["done"]:
+                    return out, full_idx[:, :, 1:]
             operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out,
                                                mfma=L.MFMA_F16 if self.mlp_precision == "f16" else L.MFMA_F32)
             return out, full_idx[:, :, 1:]

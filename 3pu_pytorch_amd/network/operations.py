@@ -276,6 +276,32 @@ class HipBackend(object):
                 L.ptr(out), out.stride(1), int(mfma)), "tpu3_dense_edge_conv_f32")
         return out
 
+    def dense_edge_conv_fold(self, x, idx, idx_off, k, mlps, out, fold_w, fold_b, acc, seed_off, store_off, xnext):
+        """dense_edge_conv (fp32) + the next prep convolutions folded into the write-out, see
+        tpu3_dense_edge_conv_fold_f32: fold_w (fold_n, 60), fold_b (fold_n) or None (sums continue from
+        acc[..., seed_off:]), acc (P,N,S) or None, xnext (P,N,24) receives the next block's input rows.
+        Returns False when the patch size is beyond the kernel (the caller then runs the layers unfolded)."""
+        L.require_device(x, "x")
+        L.require_dtype(x, torch.float32, "x")
+        P, N, _ = x.shape
+        if out.stride(2) != 1 or out.stride(0) != N * out.stride(1):
+            raise RuntimeError("dense_edge_conv: out must be a channel-slice of a contiguous (P,N,C) tensor")
+        w = []
+        for conv in mlps:
+            w.append(conv.weight.detach().reshape(conv.weight.size(0), -1).contiguous())
+            w.append(conv.bias.detach().contiguous())
+        fold_w = fold_w.contiguous()
+        with torch.cuda.device(x.device):
+            rc = L.lib().tpu3_dense_edge_conv_fold_f32(
+                L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
+                L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
+                L.ptr(out), out.stride(1), fold_w.size(0), L.ptr(fold_w), L.ptr(fold_b), L.ptr(acc),
+                0 if acc is None else acc.stride(1), seed_off, store_off, L.ptr(xnext))
+        if rc == L.ELIMIT:
+            return False
+        L.check(rc, "tpu3_dense_edge_conv_fold_f32")
+        return True
+
     def interlevel_skip(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2, per_cloud=0):
         """Fused skip connection (inference): feat (B,N,C) is updated in place
         (x_i += scale * sum_k w_k f_k with the reference's bilateral weights).  per_cloud: patches

@@ -254,6 +254,8 @@ class Level(torch.nn.Module):
     """3PU per-level network (reference :192-374)."""
 
     mlp_precision = "f32"       # see Net.set_mlp_precision
+    # inference: fold layer{2,3,4}_prep into the write-out of the DenseEdgeConv blocks before them (fp32 kernels)
+    fold_preps = os.environ.get("TPU3_FOLD_PREPS", "1") not in ("0", "")
 
     def __init__(self, dense_n=3, growth_rate=12, knn=16, fm_knn=5, step_ratio=2):
         super(Level, self).__init__()
@@ -311,6 +313,38 @@ class Level(torch.nn.Module):
     # patches per launch group of forward_cl: bounds the (B,N,K,264) / (B,N*r,265) temporaries of the
     # skip connection and the regressor (25 GB / 10 GB for the 15 360 level-4 patches of 8 clouds)
     max_patches = int(os.environ.get("TPU3_MAX_PATCHES", "4096"))
+
+    def _fold_plan(self, blocks, widths, c0):
+        """Per DenseEdgeConv block i = 0..2 the operands of HipBackend.dense_edge_conv_fold, or None when the layers
+        are not the standard ones.  prep_j (j = i+1 .. 3) reads the concatenation [y_j-1 | ... | y_0 | x0]; block i's
+        row [y_i (36) | x_i (24)] sits at columns (j-1-i) * 60 of it.  Block 0's input IS x0, whose second copy closes
+        the concatenation: those 24 columns are added to the block's x part.  The first 24 outputs complete prep_i+1
+        (bias, ReLU applied by the kernel), the others are partial sums kept in a (B,N,48) buffer."""
+        preps = [p for _, p in blocks[1:]]
+        if (getattr(self, "mlp_precision", "f32") != "f32" or any(w != 60 for w in widths) or c0 != 24
+                or any(p.conv.out_channels != 24 or p.activation != "relu" or not p.pointwise()
+                       for p in preps)):
+            return None
+        key = tuple(p.conv.weight._version for p in preps) + tuple(p.conv.weight.data_ptr() for p in preps)
+        cached = getattr(self, "_fold_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        W = [p.conv.weight.detach().reshape(24, -1) for p in preps]            # (24, 84), (24, 144), (24, 204)
+        bs = [p.conv.bias.detach() for p in preps]
+        plan = []
+        for i in range(3):
+            rows = []
+            for j in range(i, 3):                   # prep index j feeds block j + 1
+                w = W[j][:, (j - i) * 60:(j - i) * 60 + 60].clone()
+                if i == 0:
+                    w[:, 36:60] += W[j][:, -24:]
+                rows.append(w)
+            entry = dict(w=torch.cat(rows, dim=0).contiguous(),
+                         b=torch.cat(bs, dim=0).contiguous() if i == 0 else None,
+                         seed_off=0 if i < 2 else 24, store_off=0 if i == 0 else 24)
+            plan.append(entry)
+        self._fold_cache = (key, plan)
+        return plan
 
     def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):
         """Channel-last level; large batches are processed in chunks of whole owner groups (every
@@ -377,9 +411,23 @@ class Level(torch.nn.Module):
             feat = feat_buf if feat_buf is not None else xyz_normalized.new_empty((B, N, total))
             lo = total - c0
             x0 = self.layer0.forward_cl(xyz_normalized, also=feat[..., lo:])     # x0 and its slice in one pass
-            for (blk, prep), wdt in zip(blocks, widths):
-                inp = x0 if prep is None else prep.forward_cl(feat[..., lo:])
-                blk.forward_cl(inp, layout=graph_layout, out=feat[..., lo - wdt:lo])
+            plan = self._fold_plan(blocks, widths, c0) if self.fold_preps and x0.is_cuda else None
+            acc = xyz_normalized.new_empty((B, N, 48)) if plan is not None else None
+            inp, folded = x0, False
+            for i, ((blk, prep), wdt) in enumerate(zip(blocks, widths)):
+                if i > 0 and not folded:
+                    inp = prep.forward_cl(feat[..., lo:])
+                fold = None
+                if plan is not None and i < len(plan):
+                    # the later prep convolutions' share of this block's rows is added in the block's write-out
+                    # (csrc/dense_edge_conv.hip): the buffer is not re-read, the next block's input arrives directly
+                    fold = dict(plan[i], acc=acc, xnext=xyz_normalized.new_empty((B, N, c0)))
+                blk.forward_cl(inp, layout=graph_layout, out=feat[..., lo - wdt:lo], fold=fold)
+                folded = bool(fold is not None and fold.get("done"))
+                if fold is not None and not folded:
+                    plan = None                     # (shape beyond the kernel: the remaining layers run unfolded)
+                if folded:
+                    inp = fold["xnext"]
                 lo -= wdt
             x = feat
 

@@ -234,6 +234,24 @@ int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, co
                              const float *w0, const float *b0, const float *w1, const float *b1,
                              const float *w2, const float *b2, float *out, int out_stride, int mfma);
 
+/* The same block with the NEXT prep convolutions folded into its write-out (fp32, lane-per-point kernel; reference
+ * network/upsampler.py:298-311: layer{2,3,4}_prep = Conv1d(84 / 144 / 204 -> 24) + ReLU over the level's dense
+ * concatenation).  A prep convolution is linear in the concatenated row, so this block's 60 output channels
+ * contribute fold_w . row to each later one while the row is still in registers, and the concatenation is never
+ * re-read:
+ *   t < fold_n:  s[t] = (fold_b ? fold_b[t] : acc[p, seed_off + t]) + sum_c fold_w[t, c] * y[p, c]      c < 60
+ *   t < 24:      xnext[p, t] = max(s[t], 0)        -- the next block's input rows, (patches, n, 24) contiguous
+ *   t >= 24:     acc[p, store_off + t - 24] = s[t] -- partial sums of the blocks after the next
+ * fold_n in {24, 48, 72}; fold_w (fold_n, 60) row-major: the columns of this block's [y | x] channels in each later
+ * prep convolution's weight (the caller adds the columns of a second copy of x, e.g. the buffer's x0 tail);
+ * acc (patches, n, acc_stride).  TPU3_ELIMIT when the patch's tables do not fit LDS: run the layers unfolded. */
+int tpu3_dense_edge_conv_fold_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                  const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                  const float *w0, const float *b0, const float *w1, const float *b1,
+                                  const float *w2, const float *b2, float *out, int out_stride, int fold_n,
+                                  const float *fold_w, const float *fold_b, float *acc, int acc_stride,
+                                  int seed_off, int store_off, float *xnext);
+
 /* Fused inter-level skip connection of a Level, inference (network/upsampler.py:317-347):
  *   w_k = exp(-|p_i - q_k|^2 / (h_s/2)) * exp(-|x_i - f_k|^2 / (h_f/2)),  h = mean_i min_k (dist),
  *   w_k /= sum_k (w_k + 1e-5),  x_i += scale * sum_k w_k f_k          (scale = 0.2 in the reference)

@@ -1,8 +1,11 @@
-"""Scan the gfx950 assembly of csrc/knn.hip for the two hazards hipcc does not handle around the
-hand-issued (inline asm) v_mfma_f32_4x4x1 instructions:
-  * a VALU write of an MFMA's A/B register in the two instructions before it;
-  * an MFMA whose accumulator input is the result of the MFMA issued immediately before it
-    (a dependent MFMA needs two wait states: DESIGN.md section 4).
+"""Scan the gfx950 assembly of the kernels for the hazards hipcc does not handle around inline asm:
+  * (hand-issued v_mfma_f32_4x4x1 of csrc/knn.hip) a VALU write of an MFMA's A/B register in the two instructions
+    before it; an MFMA whose accumulator input is the result of the MFMA issued immediately before it (a dependent
+    MFMA needs two wait states: DESIGN.md section 4);
+  * (any file) a VALU instruction INSIDE an inline-asm statement that reads a register a v_mfma wrote fewer than
+    ASM_READ_SLOTS issue slots earlier: the compiler's hazard recognizer does not look into asm statements, so the
+    wait states an MFMA result needs before a VALU read are not inserted (round 3: a `v_max_f32` in an asm statement
+    read stale accumulators in one instantiation of the lane-per-point DenseEdgeConv kernel).
 Exit status 0 = clean.  Usage: python tools/check_mfma_hazards.py [file.hip ...]"""
 import os
 import re
@@ -52,6 +55,42 @@ def scan(asm_path):
     return total, bad
 
 
+ASM_READ_SLOTS = 12          # (8-pass fp32 MFMAs need 11 wait states before a VALU read; 2-pass ones 5)
+
+
+def scan_asm_reads(asm_path):
+    """inline-asm VALU instructions that read a fresh MFMA result (see module doc)."""
+    bad = []
+    window = []                 # (slots ago, written registers) of recent MFMAs, newest last
+    in_asm = False
+    for raw in open(asm_path):
+        l = raw.strip()
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not raw.startswith("\t") or l.startswith((";", ".")) or not l:
+            if l.endswith(":"):
+                window = []     # a label: control flow joins, nothing is known (loops are covered by their bodies)
+            continue
+        m = re.match(r"s_nop\s+(\d+)", l)
+        step = int(m.group(1)) + 1 if m else 1
+        if in_asm and l.startswith("v_") and not l.startswith("v_mfma"):
+            ops = [t.strip() for t in l.split(None, 1)[1].split(",")] if " " in l else []
+            srcs = set()
+            for t in ops[1:]:
+                srcs |= regs(t.split()[0]) if t else set()
+            for age, dst, text in window:
+                if age < ASM_READ_SLOTS and srcs & dst:
+                    bad.append("asm VALU reads an MFMA result after %d slots: %s  <-  %s" % (age, l, text))
+        window = [(age + step, dst, text) for age, dst, text in window if age + step < 64]
+        if l.startswith("v_mfma"):
+            window.append((0, regs(l.split(None, 1)[1].split(",")[0].strip()), l))
+    return bad
+
+
 def main(files):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     status = 0
@@ -62,8 +101,9 @@ def main(files):
                                    "-munsafe-fp-atomics", "-S", "--cuda-device-only", "-I",
                                    os.path.join(ROOT, "include"), "-o", out, f],
                                   stderr=subprocess.DEVNULL)
-            total, bad = scan(out)
-        print("%s: %d v_mfma_f32_4x4x1, %d suspicious" % (os.path.basename(f), total, len(bad)))
+            total, bad = scan(out) if os.path.basename(f) == "knn.hip" else (0, [])
+            bad = bad + scan_asm_reads(out)
+        print("%s: %d hand-issued v_mfma_f32_4x4x1 checked, %d suspicious" % (os.path.basename(f), total, len(bad)))
         for b in bad[:10]:
             print("   ", b)
         status |= 1 if bad else 0
