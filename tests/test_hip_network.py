@@ -418,6 +418,51 @@ def test_optimize_step_as_hipgraph_matches_eager(dev):
     assert close >= 0.97 * total, (close, total)
 
 
+def test_captured_step_follows_the_chamfer_threshold_toggle(dev):
+    """main.py's curriculum switches the Chamfer threshold on and off mid-training (set_threshold /
+    unset_threshold).  Threshold and forward weight are scalar launch arguments, i.e. frozen into a captured step: they
+    are part of the capture key, so a toggle captures a second graph and the replayed loss is the eager one (advisor,
+    round 2: the toggle was silently ignored for shapes already captured)."""
+    model_mod, ups = pkg("model"), pkg("network.upsampler")
+
+    def make(graph):
+        class Opt(object):
+            lr_init = 0.001
+            ckpt = None
+            graph_steps = graph
+        torch.manual_seed(0)
+        net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev)
+        return model_mod.Model(net, "train", Opt())
+    inp = torch.from_numpy(np.ascontiguousarray(sphere(3, 312, 8).transpose(0, 2, 1))).to(dev)
+    lab = torch.from_numpy(np.ascontiguousarray(sphere(4, 312 * 2, 8).transpose(0, 2, 1))).to(dev)
+    lab[:, :, :6] *= 2.5                                    # strong outliers: the threshold changes the loss
+    eager, graphed = make(False), make(True)
+    for m in (eager, graphed):
+        for step in range(4):
+            if step == 2:
+                m.chamfer_criteria.set_threshold(1.5)
+            m.set_input(inp, 2, label_pc=lab)
+            m.optimize()
+    le, lg = eager.error_log["cd_loss_x2"], graphed.error_log["cd_loss_x2"]
+    assert np.isfinite(le) and abs(le - lg) <= 1e-4 * abs(le), (le, lg)
+    assert len(graphed._captured) == 2                      # one graph per (shapes, threshold, weight)
+    keys = sorted(graphed._captured, key=lambda k: (k[3] is not None, k[3] or 0))
+    assert keys[0][3] is None and keys[1][3] == 1.5
+    # the parameters after two plain + two thresholded steps agree between eager and captured execution
+    close = total = 0
+    for a, b in zip(eager.net.parameters(), graphed.net.parameters()):
+        close += int(((a - b).abs() <= 1e-4).sum())
+        total += a.numel()
+    assert close >= 0.97 * total, (close, total)
+    # and they differ from a run that ignores the toggle
+    ignored = make(False)
+    for step in range(4):
+        ignored.set_input(inp, 2, label_pc=lab)
+        ignored.optimize()
+    diff = sum(float((a - b).abs().max()) for a, b in zip(eager.net.parameters(), ignored.net.parameters()))
+    assert diff > 1e-4
+
+
 def test_pipeline_on_device_against_reference_driver(orc, dev):
     pipe = pkg("pipeline")
     g = golden("pc_prediction.npz")

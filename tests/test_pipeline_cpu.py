@@ -102,6 +102,45 @@ def _worker(rank, world, port, out_dir):
     by_cloud = pipe.upsample(net, clouds, 312, 2, shard="clouds")          # 3 clouds on 2 ranks: padded
     by_patch = pipe.upsample(net, clouds[:1], 312, 2, shard="patches")     # 6 patches on 2 ranks
     ok = bool(torch.equal(by_cloud, ref)) and bool(torch.equal(by_patch, ref[:1]))
+    # A duplicate-row event seen by ONE rank only (rank 0): both ranks must take the recompute branch -- the decision
+    # is all-reduced -- or rank 0 would issue an all-gather the other never joins (advisor, round 2).
+    class _EvBackend(_OB):
+        optimistic_graph = False
+
+        def __init__(self, fire):
+            self.fire = fire
+
+        def graph_dup_events(self, reset=True):
+            f = self.fire
+            if reset:
+                self.fire = 0
+            return f
+    ops.BACKEND = _EvBackend(1 if rank == 0 else 0)
+    calls = []
+    real = pipe._upsample
+
+    def counting(*a, **kw):
+        calls.append(ops.BACKEND.optimistic_graph)
+        return real(*a, **kw)
+    pipe._upsample = counting
+    try:
+        ops.BACKEND.fire = 1 if rank == 0 else 0         # (the reset at the start of upsample() clears it: re-arm inside)
+        orig_reset = ops.BACKEND.graph_dup_events
+        state = {"n": 0}
+
+        def events(reset=True):
+            state["n"] += 1
+            if state["n"] == 1:                          # the clearing read before the first pass
+                return 0
+            if state["n"] == 2:                          # the read after the first pass: rank 0 only
+                return 1 if rank == 0 else 0
+            return 0
+        ops.BACKEND.graph_dup_events = events
+        again = pipe.upsample(net, clouds, 312, 2, shard="clouds")
+    finally:
+        pipe._upsample = real
+    # sharded call = outer _upsample + the rank-local inner one, per pass: optimistic pass, then the exact pass
+    ok = ok and calls == [True, True, False, False] and bool(torch.equal(again, ref))
     with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
         f.write("ok" if ok else "mismatch")
     dist.barrier()
