@@ -59,6 +59,7 @@ SIGNATURES = {
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),
     "tpu3_debug_fps_level_stats": (_i, [_vp]),
+    "tpu3_debug_fps_tile_stats": (_i, [_vp]),
     "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i]),

@@ -57,6 +57,13 @@ struct FbArgs {
     size_t per_elem;
     size_t sort_stride;
     unsigned long long *prof;   // PROF builds only
+    // (r3) tile form (fl_main_kernel): sp / skey hold the Morton order TRANSPOSED per 1024-point tile
+    // ([tile][point j of the bucket][lane = bucket]); one record per 16-point bucket and per tile
+    int fl, ntile;              // fl != 0: tile form; tiles of the slab (upper bound of the live count)
+    uint4 *rec;                 // (ntile * 64) bucket records: fp16 box (3 words) | runner-up distance bits
+    int32_t *bm0;               // (ntile * 64) initial bucket maxima (distance bits)
+    uint8_t *ba0;               // (ntile * 64) initial position (0..15) of the bucket's best point
+    float *tt;                  // (ntile, 8) tile records: box lo.xyz hi.xyz, max bits, runner-up bits
 };
 
 // element i of the batch: pointers advanced, n / m / nb / lb replaced by the element's live values
@@ -70,6 +77,12 @@ __device__ __forceinline__ FbArgs fb_elem(const FbArgs &a0, int i)
     a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * a0.per_elem);
     a.ib = (uint32_t *)((char *)a0.ib + (size_t)i * a0.per_elem);
     a.bbox = (float *)((char *)a0.bbox + (size_t)i * a0.per_elem);
+    if (a0.fl) {
+        a.rec = (uint4 *)((char *)a0.rec + (size_t)i * a0.per_elem);
+        a.bm0 = (int32_t *)((char *)a0.bm0 + (size_t)i * a0.per_elem);
+        a.ba0 = (uint8_t *)((char *)a0.ba0 + (size_t)i * a0.per_elem);
+        a.tt = (float *)((char *)a0.tt + (size_t)i * a0.per_elem);
+    }
     if (a0.n_arr) {
         a.n = min(max(a0.n_arr[i], 0), a0.n);
         a.nb = (a.n + a0.bsz - 1) / a0.bsz;
@@ -158,6 +171,12 @@ __global__ __launch_bounds__(256) void fb_morton_kernel(FbArgs a0, uint32_t *__r
     put(code);
 }
 
+// tile form: slot of Morton position i -- tile i / 1024, bucket (= lane) (i / 16) % 64, point i % 16 of the bucket
+__device__ __forceinline__ int fl_pos(int i)
+{
+    return (((i >> 10) * 16 + (i & 15)) << 6) + ((i >> 4) & 63);
+}
+
 // Morton-ordered float4 (x,y,z,temp) + tie keys; slots past n repeat the last live point with temp = -1
 __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32_t *__restrict__ order0)
 {
@@ -169,17 +188,19 @@ __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32
         return;
     const bool live = i < a.n;
     const uint32_t o = order[live ? i : a.n - 1];
-    a.sp[i] = make_float4(a.xyz[(size_t)o * 3 + 0], a.xyz[(size_t)o * 3 + 1], a.xyz[(size_t)o * 3 + 2],
+    const int w = a0.fl ? fl_pos(i) : i;
+    a.sp[w] = make_float4(a.xyz[(size_t)o * 3 + 0], a.xyz[(size_t)o * 3 + 1], a.xyz[(size_t)o * 3 + 2],
                           live ? a.temp[o] : -1.0f);
-    a.skey[i] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
+    a.skey[w] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
 }
 
 __global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a0)
 {
     const FbArgs a = fb_elem(a0, blockIdx.y);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = a0.fl ? fl_pos(i) : i;
     if (i < a.n && a.m > 0)
-        a.temp[tpu3_fps_tiekey_to_index(a.skey[i], a.lb)] = a.sp[i].w;
+        a.temp[tpu3_fps_tiekey_to_index(a.skey[w], a.lb)] = a.sp[w].w;
 }
 
 // lane-local best of one bucket (64*PPL points), optionally after folding sample q into it
@@ -1550,6 +1571,451 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// (r3) Memory-resident FPS with a LANE per bucket (25 601 .. 262 144 points: the metric's final 239 616 -> 80 000)
+// ---------------------------------------------------------------------------------------------
+// fm_main_kernel re-scans a reached 64-point bucket with a whole wave: two wave-wide reductions and a table write
+// per bucket, four buckets in flight, 12 buckets per wave and round -- half of a round -- and its candidate cells are
+// the 1024-point groups, whose runner-up bound R* admits ~17 samples per round.  rl_main_kernel showed what the
+// lane-per-bucket layout buys on sets that fit the register file; this is the same scheme with the points in
+// memory:
+//   * a BUCKET is 16 Morton-consecutive points owned by a lane, a TILE 64 buckets (1024 points) owned by a wave
+//     (tile t belongs to wave t % 16).  The slab is stored transposed per tile ([tile][point j][lane]): the 16
+//     float4 loads of a reached tile are coalesced, and only the lanes whose bucket a sample reaches load at all;
+//   * per bucket: the maximum running distance and the position of that point live in LDS (5 bytes per bucket,
+//     80 KB at 262 144 points), the fp16 box and the runner-up in a 16-byte global record read when the bucket's
+//     tile is reached; per tile: box, maximum and runner-up bound in the registers of four lanes of the owner wave,
+//     which test the round's samples against it four at a time;
+//   * a reached lane updates its 16 distances with plain per-lane arithmetic and re-derives its record -- no
+//     cross-lane reduction except the tile's two maxima;
+//   * candidates are BUCKETS (bmax > R*, R* = the largest runner-up of any bucket, fresh): 16-point cells admit
+//     ~35-40 samples per round on the metric's cloud (tools/fps_cells_sim.py: 20.8 on average over the first
+//     12 000 samples, 40 in the last third) against 17 for 1024-point cells; they are appended to one list through
+//     an LDS counter, wave 0 ranks them and finds the longest clear prefix as in rl_main_kernel.
+// Exact for the same reason as the other bucketed kernels (box distance in the point distance's association is a
+// lower bound of every computed distance; stale bounds stay bounds).
+constexpr int FL_R = 16;                 // points per bucket
+constexpr int FL_TP = 64 * FL_R;         // points per tile
+constexpr int FL_CAP = 64;               // candidates (= samples) per round
+constexpr int FL_EW = 8;                 // words per candidate entry (5 used)
+
+struct FlShared {
+    FmHeader h[2][16];
+    uint32_t cand[2][FL_CAP * FL_EW];
+    float pick[2][FL_CAP][4];       // the round's samples in rank order: x, y, z, distance
+    uint32_t pkey[2][FL_CAP];
+    int mrow[FL_CAP];
+    int npick[2];
+    int ncand[2];
+    uint32_t minkey;                // arg-max with the tie rule (ties at the top)
+    unsigned long long stat[8];     // rounds, samples, overflow rounds, tie rounds; wave 0's cycles in apply,
+                                    // collecting candidates (incl. its barriers), ranking; tile visits of wave 0
+};
+
+constexpr size_t fl_lds_bytes(int ntile)
+{
+    return (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15) + sizeof(FlShared) + 64;
+}
+
+// bucket / tile records of the initial state: one wave per tile
+__global__ __launch_bounds__(64) void fl_init_kernel(FbArgs a0)
+{
+    const FbArgs a = fb_elem(a0, blockIdx.y);
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a0.ntile)
+        return;
+    float bl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float bh[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
+    uint32_t bkey = 0xFFFFFFFFu;
+    for (int j = 0; j < FL_R; ++j) {
+        const int w = (t * FL_R + j) * 64 + lane;
+        const float4 v = a.sp[w];
+        const uint32_t key = a.skey[w];
+        if (key != 0xFFFFFFFFu) {
+            bl[0] = fminf(bl[0], v.x); bl[1] = fminf(bl[1], v.y); bl[2] = fminf(bl[2], v.z);
+            bh[0] = fmaxf(bh[0], v.x); bh[1] = fmaxf(bh[1], v.y); bh[2] = fmaxf(bh[2], v.z);
+        }
+        const int tb = __float_as_int(v.w);
+        if (tb > best || (tb == best && key < bkey)) {
+            run = best; best = tb; bkey = key; arg = j;
+        } else {
+            run = max(run, tb);
+        }
+    }
+    uint32_t h[6];
+    for (int c = 0; c < 3; ++c) {
+        h[c] = __half_as_ushort(__float2half_rd(bl[c]));
+        h[3 + c] = __half_as_ushort(__float2half_ru(bh[c]));
+    }
+    const int b = t * 64 + lane;
+    a.rec[b] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), (uint32_t)run);
+    a.bm0[b] = best;
+    a.ba0[b] = (uint8_t)arg;
+    float tl[3], th[3];
+    for (int c = 0; c < 3; ++c) {
+        tl[c] = -tpu3_wave_max_f32(-bl[c]);
+        th[c] = tpu3_wave_max_f32(bh[c]);
+    }
+    const int tm = tpu3_wave_max_i32_fast(best), tr = tpu3_wave_max_i32_fast(run);
+    if (lane == 0) {
+        float *o = a.tt + t * 8;
+        o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = th[0]; o[4] = th[1]; o[5] = th[2];
+        o[6] = __int_as_float(tm); o[7] = __int_as_float(tr);
+    }
+}
+
+__global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    if (a.n <= 0 || a.m <= 0)
+        return;
+    const int ntile = (a.n + FL_TP - 1) / FL_TP;            // live tiles of this element
+    int *bmax = (int *)smem;
+    uint8_t *barg = (uint8_t *)(bmax + a0.ntile * 64);
+    FlShared &sh = *(FlShared *)(smem + (((size_t)a0.ntile * 64 * 5 + 15) & ~(size_t)15));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = a.lb;
+    float4 *__restrict__ TP = a.sp;
+    const uint32_t *__restrict__ TK = a.skey;
+
+    for (int i = tid; i < ntile * 64; i += 1024) {
+        bmax[i] = a.bm0[i];
+        barg[i] = a.ba0[i];
+    }
+    // the tile of this lane's quad: slot = lane / 4 (16 tiles per wave), tile = slot * 16 + wave
+    const int slot = lane >> 2, quad = lane & 3;
+    const int tq = slot * 16 + wave;
+    const bool tvalid = tq < ntile;
+    float tbx[6];
+    int tmax = (int)0x80000000, trun = (int)0x80000000;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        tbx[c] = tvalid ? a.tt[tq * 8 + c] : __builtin_inff();
+    if (tvalid) {
+        tmax = __float_as_int(a.tt[tq * 8 + 6]);
+        trun = __float_as_int(a.tt[tq * 8 + 7]);
+    }
+    if (tid < 2)
+        sh.ncand[tid] = 0;
+    if (tid < 8)
+        sh.stat[tid] = 0;
+    const bool prof = a0.prof != nullptr && blockIdx.x == 0;
+    unsigned long long c_apply = 0, c_coll = 0, c_rank = 0, c_vis = 0, c0 = 0, c1 = 0;
+    if (tid == 0) {
+        a.idx[0] = 0;
+        sh.pick[1][0][0] = a.xyz[0]; sh.pick[1][0][1] = a.xyz[1]; sh.pick[1][0][2] = a.xyz[2];
+        sh.pick[1][0][3] = 0.f;
+    }
+    __syncthreads();
+    if (a.m <= 1)
+        return;                                     // the reference's loop body never runs: temp untouched
+
+    // pair (i < l) number `lane` of the l-major enumeration (wave 0's clearance test, first pass)
+    int pair_l = (int)((1.f + sqrtf(1.f + 8.f * (float)lane)) * 0.5f);
+    pair_l -= pair_l * (pair_l - 1) / 2 > lane ? 1 : 0;
+    pair_l += (pair_l + 1) * pair_l / 2 <= lane ? 1 : 0;
+    const int pair_i = lane - pair_l * (pair_l - 1) / 2;
+
+    auto quad_or = [](uint32_t v) __attribute__((always_inline)) {
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+        return v;
+    };
+
+    // ---- fold the first nj samples of pick[cur] into every bucket they reach ---------------------------------
+    auto apply = [&](int nj, int cur) __attribute__((always_inline)) {
+        // the round's samples against this quad's tile, four at a time
+        uint32_t mlo = 0, mhi = 0;
+        if (tvalid)
+            for (int i = quad; i < nj; i += 4) {
+                const float4 p = *(const float4 *)sh.pick[cur][i];
+                const bool hit = fb_dbox(p.x, p.y, p.z, tbx[0], tbx[1], tbx[2], tbx[3], tbx[4], tbx[5]) <
+                                 __int_as_float(tmax);
+                mlo |= (hit && i < 32) ? (1u << i) : 0u;
+                mhi |= (hit && i >= 32) ? (1u << (i - 32)) : 0u;
+            }
+        mlo = quad_or(mlo);
+        mhi = quad_or(mhi);
+        unsigned long long touched = __ballot((mlo | mhi) != 0 && quad == 0);
+        while (touched) {
+            const int L = __builtin_ctzll(touched);
+            touched &= touched - 1;
+            const int s = L >> 2, t = s * 16 + wave;
+            c_vis += 1;
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
+            const int b = t * 64 + lane;
+            const uint4 rc = a.rec[b];
+            const int bm = bmax[b];
+            const float lx = fb_half_lo(rc.x), ly = fb_half_hi(rc.x), lz = fb_half_lo(rc.y);
+            const float hx = fb_half_hi(rc.y), hy = fb_half_lo(rc.z), hz = fb_half_hi(rc.z);
+            bool reached = false;
+            for (unsigned long long sm = ((unsigned long long)shi << 32) | slo; sm; sm &= sm - 1) {
+                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
+                reached |= fb_dbox(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz) < __int_as_float(bm);
+            }
+            if (!__ballot(reached))
+                continue;
+            // the reached lanes' 16 points (coalesced: [tile][j][lane]); every sample of the tile is folded into
+            // every loaded bucket -- one that does not reach a bucket cannot lower any of its distances
+            float4 pt[FL_R];
+            float nt[FL_R];
+            const float4 *__restrict__ base = TP + (size_t)t * FL_R * 64 + lane;
+            if (reached) {
+#pragma unroll
+                for (int j = 0; j < FL_R; ++j)
+                    pt[j] = base[j * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < FL_R; ++j)
+                nt[j] = reached ? pt[j].w : 0.f;
+            for (unsigned long long sm = ((unsigned long long)shi << 32) | slo; sm; sm &= sm - 1) {
+                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
+                if (reached) {
+#pragma unroll
+                    for (int j = 0; j < FL_R; ++j)
+                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+                }
+            }
+            int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
+            if (reached) {
+#pragma unroll
+                for (int j = 0; j < FL_R; ++j) {
+                    const int tb = __float_as_int(nt[j]);
+                    asm("v_med3_i32 %0, %1, %2, %0" : "+v"(run) : "v"(best), "v"(tb));
+                    best = max(best, tb);
+                }
+#pragma unroll
+                for (int j = 0; j < FL_R; ++j)
+                    arg = __float_as_int(nt[j]) == best ? j : arg;
+            }
+            // equal maxima inside a bucket (duplicated points): the smallest tie key wins
+            if (__ballot(reached && run == best && best >= 0)) {
+                if (reached && run == best && best >= 0) {
+                    uint32_t bk = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < FL_R; ++j) {
+                        const uint32_t kj = TK[((size_t)t * FL_R + j) * 64 + lane];
+                        const bool take = __float_as_int(nt[j]) == best && kj < bk;
+                        bk = take ? kj : bk;
+                        arg = take ? j : arg;
+                    }
+                }
+            }
+            if (reached) {
+#pragma unroll
+                for (int j = 0; j < FL_R; ++j)
+                    if (nt[j] != pt[j].w)
+                        ((float *)(TP + ((size_t)t * FL_R + j) * 64 + lane))[3] = nt[j];
+                bmax[b] = best;
+                barg[b] = (uint8_t)arg;
+                ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
+            }
+            const int tm = tpu3_wave_max_i32_fast(reached ? best : bm);
+            const int tr = tpu3_wave_max_i32_fast(reached ? run : (int)rc.w);
+            if (slot == s) {
+                tmax = tm;
+                trun = tr;
+            }
+        }
+    };
+
+    int J = 1, r = 1;
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        if (prof) c0 = __builtin_amdgcn_s_memtime();
+        apply(J, par ^ 1);
+        if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_apply += c1 - c0; c0 = c1; }
+        // ---- select the next samples ---------------------------------------------------------------------
+        uint32_t *cl = sh.cand[par];
+        {
+            const int wv = tpu3_wave_max_i32_fast(tvalid ? tmax : (int)0x80000000);
+            const int wr = tpu3_wave_max_i32_fast(tvalid ? trun : (int)0x80000000);
+            if (lane == 0) {
+                sh.h[par][wave].best = wv;
+                sh.h[par][wave].rmax = wr;
+            }
+        }
+        __syncthreads();
+        const int sd = lane < 16 ? sh.h[par][lane].best : (int)0x80000000;
+        const int sr = lane < 16 ? sh.h[par][lane].rmax : (int)0x80000000;
+        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
+        const int rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+        bool ties_top = gbest <= rstar;             // no bucket beats every runner-up: plain arg-max, tie rule
+        int thr = rstar;
+        int total = 0;
+        for (;;) {
+            // the buckets with bmax > thr (ties_top: == gbest) of this wave's tiles
+            unsigned long long tl = __ballot(tvalid && quad == 0 && (ties_top ? tmax == gbest : tmax > thr));
+            if (ties_top) {
+                if (tid == 0)
+                    sh.minkey = 0xFFFFFFFFu;
+                __syncthreads();
+            }
+            while (tl) {
+                const int L = __builtin_ctzll(tl);
+                tl &= tl - 1;
+                const int t = (L >> 2) * 16 + wave, b = t * 64 + lane;
+                const int bm = bmax[b];
+                const bool c = ties_top ? bm == gbest : bm > thr;
+                const unsigned long long cm = __ballot(c);
+                if (!cm)
+                    continue;
+                if (ties_top) {
+                    if (c)
+                        atomicMin(&sh.minkey, TK[((size_t)t * FL_R + barg[b]) * 64 + lane]);
+                    continue;
+                }
+                // (no memory access here: an entry is the maximum and the bucket; wave 0 fetches the coordinates of
+                // the ranked list in one round trip -- with the point loads in this loop every wave paid a dependent
+                // L2 trip per candidate tile, 33 k cycles of a 61 k round)
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&sh.ncand[par], (int)__builtin_popcountll(cm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                if (c && pos < FL_CAP) {
+                    cl[pos * 2] = (uint32_t)bm;
+                    cl[pos * 2 + 1] = ((uint32_t)b << 4) | barg[b];
+                }
+            }
+            __syncthreads();
+            if (ties_top) {
+                // second sweep: the bucket holding the smallest key among the maxima enters, alone
+                const uint32_t mk = sh.minkey;
+                unsigned long long t2 = __ballot(tvalid && quad == 0 && tmax == gbest);
+                while (t2) {
+                    const int L = __builtin_ctzll(t2);
+                    t2 &= t2 - 1;
+                    const int t = (L >> 2) * 16 + wave, b = t * 64 + lane;
+                    if (bmax[b] == gbest) {
+                        const size_t w = ((size_t)t * FL_R + barg[b]) * 64 + lane;
+                        if (TK[w] == mk) {
+                            cl[0] = (uint32_t)gbest;
+                            cl[1] = ((uint32_t)b << 4) | barg[b];
+                        }
+                    }
+                }
+                __syncthreads();
+                total = 1;
+                break;
+            }
+            total = sh.ncand[par];
+            if (total <= FL_CAP)
+                break;
+            // more candidates than the list holds: raise the threshold (any threshold >= R* is valid) and collect again
+            __syncthreads();
+            if (tid == 0) {
+                sh.ncand[par] = 0;
+                sh.stat[2] += 1;
+            }
+            if (gbest - thr <= 1)
+                ties_top = true;
+            else
+                thr += (gbest - thr) >> 1;
+            __syncthreads();
+        }
+        if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_coll += c1 - c0; c0 = c1; }
+        // wave 0 ranks the candidates; the others wait at the barrier and read the round's samples from LDS
+        const int left = a.m - r;
+        if (wave == 0) {
+            const bool live = lane < total;
+            const int cM = live ? (int)cl[(lane & (FL_CAP - 1)) * 2] : (int)0x80000000;
+            const uint32_t cB = cl[(lane & (FL_CAP - 1)) * 2 + 1];
+            // slot of the candidate's point: bucket b = tile * 64 + lane', position cB & 15
+            auto slot_of = [](uint32_t w) __attribute__((always_inline)) {
+                const uint32_t b = w >> 4;
+                return ((size_t)(b >> 6) * FL_R + (w & 15)) * 64 + (b & 63);
+            };
+            int rank = 0;
+            bool tie = false;
+            sh.mrow[lane & (FL_CAP - 1)] = cM;
+            for (int c0 = 0; c0 < total; c0 += 16) {
+                int4 mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    mv[u] = *(const int4 *)(sh.mrow + c0 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m4[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        rank += m4[v] > cM ? 1 : 0;
+                        tie |= m4[v] == cM && c0 + 4 * u + v != lane;
+                    }
+                }
+            }
+            if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
+                const uint32_t cK = live ? TK[slot_of(cB)] : 0xFFFFFFFFu;
+                sh.pkey[par][lane & (FL_CAP - 1)] = cK;
+                rank = 0;
+                for (int i = 0; i < total; ++i) {
+                    const int mi = sh.mrow[i];
+                    const uint32_t ki = sh.pkey[par][i];
+                    rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
+                }
+                if (lane == 0) sh.stat[3] += 1;
+            }
+            // into rank order, then ONE round trip for the coordinates and keys of the whole list
+            if (live)
+                cl[2 * FL_CAP + rank] = cB;
+            const uint32_t sB = cl[2 * FL_CAP + (lane & (FL_CAP - 1))];
+            const size_t sw = live ? slot_of(sB) : 0;
+            const float4 sp4 = TP[sw];
+            const uint32_t okey = TK[sw];
+            if (live)
+                *(float4 *)sh.pick[par][lane] = sp4;            // (.w = the running distance = the bucket's maximum)
+            int jmax = total < left ? total : left;
+            // longest prefix in which no member lies inside the update ball of an earlier member, all pairs (i < l),
+            // 64 per pass in l-major order: the first pass with a hit holds the smallest l
+            const int npair = jmax * (jmax - 1) / 2;
+            for (int t0 = 0; t0 < npair; t0 += 64) {
+                int pl = pair_l, pi = pair_i;
+                if (t0) {
+                    const int t = t0 + lane;
+                    pl = (int)((1.f + sqrtf(1.f + 8.f * (float)t)) * 0.5f);
+                    pl -= pl * (pl - 1) / 2 > t ? 1 : 0;
+                    pl += (pl + 1) * pl / 2 <= t ? 1 : 0;
+                    pi = t - pl * (pl - 1) / 2;
+                }
+                const bool ok = pl < jmax;
+                const float4 L4 = *(const float4 *)sh.pick[par][ok ? pl : 0];
+                const float4 I4 = *(const float4 *)sh.pick[par][ok ? pi : 0];
+                const float d = tpu3_sqdist3(L4.x - I4.x, L4.y - I4.y, L4.z - I4.z);
+                const unsigned long long hit = __ballot(ok && d < L4.w);
+                if (hit) {
+                    jmax = __builtin_amdgcn_readlane(pl, (int)__builtin_ctzll(hit));
+                    break;
+                }
+            }
+            if (lane < jmax)
+                a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
+            if (lane == 0) {
+                sh.npick[par] = jmax;
+                sh.ncand[par ^ 1] = 0;
+                sh.stat[0] += 1;
+                sh.stat[1] += (unsigned long long)jmax;
+            }
+        }
+        if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_rank += c1 - c0; c0 = c1; }
+        __syncthreads();
+        J = sh.npick[par];
+        r += J;
+        if (r >= a.m) {
+            if (J > 1)
+                apply(J - 1, par);                  // every sample but the last one updates `temp`
+            break;
+        }
+    }
+    if (prof && tid == 0) {
+        sh.stat[4] = c_apply; sh.stat[5] = c_coll; sh.stat[6] = c_rank; sh.stat[7] = c_vis;
+        for (int i = 0; i < 8; ++i)
+            a0.prof[i] = sh.stat[i];
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
@@ -1557,6 +2023,9 @@ constexpr int RB_MAX_N = 16 * 64 * 25;     // 25 rows per wave
 struct FbPlan {
     int ppl, nw, ngpt, nb, nbpad, npad, ng, ncell;
     bool l3;              // three levels: LDS cells of 16 leaf buckets, leaf table in global memory
+    bool fl;              // tile form (fl_main_kernel): a lane per 16-point bucket, points in memory
+    int ntile;            // tiles of 1024 points (fl)
+    size_t fl_rec, fl_bm, fl_ba, fl_tt;     // byte sizes of the tile form's record arrays
     int rb_rows;          // > 0: register-resident kernel with this many rows per wave
     bool segmented;       // one segmented sort for the batch instead of a device sort per element
     bool global64;        // large sets, several elements: one device sort on (element << 32 | key)
@@ -1610,11 +2079,23 @@ bool fb_plan(int b, int n, FbPlan &p)
     }
     p.ng = p.ncell / FB_GS;
     p.npad = p.nb * bsz;
+    // 25 601 .. 262 144 points: the tile form (TPU3_FL=0: tuning hook, the 64-point-bucket kernel instead)
+    static const int use_fl = getenv("TPU3_FL") ? atoi(getenv("TPU3_FL")) : 1;
+    p.fl = use_fl && !p.rb_rows && !p.l3;
+    p.ntile = (n + FL_TP - 1) / FL_TP;
+    p.fl_rec = p.fl_bm = p.fl_ba = p.fl_tt = 0;
+    if (p.fl) {
+        p.npad = p.ntile * FL_TP;
+        p.fl_rec = align256((size_t)p.ntile * 64 * sizeof(uint4));
+        p.fl_bm = align256((size_t)p.ntile * 64 * sizeof(int32_t));
+        p.fl_ba = align256((size_t)p.ntile * 64);
+        p.fl_tt = align256((size_t)p.ntile * 8 * sizeof(float));
+    }
     p.ngpt = (p.ng + p.nw * 64 - 1) / (p.nw * 64);          // 1 for ng <= 256
     p.ks = align256(sizeof(uint32_t) * (size_t)n);
     p.ps = align256(sizeof(float) * (size_t)p.npad);
     p.bs = align256(sizeof(uint32_t) * (size_t)p.nbpad);
-    p.per_elem = 5 * p.ps + 9 * p.bs + align256(8 * sizeof(float));
+    p.per_elem = 5 * p.ps + 9 * p.bs + align256(8 * sizeof(float)) + p.fl_rec + p.fl_bm + p.fl_ba + p.fl_tt;
     p.segmented = b >= 4 && n <= 65536 && (size_t)b * (p.ks / 4) < 0x7FFFFFFFu;
     p.global64 = !p.segmented && b >= 2;
     p.ebits = 1;
@@ -1649,6 +2130,9 @@ hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 // development probe: two device words that the register-resident multi-sample kernel of the NEXT call fills with
 // (rounds, samples) of its first set, see tpu3_debug_fps_level_stats
 unsigned long long *g_level_stats = nullptr;
+// development probe: four device words the NEXT tile-form launch fills with (rounds, samples, overflow rounds, tie
+// rounds) of its first set, see tpu3_debug_fps_tile_stats
+unsigned long long *g_tile_stats = nullptr;
 
 template <int PPL, bool PROF>
 int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
@@ -1703,6 +2187,15 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     a0.bbox = (float *)(slabs + 5 * p.ps + 9 * p.bs);
     a0.per_elem = p.per_elem;
     a0.sort_stride = p.ks / 4;
+    a0.fl = (p.fl && !prof) ? 1 : 0;
+    a0.ntile = p.ntile;
+    {
+        char *f = slabs + 5 * p.ps + 9 * p.bs + align256(8 * sizeof(float));
+        a0.rec = (uint4 *)f;
+        a0.bm0 = (int32_t *)(f + p.fl_rec);
+        a0.ba0 = (uint8_t *)(f + p.fl_rec + p.fl_bm);
+        a0.tt = (float *)(f + p.fl_rec + p.fl_bm + p.fl_ba);
+    }
 
     hipLaunchKernelGGL(fb_bbox_kernel, dim3(b), dim3(1024), 0, s, a0);
     hipLaunchKernelGGL(fb_morton_kernel, dim3((unsigned)((a0.sort_stride + 255) / 256), b), dim3(256), 0, s, a0, k_in,
@@ -1773,6 +2266,27 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
         return tpu3_launch_status();
     }
+    if (a0.fl) {
+        // a lane per 16-point bucket, 1024-point tiles (fl_main_kernel)
+        a0.prof = g_tile_stats;
+        g_tile_stats = nullptr;
+        hipLaunchKernelGGL(fl_init_kernel, dim3(p.ntile, b), dim3(64), 0, s, a0);
+        const size_t lds = fl_lds_bytes(p.ntile);
+        const hipError_t e = hipFuncSetAttribute((const void *)fl_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds);
+        if (e != hipSuccess)
+            return (int)e;
+        const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
+        g_ev_start = g_ev_stop = nullptr;
+        if (e0) (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(fl_main_kernel, dim3(b), dim3(1024), lds, s, a0);
+        if (e1) (void)hipEventRecord(e1, s);
+        const int r = tpu3_launch_status();
+        if (r)
+            return r;
+        hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);
+        return tpu3_launch_status();
+    }
     hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
     const int r = prof ? fb_launch_main<1, true>(s, b, a0, p) : fb_launch_main<1, false>(s, b, a0, p);
     if (r)
@@ -1810,6 +2324,12 @@ extern "C" int tpu3_debug_fps_bucket_events(void *start, void *stop)
 extern "C" int tpu3_debug_fps_level_stats(unsigned long long *stats)
 {
     g_level_stats = stats;
+    return TPU3_OK;
+}
+
+extern "C" int tpu3_debug_fps_tile_stats(unsigned long long *stats)
+{
+    g_tile_stats = stats;
     return TPU3_OK;
 }
 
