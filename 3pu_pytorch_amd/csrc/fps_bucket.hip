@@ -57,8 +57,8 @@ struct FbArgs {
     size_t per_elem;
     size_t sort_stride;
     unsigned long long *prof;   // PROF builds only
-    // (r3) tile form (fl_main_kernel): sp / skey hold the Morton order TRANSPOSED per 1024-point tile
-    // ([tile][point j of the bucket][lane = bucket]); one record per 16-point bucket and per tile
+    // (r3) tile form (fl_main_kernel): a bucket = 16 consecutive slots of sp / skey, a tile = 64 buckets; one record
+    // per bucket and per tile
     int fl, ntile;              // fl != 0: tile form; tiles of the slab (upper bound of the live count)
     uint4 *rec;                 // (ntile * 64) bucket records: fp16 box (3 words) | runner-up distance bits
     int32_t *bm0;               // (ntile * 64) initial bucket maxima (distance bits)
@@ -171,12 +171,6 @@ __global__ __launch_bounds__(256) void fb_morton_kernel(FbArgs a0, uint32_t *__r
     put(code);
 }
 
-// tile form: slot of Morton position i -- tile i / 1024, bucket (= lane) (i / 16) % 64, point i % 16 of the bucket
-__device__ __forceinline__ int fl_pos(int i)
-{
-    return (((i >> 10) * 16 + (i & 15)) << 6) + ((i >> 4) & 63);
-}
-
 // Morton-ordered float4 (x,y,z,temp) + tie keys; slots past n repeat the last live point with temp = -1
 __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32_t *__restrict__ order0)
 {
@@ -188,7 +182,7 @@ __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32
         return;
     const bool live = i < a.n;
     const uint32_t o = order[live ? i : a.n - 1];
-    const int w = a0.fl ? fl_pos(i) : i;
+    const int w = i;
     a.sp[w] = make_float4(a.xyz[(size_t)o * 3 + 0], a.xyz[(size_t)o * 3 + 1], a.xyz[(size_t)o * 3 + 2],
                           live ? a.temp[o] : -1.0f);
     a.skey[w] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
@@ -198,7 +192,7 @@ __global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a0)
 {
     const FbArgs a = fb_elem(a0, blockIdx.y);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int w = a0.fl ? fl_pos(i) : i;
+    const int w = i;
     if (i < a.n && a.m > 0)
         a.temp[tpu3_fps_tiekey_to_index(a.skey[w], a.lb)] = a.sp[w].w;
 }
@@ -1580,14 +1574,14 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
 // lane-per-bucket layout buys on sets that fit the register file; this is the same scheme with the points in
 // memory:
 //   * a BUCKET is 16 Morton-consecutive points owned by a lane, a TILE 64 buckets (1024 points) owned by a wave
-//     (tile t belongs to wave t % 16).  The slab is stored transposed per tile ([tile][point j][lane]): the 16
-//     float4 loads of a reached tile are coalesced, and only the lanes whose bucket a sample reaches load at all;
+//     (tile t belongs to wave t % 16): a bucket is 256 contiguous bytes of the Morton-ordered slab;
 //   * per bucket: the maximum running distance and the position of that point live in LDS (5 bytes per bucket,
 //     80 KB at 262 144 points), the fp16 box and the runner-up in a 16-byte global record read when the bucket's
 //     tile is reached; per tile: box, maximum and runner-up bound in the registers of four lanes of the owner wave,
 //     which test the round's samples against it four at a time;
-//   * a reached lane updates its 16 distances with plain per-lane arithmetic and re-derives its record -- no
-//     cross-lane reduction except the tile's two maxima;
+//   * the reached buckets of a round (a handful per tile, found by the owner wave with a lane per bucket) go on one
+//     work list and are updated by a DPP ROW each, a lane per point, dealt over all waves; only when a sample's
+//     ball covers most of a tile (the first rounds) the owner updates it on the spot with a lane per bucket;
 //   * candidates are BUCKETS (bmax > R*, R* = the largest runner-up of any bucket, fresh): 16-point cells admit
 //     ~35-40 samples per round on the metric's cloud (tools/fps_cells_sim.py: 20.8 on average over the first
 //     12 000 samples, 40 in the last third) against 17 for 1024-point cells; they are appended to one list through
@@ -1598,6 +1592,8 @@ constexpr int FL_R = 16;                 // points per bucket
 constexpr int FL_TP = 64 * FL_R;         // points per tile
 constexpr int FL_CAP = 64;               // candidates (= samples) per round
 constexpr int FL_EW = 8;                 // words per candidate entry (5 used)
+constexpr int FL_WORK = 4096;            // work list entries: fewer than FL_DENSE reached buckets per tile x 256 tiles
+constexpr int FL_DENSE = 16;             // a tile with this many reached buckets is updated on the spot
 
 struct FlShared {
     FmHeader h[2][16];
@@ -1608,13 +1604,14 @@ struct FlShared {
     int npick[2];
     int ncand[2];
     uint32_t minkey;                // arg-max with the tie rule (ties at the top)
+    int nwork;                      // entries on the work list
     unsigned long long stat[8];     // rounds, samples, overflow rounds, tie rounds; wave 0's cycles in apply,
                                     // collecting candidates (incl. its barriers), ranking; tile visits of wave 0
 };
 
 constexpr size_t fl_lds_bytes(int ntile)
 {
-    return (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15) + sizeof(FlShared) + 64;
+    return (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15) + 512 * 4 + (size_t)FL_WORK * 12 + sizeof(FlShared) + 64;
 }
 
 // bucket / tile records of the initial state: one wave per tile
@@ -1629,7 +1626,7 @@ __global__ __launch_bounds__(64) void fl_init_kernel(FbArgs a0)
     int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
     uint32_t bkey = 0xFFFFFFFFu;
     for (int j = 0; j < FL_R; ++j) {
-        const int w = (t * FL_R + j) * 64 + lane;
+        const int w = (t * 64 + lane) * FL_R + j;
         const float4 v = a.sp[w];
         const uint32_t key = a.skey[w];
         if (key != 0xFFFFFFFFu) {
@@ -1665,6 +1662,7 @@ __global__ __launch_bounds__(64) void fl_init_kernel(FbArgs a0)
     }
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1674,7 +1672,10 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
     const int ntile = (a.n + FL_TP - 1) / FL_TP;            // live tiles of this element
     int *bmax = (int *)smem;
     uint8_t *barg = (uint8_t *)(bmax + a0.ntile * 64);
-    FlShared &sh = *(FlShared *)(smem + (((size_t)a0.ntile * 64 * 5 + 15) & ~(size_t)15));
+    int *tmx = (int *)(smem + (((size_t)a0.ntile * 64 * 5 + 15) & ~(size_t)15));        // tile maxima, [256]
+    int *trn = tmx + 256;                                                               // tile runner-up bounds
+    uint32_t *work = (uint32_t *)(trn + 256);                                           // [FL_WORK][3]
+    FlShared &sh = *(FlShared *)(work + FL_WORK * 3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = a.lb;
     float4 *__restrict__ TP = a.sp;
@@ -1689,20 +1690,22 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
     const int tq = slot * 16 + wave;
     const bool tvalid = tq < ntile;
     float tbx[6];
-    int tmax = (int)0x80000000, trun = (int)0x80000000;
 #pragma unroll
     for (int c = 0; c < 6; ++c)
         tbx[c] = tvalid ? a.tt[tq * 8 + c] : __builtin_inff();
-    if (tvalid) {
-        tmax = __float_as_int(a.tt[tq * 8 + 6]);
-        trun = __float_as_int(a.tt[tq * 8 + 7]);
+    if (tid < 256) {
+        tmx[tid] = tid < ntile ? __float_as_int(a.tt[tid * 8 + 6]) : (int)0x80000000;
+        trn[tid] = tid < ntile ? __float_as_int(a.tt[tid * 8 + 7]) : (int)0x80000000;
     }
     if (tid < 2)
         sh.ncand[tid] = 0;
+    if (tid == 0)
+        sh.nwork = 0;
     if (tid < 8)
         sh.stat[tid] = 0;
-    const bool prof = a0.prof != nullptr && blockIdx.x == 0;
+    const bool prof = PROF && a0.prof != nullptr && blockIdx.x == 0;
     unsigned long long c_apply = 0, c_coll = 0, c_rank = 0, c_vis = 0, c0 = 0, c1 = 0;
+    unsigned long long c_p1 = 0, c_b1 = 0, c_p2 = 0, c_b2 = 0, d0 = 0, d1 = 0;
     if (tid == 0) {
         a.idx[0] = 0;
         sh.pick[1][0][0] = a.xyz[0]; sh.pick[1][0][1] = a.xyz[1]; sh.pick[1][0][2] = a.xyz[2];
@@ -1724,102 +1727,197 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         return v;
     };
 
+    // ---- one bucket (the lane's): fold the samples of `sm` into its 16 distances, re-derive its record -----------
+    // (wave-uniform control flow around it; `act` = this lane has a bucket to update)
+    auto update_bucket = [&](bool act, int b, unsigned long long sm0, int cur, int &best, int &run)
+        __attribute__((always_inline)) {
+        // (two halves of 8 points: all 16 float4 at once cost 28 spilled registers in the whole kernel)
+        float4 *__restrict__ base = TP + (size_t)b * FL_R;
+        int arg = 0;
+        best = (int)0x80000000; run = (int)0x80000000;
+#pragma unroll 1
+        for (int h = 0; h < FL_R; h += 8) {
+            float4 pt[8];
+            float nt[8];
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    pt[j] = base[h + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                nt[j] = act ? pt[j].w : 0.f;
+            for (unsigned long long sm = sm0; sm; sm &= sm - 1) {
+                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tb = __float_as_int(nt[j]);
+                    asm("v_med3_i32 %0, %1, %2, %0" : "+v"(run) : "v"(best), "v"(tb));
+                    arg = tb > best ? h + j : arg;          // (first of equal maxima; ties are settled below)
+                    best = max(best, tb);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (nt[j] != pt[j].w)
+                        ((float *)(base + h + j))[3] = nt[j];
+            }
+        }
+        // equal maxima inside a bucket (duplicated points): the smallest tie key wins
+        if (__ballot(act && run == best && best >= 0)) {
+            if (act && run == best && best >= 0) {
+                uint32_t bk = 0xFFFFFFFFu;
+                for (int j = 0; j < FL_R; ++j) {
+                    const uint32_t kj = TK[(size_t)b * FL_R + j];
+                    const bool take = __float_as_int(base[j].w) == best && kj < bk;
+                    bk = take ? kj : bk;
+                    arg = take ? j : arg;
+                }
+            }
+        }
+        if (act) {
+            bmax[b] = best;
+            barg[b] = (uint8_t)arg;
+            ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
+        }
+    };
+
     // ---- fold the first nj samples of pick[cur] into every bucket they reach ---------------------------------
+    // Two phases.  (1) every wave walks the tiles of its own that a sample may reach: bucket records, box tests;
+    // the few reached buckets of a tile go on ONE work list (bucket, its samples); a tile with many reached buckets
+    // -- the first rounds, when a sample's ball covers the whole cloud -- is updated on the spot, a lane per bucket.
+    // (2) the list is worked off 64 entries per wave pass, a lane per entry: the lanes of a pass all have a bucket
+    // to update.  (A first version updated every reached tile on the spot: 2-4 of 64 lanes had anything to do, and
+    // the 70 tile visits of a round saturated the compute unit's VALU: 19-35 k cycles per round and wave.)
     auto apply = [&](int nj, int cur) __attribute__((always_inline)) {
-        // the round's samples against this quad's tile, four at a time
         uint32_t mlo = 0, mhi = 0;
-        if (tvalid)
+        if (prof) d0 = __builtin_amdgcn_s_memtime();
+        if (tvalid) {
+            const float tmf = __int_as_float(tmx[tq]);
             for (int i = quad; i < nj; i += 4) {
                 const float4 p = *(const float4 *)sh.pick[cur][i];
-                const bool hit = fb_dbox(p.x, p.y, p.z, tbx[0], tbx[1], tbx[2], tbx[3], tbx[4], tbx[5]) <
-                                 __int_as_float(tmax);
+                const bool hit = fb_dbox(p.x, p.y, p.z, tbx[0], tbx[1], tbx[2], tbx[3], tbx[4], tbx[5]) < tmf;
                 mlo |= (hit && i < 32) ? (1u << i) : 0u;
                 mhi |= (hit && i >= 32) ? (1u << (i - 32)) : 0u;
             }
+        }
         mlo = quad_or(mlo);
         mhi = quad_or(mhi);
+        // (dealing the reached tiles out over all waves through a visit list, with the records of four visits in
+        // flight, was measured: 49.6 vs 45.1 ms -- the phase is bound by the compute unit's VALU throughput, ~100
+        // instructions per visit and 70 visits per round, not by which wave runs them)
         unsigned long long touched = __ballot((mlo | mhi) != 0 && quad == 0);
         while (touched) {
             const int L = __builtin_ctzll(touched);
             touched &= touched - 1;
-            const int s = L >> 2, t = s * 16 + wave;
-            c_vis += 1;
+            const int t = (L >> 2) * 16 + wave;
+            if (PROF) c_vis += 1;
             const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
             const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
+            const unsigned long long smt = ((unsigned long long)shi << 32) | slo;
             const int b = t * 64 + lane;
             const uint4 rc = a.rec[b];
             const int bm = bmax[b];
             const float lx = fb_half_lo(rc.x), ly = fb_half_hi(rc.x), lz = fb_half_lo(rc.y);
             const float hx = fb_half_hi(rc.y), hy = fb_half_lo(rc.z), hz = fb_half_hi(rc.z);
-            bool reached = false;
-            for (unsigned long long sm = ((unsigned long long)shi << 32) | slo; sm; sm &= sm - 1) {
-                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
-                reached |= fb_dbox(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz) < __int_as_float(bm);
+            unsigned long long mine = 0;            // the samples that reach THIS lane's bucket
+            for (unsigned long long sm = smt; sm; sm &= sm - 1) {
+                const int i = __builtin_ctzll(sm);
+                const float4 p = *(const float4 *)sh.pick[cur][i];
+                mine |= fb_dbox(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz) < __int_as_float(bm) ? (1ull << i) : 0ull;
             }
-            if (!__ballot(reached))
+            const bool reached = mine != 0;
+            const unsigned long long rm = __ballot(reached);
+            if (!rm)
                 continue;
-            // the reached lanes' 16 points (coalesced: [tile][j][lane]); every sample of the tile is folded into
-            // every loaded bucket -- one that does not reach a bucket cannot lower any of its distances
-            float4 pt[FL_R];
-            float nt[FL_R];
-            const float4 *__restrict__ base = TP + (size_t)t * FL_R * 64 + lane;
-            if (reached) {
-#pragma unroll
-                for (int j = 0; j < FL_R; ++j)
-                    pt[j] = base[j * 64];
-            }
-#pragma unroll
-            for (int j = 0; j < FL_R; ++j)
-                nt[j] = reached ? pt[j].w : 0.f;
-            for (unsigned long long sm = ((unsigned long long)shi << 32) | slo; sm; sm &= sm - 1) {
-                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
-                if (reached) {
-#pragma unroll
-                    for (int j = 0; j < FL_R; ++j)
-                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+            const int nreach = __builtin_popcountll(rm);
+            if (nreach >= FL_DENSE) {
+                int best, run;
+                update_bucket(reached, b, smt, cur, best, run);
+                int tm = reached ? best : bm, tr = reached ? run : (int)rc.w;
+                tpu3_wave_max_i32_fast_x2(tm, tr);
+                if (lane == 0) {
+                    tmx[t] = tm;
+                    trn[t] = tr;
                 }
+                continue;
             }
-            int best = (int)0x80000000, run = (int)0x80000000, arg = 0;
+            // the tile's maxima over the buckets NOT reached; phase 2 adds the reached ones' (atomic max)
+            int um = reached ? (int)0x80000000 : bm, ur = reached ? (int)0x80000000 : (int)rc.w;
+            tpu3_wave_max_i32_fast_x2(um, ur);
+            int base = 0;
+            if (lane == 0) {
+                tmx[t] = um;
+                trn[t] = ur;
+                base = atomicAdd(&sh.nwork, nreach);
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
             if (reached) {
-#pragma unroll
-                for (int j = 0; j < FL_R; ++j) {
-                    const int tb = __float_as_int(nt[j]);
-                    asm("v_med3_i32 %0, %1, %2, %0" : "+v"(run) : "v"(best), "v"(tb));
-                    best = max(best, tb);
-                }
-#pragma unroll
-                for (int j = 0; j < FL_R; ++j)
-                    arg = __float_as_int(nt[j]) == best ? j : arg;
-            }
-            // equal maxima inside a bucket (duplicated points): the smallest tie key wins
-            if (__ballot(reached && run == best && best >= 0)) {
-                if (reached && run == best && best >= 0) {
-                    uint32_t bk = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int j = 0; j < FL_R; ++j) {
-                        const uint32_t kj = TK[((size_t)t * FL_R + j) * 64 + lane];
-                        const bool take = __float_as_int(nt[j]) == best && kj < bk;
-                        bk = take ? kj : bk;
-                        arg = take ? j : arg;
-                    }
-                }
-            }
-            if (reached) {
-#pragma unroll
-                for (int j = 0; j < FL_R; ++j)
-                    if (nt[j] != pt[j].w)
-                        ((float *)(TP + ((size_t)t * FL_R + j) * 64 + lane))[3] = nt[j];
-                bmax[b] = best;
-                barg[b] = (uint8_t)arg;
-                ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
-            }
-            const int tm = tpu3_wave_max_i32_fast(reached ? best : bm);
-            const int tr = tpu3_wave_max_i32_fast(reached ? run : (int)rc.w);
-            if (slot == s) {
-                tmax = tm;
-                trun = tr;
+                uint32_t *e = work + 3 * (base + __builtin_popcountll(rm & ((1ull << lane) - 1ull)));
+                e[0] = (uint32_t)b; e[1] = (uint32_t)mine; e[2] = (uint32_t)(mine >> 32);
             }
         }
+        if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_p1 += d1 - d0; d0 = d1; }
+        __syncthreads();
+        if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_b1 += d1 - d0; d0 = d1; }
+        // phase 2: a DPP row of 16 lanes per listed bucket, a lane per point -- one coalesced 256-byte read per
+        // bucket, seven instructions per sample, the record by row reductions; four buckets per wave step, the
+        // steps dealt over the 16 waves (a lane per bucket here took 800 instructions for ONE pass, 8 k cycles in a
+        // lone wave: the sixteen points of a bucket are the parallelism a few reached buckets have)
+        const int E = sh.nwork;
+        const int row = lane >> 4, col = lane & 15;
+        for (int e0 = wave * 4; e0 < E; e0 += 64) {
+            const bool act = e0 + row < E;
+            const uint32_t *e = work + 3 * (act ? e0 + row : 0);
+            const int b = (int)e[0];
+            unsigned long long mine = act ? (((unsigned long long)e[2] << 32) | e[1]) : 0ull;
+            float4 *__restrict__ pp = TP + (size_t)b * FL_R + col;
+            const float4 pt = *pp;
+            float nt = pt.w;
+            while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
+                const bool go = mine != 0;
+                const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
+                mine &= mine - 1;
+                const float d = fminf(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
+                nt = go ? d : nt;
+            }
+            const int tb = act ? __float_as_int(nt) : (int)0x80000000;
+            const int best = tpu3_row_max_i32_fast(tb);
+            // the winner: the only lane at the maximum, or -- duplicated points -- the one with the smallest tie key
+            unsigned long long tie = __ballot(act && tb == best);
+            const unsigned long long rowm = 0xFFFFull << (row * 16);
+            bool single = true;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                single &= __builtin_popcountll(tie & (0xFFFFull << (rr * 16))) <= 1;
+            if (!single) {
+                const uint32_t kj = act && tb == best ? TK[(size_t)b * FL_R + col] : 0xFFFFFFFFu;
+                const uint32_t km = tpu3_row_min_u32(kj);
+                tie = __ballot(act && tb == best && kj == km);
+            }
+            const bool winner = act && ((tie >> lane) & 1ull) != 0 && (tie & rowm & ((1ull << lane) - 1ull)) == 0;
+            const int run = tpu3_row_max_i32_fast(winner || !act ? (int)0x80000000 : tb);
+            if (act && nt != pt.w)
+                ((float *)pp)[3] = nt;
+            if (winner) {
+                bmax[b] = best;
+                barg[b] = (uint8_t)col;
+                ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
+                atomicMax(&tmx[b >> 6], best);
+                atomicMax(&trn[b >> 6], run);
+            }
+        }
+        if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_p2 += d1 - d0; d0 = d1; }
+        __syncthreads();
+        if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_b2 += d1 - d0; d0 = d1; }
+        if (tid == 0)
+            sh.nwork = 0;
     };
 
     int J = 1, r = 1;
@@ -1830,19 +1928,19 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_apply += c1 - c0; c0 = c1; }
         // ---- select the next samples ---------------------------------------------------------------------
         uint32_t *cl = sh.cand[par];
+        // (every wave reduces the 256 tile records itself: they are final behind apply()'s last barrier)
+        int gbest, rstar;
         {
-            const int wv = tpu3_wave_max_i32_fast(tvalid ? tmax : (int)0x80000000);
-            const int wr = tpu3_wave_max_i32_fast(tvalid ? trun : (int)0x80000000);
-            if (lane == 0) {
-                sh.h[par][wave].best = wv;
-                sh.h[par][wave].rmax = wr;
+            int vm = (int)0x80000000, vr = (int)0x80000000;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vm = max(vm, tmx[i * 64 + lane]);
+                vr = max(vr, trn[i * 64 + lane]);
             }
+            gbest = tpu3_wave_max_i32_fast(vm);
+            rstar = tpu3_wave_max_i32_fast(vr);
         }
-        __syncthreads();
-        const int sd = lane < 16 ? sh.h[par][lane].best : (int)0x80000000;
-        const int sr = lane < 16 ? sh.h[par][lane].rmax : (int)0x80000000;
-        const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
-        const int rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
+        const int tmax = tvalid ? tmx[tq] : (int)0x80000000;
         bool ties_top = gbest <= rstar;             // no bucket beats every runner-up: plain arg-max, tie rule
         int thr = rstar;
         int total = 0;
@@ -1865,7 +1963,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     continue;
                 if (ties_top) {
                     if (c)
-                        atomicMin(&sh.minkey, TK[((size_t)t * FL_R + barg[b]) * 64 + lane]);
+                        atomicMin(&sh.minkey, TK[(size_t)b * FL_R + barg[b]]);
                     continue;
                 }
                 // (no memory access here: an entry is the maximum and the bucket; wave 0 fetches the coordinates of
@@ -1891,7 +1989,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     t2 &= t2 - 1;
                     const int t = (L >> 2) * 16 + wave, b = t * 64 + lane;
                     if (bmax[b] == gbest) {
-                        const size_t w = ((size_t)t * FL_R + barg[b]) * 64 + lane;
+                        const size_t w = (size_t)b * FL_R + barg[b];
                         if (TK[w] == mk) {
                             cl[0] = (uint32_t)gbest;
                             cl[1] = ((uint32_t)b << 4) | barg[b];
@@ -1924,11 +2022,8 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             const bool live = lane < total;
             const int cM = live ? (int)cl[(lane & (FL_CAP - 1)) * 2] : (int)0x80000000;
             const uint32_t cB = cl[(lane & (FL_CAP - 1)) * 2 + 1];
-            // slot of the candidate's point: bucket b = tile * 64 + lane', position cB & 15
-            auto slot_of = [](uint32_t w) __attribute__((always_inline)) {
-                const uint32_t b = w >> 4;
-                return ((size_t)(b >> 6) * FL_R + (w & 15)) * 64 + (b & 63);
-            };
+            // slot of the candidate's point: 16 b + position = the entry's second word itself
+            auto slot_of = [](uint32_t w) __attribute__((always_inline)) { return (size_t)w; };   // 16 b + position
             int rank = 0;
             bool tie = false;
             sh.mrow[lane & (FL_CAP - 1)] = cM;
@@ -2013,6 +2108,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         sh.stat[4] = c_apply; sh.stat[5] = c_coll; sh.stat[6] = c_rank; sh.stat[7] = c_vis;
         for (int i = 0; i < 8; ++i)
             a0.prof[i] = sh.stat[i];
+        a0.prof[8] = c_p1; a0.prof[9] = c_b1; a0.prof[10] = c_p2; a0.prof[11] = c_b2;
     }
 }
 
@@ -2272,14 +2368,14 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         g_tile_stats = nullptr;
         hipLaunchKernelGGL(fl_init_kernel, dim3(p.ntile, b), dim3(64), 0, s, a0);
         const size_t lds = fl_lds_bytes(p.ntile);
-        const hipError_t e = hipFuncSetAttribute((const void *)fl_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lds);
+        void (*kern)(FbArgs) = a0.prof ? fl_main_kernel<true> : fl_main_kernel<false>;
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return (int)e;
         const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
         g_ev_start = g_ev_stop = nullptr;
         if (e0) (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(fl_main_kernel, dim3(b), dim3(1024), lds, s, a0);
+        hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, s, a0);
         if (e1) (void)hipEventRecord(e1, s);
         const int r = tpu3_launch_status();
         if (r)
