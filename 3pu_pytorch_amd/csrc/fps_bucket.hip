@@ -1590,14 +1590,16 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
 // lower bound of every computed distance; stale bounds stay bounds).
 constexpr int FL_R = 16;                 // points per bucket
 constexpr int FL_TP = 64 * FL_R;         // points per tile
-constexpr int FL_CAP = 64;               // candidates (= samples) per round
+constexpr int FL_CAP = 64;               // samples per round
+constexpr int FL_LIST = 512;             // candidates a round may list
 constexpr int FL_EW = 8;                 // words per candidate entry (5 used)
 constexpr int FL_WORK = 4096;            // work list entries: fewer than FL_DENSE reached buckets per tile x 256 tiles
 constexpr int FL_DENSE = 16;             // a tile with this many reached buckets is updated on the spot
+constexpr int FL_P2 = 3;                 // phase-2 steps of a wave whose points are fetched together
 
 struct FlShared {
     FmHeader h[2][16];
-    uint32_t cand[2][FL_CAP * FL_EW];
+    uint32_t cand[2][FL_LIST * 2 + 2 * FL_CAP];     // (maximum, slot) per candidate; the selected / ranked slots
     float pick[2][FL_CAP][4];       // the round's samples in rank order: x, y, z, distance
     uint32_t pkey[2][FL_CAP];
     int mrow[FL_CAP];
@@ -1605,6 +1607,7 @@ struct FlShared {
     int ncand[2];
     uint32_t minkey;                // arg-max with the tie rule (ties at the top)
     int nwork;                      // entries on the work list
+    int jclear;                     // length of the clear prefix of the round's ranked candidates
     unsigned long long stat[8];     // rounds, samples, overflow rounds, tie rounds; wave 0's cycles in apply,
                                     // collecting candidates (incl. its barriers), ranking; tile visits of wave 0
 };
@@ -1872,15 +1875,28 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         // lone wave: the sixteen points of a bucket are the parallelism a few reached buckets have)
         const int E = sh.nwork;
         const int row = lane >> 4, col = lane & 15;
-        for (int e0 = wave * 4; e0 < E; e0 += 64) {
+        for (int g0 = wave * 4; g0 < E; g0 += 64 * FL_P2) {
+          // the points of up to FL_P2 steps of this wave in flight together (a step is one dependent trip to L2)
+          float4 ptv[FL_P2];
+          int bv[FL_P2];
+#pragma unroll
+          for (int k = 0; k < FL_P2; ++k) {
+              const int ee = g0 + 64 * k + row;
+              bv[k] = (int)work[3 * (ee < E ? ee : 0)];
+              ptv[k] = TP[(size_t)bv[k] * FL_R + col];
+          }
+#pragma unroll
+          for (int k = 0; k < FL_P2; ++k) {
+            const int e0 = g0 + 64 * k;
+            if (e0 >= E)
+                break;
             const bool act = e0 + row < E;
             const uint32_t *e = work + 3 * (act ? e0 + row : 0);
-            const int b = (int)e[0];
+            const int b = bv[k];
             unsigned long long mine = act ? (((unsigned long long)e[2] << 32) | e[1]) : 0ull;
             float4 *__restrict__ pp = TP + (size_t)b * FL_R + col;
-            const float4 pt = *pp;
-            float nt = pt.w;
-            while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
+            const float4 pt = ptv[k];
+            float nt = pt.w;            while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
                 const bool go = mine != 0;
                 const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
                 mine &= mine - 1;
@@ -1912,6 +1928,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 atomicMax(&tmx[b >> 6], best);
                 atomicMax(&trn[b >> 6], run);
             }
+          }
         }
         if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_p2 += d1 - d0; d0 = d1; }
         __syncthreads();
@@ -1974,7 +1991,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     base = atomicAdd(&sh.ncand[par], (int)__builtin_popcountll(cm));
                 base = __builtin_amdgcn_readfirstlane(base);
                 const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
-                if (c && pos < FL_CAP) {
+                if (c && pos < FL_LIST) {
                     cl[pos * 2] = (uint32_t)bm;
                     cl[pos * 2 + 1] = ((uint32_t)b << 4) | barg[b];
                 }
@@ -2001,9 +2018,10 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 break;
             }
             total = sh.ncand[par];
-            if (total <= FL_CAP)
+            if (total <= FL_LIST)
                 break;
-            // more candidates than the list holds: raise the threshold (any threshold >= R* is valid) and collect again
+            // more candidates than the list holds (the first rounds): raise the threshold (any threshold >= R* is valid)
+            // and collect again
             __syncthreads();
             if (tid == 0) {
                 sh.ncand[par] = 0;
@@ -2016,18 +2034,63 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             __syncthreads();
         }
         if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_coll += c1 - c0; c0 = c1; }
-        // wave 0 ranks the candidates; the others wait at the barrier and read the round's samples from LDS
+        // wave 0: the FL_CAP best of the list (a few bisection steps on the values it holds in registers -- the list
+        // usually holds more: 16-point cells qualify by the dozen), their rank order, ONE round trip for their
+        // coordinates and keys; then ALL waves test the pairs for clearance (2016 pairs at 64 candidates: 32 passes
+        // for a lone wave, 7 k cycles; two per wave here)
         const int left = a.m - r;
+        uint32_t okey = 0;
         if (wave == 0) {
-            const bool live = lane < total;
-            const int cM = live ? (int)cl[(lane & (FL_CAP - 1)) * 2] : (int)0x80000000;
-            const uint32_t cB = cl[(lane & (FL_CAP - 1)) * 2 + 1];
-            // slot of the candidate's point: 16 b + position = the entry's second word itself
-            auto slot_of = [](uint32_t w) __attribute__((always_inline)) { return (size_t)w; };   // 16 b + position
+            int em[FL_LIST / 64];
+            uint32_t eb[FL_LIST / 64];
+#pragma unroll
+            for (int u = 0; u < FL_LIST / 64; ++u) {
+                const int i = u * 64 + lane;
+                em[u] = i < total ? (int)cl[2 * i] : (int)0x80000000;
+                eb[u] = cl[2 * (i < total ? i : 0) + 1];
+            }
+            int thr2 = (int)0x80000000, nsel = total;
+            if (total > FL_CAP) {
+                int lo = rstar, hi = gbest, chi = 0;                // count(> lo) > FL_CAP >= count(> hi) = chi
+                for (int it = 0; it < 16 && hi - lo > 1; ++it) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int u = 0; u < FL_LIST / 64; ++u)
+                        c += __builtin_popcountll(__ballot(em[u] > mid));
+                    if (c > FL_CAP) {
+                        lo = mid;
+                    } else {
+                        hi = mid; chi = c;
+                        if (c >= FL_CAP / 2)
+                            break;
+                    }
+                }
+                thr2 = hi; nsel = chi;
+                if (lane == 0) sh.stat[2] += 1;
+            }
+            // (nsel == 0: more than FL_CAP buckets share the top value -- duplicated points; the exact arg-max
+            // with the tie rule below settles it)
+            int base = 0;
+#pragma unroll
+            for (int u = 0; u < FL_LIST / 64; ++u) {
+                const bool sel = em[u] > thr2;
+                const unsigned long long smk = __ballot(sel);
+                if (sel) {
+                    const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
+                    sh.mrow[pos] = em[u];
+                    cl[2 * FL_LIST + pos] = eb[u];
+                }
+                base += __builtin_popcountll(smk);
+            }
+            const bool live = lane < nsel;
+            const int cM = live ? sh.mrow[lane] : (int)0x80000000;
+            const uint32_t cB = cl[2 * FL_LIST + (live ? lane : 0)];
+            if (!live)
+                sh.mrow[lane] = (int)0x80000000;
             int rank = 0;
             bool tie = false;
-            sh.mrow[lane & (FL_CAP - 1)] = cM;
-            for (int c0 = 0; c0 < total; c0 += 16) {
+            for (int c0 = 0; c0 < nsel; c0 += 16) {
                 int4 mv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -2043,10 +2106,10 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 }
             }
             if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
-                const uint32_t cK = live ? TK[slot_of(cB)] : 0xFFFFFFFFu;
-                sh.pkey[par][lane & (FL_CAP - 1)] = cK;
+                const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
+                sh.pkey[par][lane] = cK;
                 rank = 0;
-                for (int i = 0; i < total; ++i) {
+                for (int i = 0; i < nsel; ++i) {
                     const int mi = sh.mrow[i];
                     const uint32_t ki = sh.pkey[par][i];
                     rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
@@ -2055,18 +2118,57 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             }
             // into rank order, then ONE round trip for the coordinates and keys of the whole list
             if (live)
-                cl[2 * FL_CAP + rank] = cB;
-            const uint32_t sB = cl[2 * FL_CAP + (lane & (FL_CAP - 1))];
-            const size_t sw = live ? slot_of(sB) : 0;
-            const float4 sp4 = TP[sw];
-            const uint32_t okey = TK[sw];
+                cl[2 * FL_LIST + FL_CAP + rank] = cB;
+            const uint32_t sB = cl[2 * FL_LIST + FL_CAP + (live ? lane : 0)];
+            const float4 sp4 = TP[live ? sB : 0];
+            okey = TK[live ? sB : 0];
             if (live)
                 *(float4 *)sh.pick[par][lane] = sp4;            // (.w = the running distance = the bucket's maximum)
-            int jmax = total < left ? total : left;
-            // longest prefix in which no member lies inside the update ball of an earlier member, all pairs (i < l),
-            // 64 per pass in l-major order: the first pass with a hit holds the smallest l
+            if (lane == 0) {
+                const int jm = nsel < left ? nsel : left;
+                sh.npick[par] = jm;
+                sh.jclear = jm;
+                sh.ncand[par ^ 1] = 0;
+            }
+        }
+        __syncthreads();
+        int jmax = sh.npick[par];
+        if (jmax == 0) {
+            // (only with > FL_CAP equal maxima at the top) one sample by the exact arg-max with the tie rule
+            if (tid == 0)
+                sh.minkey = 0xFFFFFFFFu;
+            __syncthreads();
+            unsigned long long t2 = __ballot(tvalid && quad == 0 && tmax == gbest);
+            for (unsigned long long tt = t2; tt; tt &= tt - 1) {
+                const int b = ((__builtin_ctzll(tt) >> 2) * 16 + wave) * 64 + lane;
+                if (bmax[b] == gbest)
+                    atomicMin(&sh.minkey, TK[(size_t)b * FL_R + barg[b]]);
+            }
+            __syncthreads();
+            const uint32_t mk = sh.minkey;
+            for (unsigned long long tt = t2; tt; tt &= tt - 1) {
+                const int b = ((__builtin_ctzll(tt) >> 2) * 16 + wave) * 64 + lane;
+                if (bmax[b] == gbest) {
+                    const size_t w = (size_t)b * FL_R + barg[b];
+                    if (TK[w] == mk) {
+                        *(float4 *)sh.pick[par][0] = TP[w];
+                        sh.pkey[par][0] = mk;
+                        sh.npick[par] = 1;
+                        sh.jclear = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            jmax = 1;
+            if (wave == 0)
+                okey = sh.pkey[par][0];
+        }
+        // longest prefix in which no member lies inside the update ball of an earlier member: the smallest l with
+        // d(sample i, sample l) < M_l for some i < l -- all pairs (i < l), 64 per pass in l-major order, the passes
+        // dealt over the waves
+        {
             const int npair = jmax * (jmax - 1) / 2;
-            for (int t0 = 0; t0 < npair; t0 += 64) {
+            for (int t0 = wave * 64; t0 < npair; t0 += 1024) {
                 int pl = pair_l, pi = pair_i;
                 if (t0) {
                     const int t = t0 + lane;
@@ -2081,22 +2183,24 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 const float d = tpu3_sqdist3(L4.x - I4.x, L4.y - I4.y, L4.z - I4.z);
                 const unsigned long long hit = __ballot(ok && d < L4.w);
                 if (hit) {
-                    jmax = __builtin_amdgcn_readlane(pl, (int)__builtin_ctzll(hit));
+                    const int first = __builtin_amdgcn_readlane(pl, (int)__builtin_ctzll(hit));
+                    if (lane == 0)
+                        atomicMin(&sh.jclear, first);
                     break;
                 }
             }
-            if (lane < jmax)
+        }
+        __syncthreads();
+        J = sh.jclear;
+        if (wave == 0) {
+            if (lane < J)
                 a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
             if (lane == 0) {
-                sh.npick[par] = jmax;
-                sh.ncand[par ^ 1] = 0;
                 sh.stat[0] += 1;
-                sh.stat[1] += (unsigned long long)jmax;
+                sh.stat[1] += (unsigned long long)J;
             }
         }
         if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_rank += c1 - c0; c0 = c1; }
-        __syncthreads();
-        J = sh.npick[par];
         r += J;
         if (r >= a.m) {
             if (J > 1)
