@@ -16,7 +16,7 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL):
 The default (--gpus N, 32 clouds per GPU) is the throughput configuration of the 1-GPU line.
 
 One JSON line is printed by rank 0.  Besides the contract's keys it carries
-  roofline          dominant kernel (final FPS, fm_main_kernel): measured traffic / launch time against the
+  roofline          dominant kernel (final FPS, fl_main_kernel): measured traffic / launch time against the
                     HBM peak -- never above 1 -- plus us_per_sample next to a stated per-round floor; the streaming
                     model of SURVEY 8d as `model_ratio` (the kernel skips >99 % of that model's bytes)
   rooflines_other   every other hand-written kernel of a step, timed with events on its launch stream:
@@ -410,7 +410,7 @@ def main():
         clouds = torch.cat([poisson_sphere(rank * C + i, N, dev, ops) for i in range(C)], dim=0)
 
     timing = []
-    # HIP events placed by the library immediately around fm_main_kernel on ITS stream (the events
+    # HIP events placed by the library immediately around the final-FPS kernel (fl_main_kernel) on ITS stream (the events
     # in `timing` bracket the whole final-FPS operator: Morton sort, bucket setup, kernel, write-back)
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
@@ -539,7 +539,8 @@ def main():
         if traffic and traffic.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
             tr = traffic.get("traffic_bytes_per_launch")
         model_bytes = 20.0 * CL * n_merged * (m_out - 1)
-        roof = {"kernel": "fm_main_kernel: final FPS %d->%d, %d cloud(s) per launch" % (n_merged, m_out, CL),
+        roof = {"kernel": "fl_main_kernel (tile-form FPS, a lane per 16-point bucket): final FPS %d->%d, %d cloud(s) per launch"
+                          % (n_merged, m_out, CL),
                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tr,
                 "achieved": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
                 "basis": "measured fabric traffic of one launch (PMC, profiles/r03_traffic.json) / launch time (HIP events "
@@ -547,10 +548,11 @@ def main():
                 "traffic_provenance": (traffic or {}).get("provenance"),
                 "launch_ms": fps_ms, "operator_ms": op_ms,
                 "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
-                "us_per_round_floor": 0.9,
-                "floor_note": "a round (~8 samples of a cloud) is one dependent chain on ONE compute unit: L2-hit load of "
-                              "the reached bucket groups (~320 cycles) -> distance update + row arg-max (DPP) -> one "
-                              "barrier -> ranking; ~2200 cycles = 0.9 us at 2.4 GHz with every load hitting L2; "
+                "us_per_round_floor": 2.5,
+                "floor_note": "a round (~34 samples of a cloud) is one dependent chain on ONE compute unit: tile prune -> "
+                              "bucket records of the reached tiles (L2 trip) -> the reached buckets' points (L2 trip) -> "
+                              "candidate list -> the ranked candidates' coordinates (L2 trip) -> clearance, with five "
+                              "workgroup barriers; three trips of ~0.5 us + ~1 us of instruction issue = 2.5 us per ROUND; "
                               "us_per_sample = launch time / samples per cloud (the clouds of a launch run side by side)",
                 "model_bytes_per_launch": model_bytes,
                 "model_ratio": (model_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fps_ms else None,

@@ -17,7 +17,7 @@ pass() { # $1 = tag, rest = counters
   (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /root/repo/gpurun_out/prof/$tag -- python /root/repo/bench.py $SS --steps 2 --warmup 1 > /dev/null 2>&1)
   f=$(find gpurun_out/prof/$tag -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_by_kernel.py $f > $O/pmc_${tag}_by_kernel.txt
-  [ -n "$f" ] && { head -1 $f > $O/pmc_${tag}_fm_main.csv; grep fm_main_kernel $f >> $O/pmc_${tag}_fm_main.csv; }
+  [ -n "$f" ] && { head -1 $f > $O/pmc_${tag}_fm_main.csv; grep -E 'fl_main_kernel|fm_main_kernel' $f >> $O/pmc_${tag}_fm_main.csv; }
   rm -rf gpurun_out/prof/$tag
 }
 pass FETCH_SIZE FETCH_SIZE
@@ -27,5 +27,5 @@ pass SQ_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAVES SQ_I
 pass GRBM GRBM_GUI_ACTIVE GRBM_COUNT
 tail -1 $O/bench_default.json | cut -c1-300
 python tools/kstats.py $O/kernel_stats_single_stream.csv 5 16
-grep -h "fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
+grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
 rm -rf gpurun_out/prof

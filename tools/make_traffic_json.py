@@ -1,7 +1,7 @@
 """Derive profiles/r03_traffic.json (read by bench.py) from the PMC passes of tools/collect_profiles.sh.
 
 usage: python tools/make_traffic_json.py <dir with pmc_*_by_kernel.txt and pmc_*_fm_main.csv> <clouds per launch> [out.json] [commit]
-  traffic of the dominant kernel (fm_main_kernel, final FPS): mean over the bench's launches (the dispatches
+  traffic of the dominant kernel (final FPS: fl_main_kernel, fm_main_kernel until round 2): mean over the bench's launches (the dispatches
       with the large counter values; the small ones are the input thinning) of FETCH_SIZE x 2 (gfx950: 128-byte
       requests are tallied at 64 B for 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE,
       counter unit KiB;
@@ -70,7 +70,8 @@ for key in ("dec_fused", "knn_graph_key_kernel", "regress_tail_kernel", "linear_
                      "SQ_BUSY_CYCLES": m["SQ_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": g["GRBM_GUI_ACTIVE"],
                      "SQ_INSTS_VALU": None if not v else v.get("SQ_INSTS_VALU")}
 out = {
-    "kernel": "fm_main_kernel<8,1,false,false>", "clouds_per_launch": clouds, "launches_averaged": nl,
+    "kernel": "fl_main_kernel<false> (final FPS; fm_main_kernel<8,1,false,false> until round 2)", "clouds_per_launch": clouds,
+    "launches_averaged": nl,
     "fetch_size_kib": fetch, "write_size_kib": write,
     "fetch_correction": "x2 (gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane coalesced reads, "
                         "MI355X_MICROARCH.md HBM section)",
