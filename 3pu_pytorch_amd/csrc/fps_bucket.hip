@@ -1596,6 +1596,10 @@ constexpr int FL_EW = 8;                 // words per candidate entry (5 used)
 constexpr int FL_WORK = 4096;            // work list entries: fewer than FL_DENSE reached buckets per tile x 256 tiles
 constexpr int FL_DENSE = 16;             // a tile with this many reached buckets is updated on the spot
 constexpr int FL_P2 = 3;                 // phase-2 steps of a wave whose points are fetched together
+constexpr int FL_VIS = 4096;             // L3: entries of the visit list (reached tiles of a round: all of them at most)
+constexpr int FL_CB = 8;                 // L3: tiles of a wave whose maxima are fetched together when candidates are listed
+constexpr int FL_VB = 4;                 // L3: visits of a wave whose records are fetched together
+constexpr int FL_TMAX = 4096;            // tiles of the three-level form (256 super-tiles of 16): 4 194 304 points
 
 struct FlShared {
     FmHeader h[2][16];
@@ -1607,14 +1611,18 @@ struct FlShared {
     int ncand[2];
     uint32_t minkey;                // arg-max with the tie rule (ties at the top)
     int nwork;                      // entries on the work list
+    int nvis, vnext;                // L3: entries on the visit list, the next one to hand out
     int jclear;                     // length of the clear prefix of the round's ranked candidates
     unsigned long long stat[8];     // rounds, samples, overflow rounds, tie rounds; wave 0's cycles in apply,
                                     // collecting candidates (incl. its barriers), ranking; tile visits of wave 0
 };
 
-constexpr size_t fl_lds_bytes(int ntile)
+static_assert(offsetof(FlShared, cand) % 16 == 0 && offsetof(FlShared, mrow) % 16 == 0 && offsetof(FlShared, pick) % 16 == 0,
+              "vector reads of the lists");
+constexpr size_t fl_lds_bytes(int ntile, bool l3)
 {
-    return (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15) + 512 * 4 + (size_t)FL_WORK * 12 + sizeof(FlShared) + 64;
+    return (l3 ? (size_t)FL_TMAX * 8 + FL_VIS * 12 : (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15)) + 512 * 4 +
+           (size_t)FL_WORK * 12 + sizeof(FlShared) + 64;
 }
 
 // bucket / tile records of the initial state: one wave per tile
@@ -1665,7 +1673,12 @@ __global__ __launch_bounds__(64) void fl_init_kernel(FbArgs a0)
     }
 }
 
-template <bool PROF>
+// L3 (more than 256 tiles, up to 4096: config C5's 3.83 M points): one more level.  The unit a lane quad owns and
+// tests the samples against is a SUPER-TILE of 16 tiles; a reached super-tile reads its 16 tile boxes (one lane
+// each), a reached tile is visited as in the two-level form.  The buckets' maxima and arg-max positions do not
+// fit LDS (1.2 MB) and live in memory next to the records; LDS keeps the maxima and runner-up bounds of the
+// tiles (32 KB) and of the super-tiles.
+template <bool PROF, bool L3>
 __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1673,42 +1686,94 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
     if (a.n <= 0 || a.m <= 0)
         return;
     const int ntile = (a.n + FL_TP - 1) / FL_TP;            // live tiles of this element
+    // two levels: bucket maxima / positions [ntile * 64] | tile maxima, runner-up bounds [256] each | work list | shared
+    // L3:         tile maxima, runner-up bounds [4096] each | super-tile maxima, bounds [256] each | work list |
+    //             visit list | shared
     int *bmax = (int *)smem;
     uint8_t *barg = (uint8_t *)(bmax + a0.ntile * 64);
-    int *tmx = (int *)(smem + (((size_t)a0.ntile * 64 * 5 + 15) & ~(size_t)15));        // tile maxima, [256]
-    int *trn = tmx + 256;                                                               // tile runner-up bounds
-    uint32_t *work = (uint32_t *)(trn + 256);                                           // [FL_WORK][3]
-    FlShared &sh = *(FlShared *)(work + FL_WORK * 3);
+    int *tmx = L3 ? (int *)smem : (int *)(smem + (((size_t)a0.ntile * 64 * 5 + 15) & ~(size_t)15));
+    int *trn = tmx + (L3 ? FL_TMAX : 256);
+    int *gmx = L3 ? trn + FL_TMAX : tmx;            // the level the quads own: super-tiles (L3) or the tiles themselves
+    int *grn = L3 ? gmx + 256 : trn;
+    uint32_t *work = (uint32_t *)(grn + 256);                                           // [FL_WORK][3]
+    uint32_t *vis = work + FL_WORK * 3;                                                 // L3: [FL_VIS][3], the visit list
+    FlShared &sh = *(FlShared *)(vis + (L3 ? FL_VIS * 3 : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = a.lb;
     float4 *__restrict__ TP = a.sp;
     const uint32_t *__restrict__ TK = a.skey;
 
-    for (int i = tid; i < ntile * 64; i += 1024) {
-        bmax[i] = a.bm0[i];
-        barg[i] = a.ba0[i];
-    }
-    // the tile of this lane's quad: slot = lane / 4 (16 tiles per wave), tile = slot * 16 + wave
+    if constexpr (!L3)
+        for (int i = tid; i < ntile * 64; i += 1024) {
+            bmax[i] = a.bm0[i];
+            barg[i] = a.ba0[i];
+        }
+    // a bucket's maximum / position of its best point: LDS, or (L3) the arrays the init kernel wrote, updated in place
+    auto ld_bm = [&](int b) __attribute__((always_inline)) { return L3 ? a.bm0[b] : bmax[b]; };
+    auto ld_ba = [&](int b) __attribute__((always_inline)) { return L3 ? (int)a.ba0[b] : (int)barg[b]; };
+    auto st_bm = [&](int b, int best, int arg) __attribute__((always_inline)) {
+        if constexpr (L3) {
+            a.bm0[b] = best;
+            a.ba0[b] = (uint8_t)arg;
+        } else {
+            bmax[b] = best;
+            barg[b] = (uint8_t)arg;
+        }
+    };
+    // the unit of this lane's quad (a tile; L3: a super-tile of 16 tiles): slot = lane / 4, unit = slot * 16 + wave
     const int slot = lane >> 2, quad = lane & 3;
     const int tq = slot * 16 + wave;
-    const bool tvalid = tq < ntile;
+    const int nunit = L3 ? (ntile + 15) >> 4 : ntile;
+    const bool tvalid = tq < nunit;
     float tbx[6];
+    for (int i = tid; i < (L3 ? FL_TMAX : 256); i += 1024) {
+        tmx[i] = i < ntile ? __float_as_int(a.tt[i * 8 + 6]) : (int)0x80000000;
+        trn[i] = i < ntile ? __float_as_int(a.tt[i * 8 + 7]) : (int)0x80000000;
+    }
+    if constexpr (L3) {
+        // box = union of the super-tile's tile boxes, maxima over its tiles (every lane of the quad walks all 16)
+        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+        float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        int um = (int)0x80000000, ur = (int)0x80000000;
+        for (int l = 0; l < 16; ++l) {
+            const int t = tq * 16 + l;
+            if (tvalid && t < ntile) {
+                const float *o = a.tt + t * 8;
+                lo[0] = fminf(lo[0], o[0]); lo[1] = fminf(lo[1], o[1]); lo[2] = fminf(lo[2], o[2]);
+                hi[0] = fmaxf(hi[0], o[3]); hi[1] = fmaxf(hi[1], o[4]); hi[2] = fmaxf(hi[2], o[5]);
+                um = max(um, __float_as_int(o[6]));
+                ur = max(ur, __float_as_int(o[7]));
+            }
+        }
+        const bool ok = tvalid && lo[0] <= hi[0];
+        tbx[0] = ok ? lo[0] : __builtin_inff(); tbx[1] = ok ? lo[1] : __builtin_inff(); tbx[2] = ok ? lo[2] : __builtin_inff();
+        tbx[3] = ok ? hi[0] : __builtin_inff(); tbx[4] = ok ? hi[1] : __builtin_inff(); tbx[5] = ok ? hi[2] : __builtin_inff();
+        if (quad == 0 && tq < 256) {
+            gmx[tq] = um;
+            grn[tq] = ur;
+        }
+        if (tid < 256 && tid >= nunit) {
+            gmx[tid] = (int)0x80000000;
+            grn[tid] = (int)0x80000000;
+        }
+    } else {
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
-        tbx[c] = tvalid ? a.tt[tq * 8 + c] : __builtin_inff();
-    if (tid < 256) {
-        tmx[tid] = tid < ntile ? __float_as_int(a.tt[tid * 8 + 6]) : (int)0x80000000;
-        trn[tid] = tid < ntile ? __float_as_int(a.tt[tid * 8 + 7]) : (int)0x80000000;
+        for (int c = 0; c < 6; ++c)
+            tbx[c] = tvalid ? a.tt[tq * 8 + c] : __builtin_inff();
     }
     if (tid < 2)
         sh.ncand[tid] = 0;
-    if (tid == 0)
+    if (tid == 0) {
         sh.nwork = 0;
+        sh.nvis = 0;
+        sh.vnext = 0;
+    }
     if (tid < 8)
         sh.stat[tid] = 0;
     const bool prof = PROF && a0.prof != nullptr && blockIdx.x == 0;
     unsigned long long c_apply = 0, c_coll = 0, c_rank = 0, c_vis = 0, c0 = 0, c1 = 0;
     unsigned long long c_p1 = 0, c_b1 = 0, c_p2 = 0, c_b2 = 0, d0 = 0, d1 = 0;
+    unsigned long long c_pass = 0, c_tot = 0, c_nsel = 0, c_cut = 0;     // collect passes, listed / selected candidates, rounds cut by clearance
     if (tid == 0) {
         a.idx[0] = 0;
         sh.pick[1][0][0] = a.xyz[0]; sh.pick[1][0][1] = a.xyz[1]; sh.pick[1][0][2] = a.xyz[2];
@@ -1785,8 +1850,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             }
         }
         if (act) {
-            bmax[b] = best;
-            barg[b] = (uint8_t)arg;
+            st_bm(b, best, arg);
             ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
         }
     };
@@ -1802,7 +1866,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         uint32_t mlo = 0, mhi = 0;
         if (prof) d0 = __builtin_amdgcn_s_memtime();
         if (tvalid) {
-            const float tmf = __int_as_float(tmx[tq]);
+            const float tmf = __int_as_float(gmx[tq]);
             for (int i = quad; i < nj; i += 4) {
                 const float4 p = *(const float4 *)sh.pick[cur][i];
                 const bool hit = fb_dbox(p.x, p.y, p.z, tbx[0], tbx[1], tbx[2], tbx[3], tbx[4], tbx[5]) < tmf;
@@ -1812,21 +1876,11 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         }
         mlo = quad_or(mlo);
         mhi = quad_or(mhi);
-        // (dealing the reached tiles out over all waves through a visit list, with the records of four visits in
-        // flight, was measured: 49.6 vs 45.1 ms -- the phase is bound by the compute unit's VALU throughput, ~100
-        // instructions per visit and 70 visits per round, not by which wave runs them)
-        unsigned long long touched = __ballot((mlo | mhi) != 0 && quad == 0);
-        while (touched) {
-            const int L = __builtin_ctzll(touched);
-            touched &= touched - 1;
-            const int t = (L >> 2) * 16 + wave;
+        // ---- one tile: which of its 64 buckets do the samples of `smt` reach?  few: on the work list; many: on the spot
+        // (rc, bm: the record and maximum of this lane's bucket, loaded by the caller)
+        auto visit_tile = [&](int t, unsigned long long smt, uint4 rc, int bm) __attribute__((always_inline)) {
             if (PROF) c_vis += 1;
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
-            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
-            const unsigned long long smt = ((unsigned long long)shi << 32) | slo;
             const int b = t * 64 + lane;
-            const uint4 rc = a.rec[b];
-            const int bm = bmax[b];
             const float lx = fb_half_lo(rc.x), ly = fb_half_hi(rc.x), lz = fb_half_lo(rc.y);
             const float hx = fb_half_hi(rc.y), hy = fb_half_lo(rc.z), hz = fb_half_hi(rc.z);
             unsigned long long mine = 0;            // the samples that reach THIS lane's bucket
@@ -1838,9 +1892,22 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             const bool reached = mine != 0;
             const unsigned long long rm = __ballot(reached);
             if (!rm)
-                continue;
+                return;
             const int nreach = __builtin_popcountll(rm);
-            if (nreach >= FL_DENSE) {
+            int base = 0;
+            bool dense = nreach >= FL_DENSE;
+            if (!dense) {
+                if (lane == 0)
+                    base = atomicAdd(&sh.nwork, nreach);
+                base = __builtin_amdgcn_readfirstlane(base);
+                dense = base + nreach > FL_WORK;        // (list full -- L3, large balls: on the spot; the reserved slots are voided)
+            }
+            if (dense) {
+                if (nreach < FL_DENSE && reached) {
+                    const int pos = base + __builtin_popcountll(rm & ((1ull << lane) - 1ull));
+                    if (pos < FL_WORK)
+                        work[3 * pos] = 0xFFFFFFFFu;
+                }
                 int best, run;
                 update_bucket(reached, b, smt, cur, best, run);
                 int tm = reached ? best : bm, tr = reached ? run : (int)rc.w;
@@ -1849,21 +1916,101 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     tmx[t] = tm;
                     trn[t] = tr;
                 }
-                continue;
+                return;
             }
             // the tile's maxima over the buckets NOT reached; phase 2 adds the reached ones' (atomic max)
             int um = reached ? (int)0x80000000 : bm, ur = reached ? (int)0x80000000 : (int)rc.w;
             tpu3_wave_max_i32_fast_x2(um, ur);
-            int base = 0;
             if (lane == 0) {
                 tmx[t] = um;
                 trn[t] = ur;
-                base = atomicAdd(&sh.nwork, nreach);
             }
-            base = __builtin_amdgcn_readfirstlane(base);
             if (reached) {
                 uint32_t *e = work + 3 * (base + __builtin_popcountll(rm & ((1ull << lane) - 1ull)));
                 e[0] = (uint32_t)b; e[1] = (uint32_t)mine; e[2] = (uint32_t)(mine >> 32);
+            }
+        };
+        // Two levels: every wave visits the reached tiles of its own quads.  (Dealing them out over all waves through a
+        // visit list, with the records of four visits in flight, was measured: 49.6 vs 45.1 ms -- with the maxima in
+        // LDS the phase is bound by the compute unit's VALU throughput, ~100 instructions per visit and 70 visits per
+        // round, not by which wave runs them.)
+        // L3: the records AND the maxima come from memory, a visit is a dependent round trip (2 k cycles) in front of
+        // 600 cycles of work, and the waves' shares differ by 2x: the reached tiles go on a visit list, a barrier, and
+        // every wave takes every 16th entry, four visits' loads in flight.
+        const unsigned long long touched0 = __ballot((mlo | mhi) != 0 && quad == 0);
+        if constexpr (!L3) {
+            for (unsigned long long touched = touched0; touched; touched &= touched - 1) {
+                const int L = __builtin_ctzll(touched);
+                const int u = (L >> 2) * 16 + wave;
+                const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
+                const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
+                visit_tile(u, ((unsigned long long)shi << 32) | slo, a.rec[u * 64 + lane], bmax[u * 64 + lane]);
+            }
+        } else {
+            // the touched super-tiles' 16 tiles, a lane each and FOUR super-tiles per step (their tile boxes are one
+            // round trip to memory): box and maximum, the samples that may reach the tile.  (The super-tiles and their
+            // samples are handed to the lanes through this wave's slice of the idle candidate list.)
+            uint32_t *ul = sh.cand[cur ^ 1] + wave * 48;
+            const int ntouch = __builtin_popcountll(touched0);
+            if ((mlo | mhi) != 0 && quad == 0) {
+                uint32_t *e = ul + 3 * __builtin_popcountll(touched0 & ((1ull << lane) - 1ull));
+                e[0] = (uint32_t)tq; e[1] = mlo; e[2] = mhi;
+            }
+            for (int e0 = 0; e0 < ntouch; e0 += 4) {
+                const int ei = e0 + (lane >> 4);
+                const bool ev = ei < ntouch;
+                const uint32_t *e = ul + 3 * (ev ? ei : 0);
+                const int t = (int)e[0] * 16 + (lane & 15);
+                const bool tv = ev && t < ntile;
+                const float *o = a.tt + (tv ? t : 0) * 8;
+                const float4 o0 = *(const float4 *)o, o1 = *(const float4 *)(o + 4);
+                const float tmf = tv ? __int_as_float(tmx[t]) : -1.f;
+                unsigned long long minet = 0;
+                for (unsigned long long sm = tv ? ((unsigned long long)e[2] << 32) | e[1] : 0ull; sm; sm &= sm - 1) {
+                    const int i = __builtin_ctzll(sm);
+                    const float4 p = *(const float4 *)sh.pick[cur][i];
+                    minet |= fb_dbox(p.x, p.y, p.z, o0.x, o0.y, o0.z, o0.w, o1.x, o1.y) < tmf ? (1ull << i) : 0ull;
+                }
+                const unsigned long long tm = __ballot(minet != 0);
+                int base = 0;
+                if (lane == 0 && tm)
+                    base = atomicAdd(&sh.nvis, (int)__builtin_popcountll(tm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (minet != 0) {
+                    uint32_t *v = vis + 3 * (base + __builtin_popcountll(tm & ((1ull << lane) - 1ull)));
+                    v[0] = (uint32_t)t; v[1] = (uint32_t)minet; v[2] = (uint32_t)(minet >> 32);
+                }
+            }
+        }
+        if constexpr (L3) {
+            __syncthreads();
+            const int nv = sh.nvis;
+            for (;;) {
+                int i0 = 0;
+                if (lane == 0)
+                    i0 = atomicAdd(&sh.vnext, FL_VB);
+                i0 = __builtin_amdgcn_readfirstlane(i0);
+                if (i0 >= nv)
+                    break;
+                int tv[FL_VB], bmv[FL_VB];
+                uint4 rcv[FL_VB];
+#pragma unroll
+                for (int k = 0; k < FL_VB; ++k) {
+                    const int i = i0 + k;
+                    tv[k] = (int)vis[3 * (i < nv ? i : i0)];
+                    rcv[k] = a.rec[tv[k] * 64 + lane];
+                    bmv[k] = a.bm0[tv[k] * 64 + lane];
+                }
+                // (ONE copy of the visit: the batch rotates through the first slot)
+#pragma unroll 1
+                for (int i = i0; i < nv && i < i0 + FL_VB; ++i) {
+                    const uint32_t *e = vis + 3 * i;
+                    visit_tile(tv[0], ((unsigned long long)e[2] << 32) | e[1], rcv[0], bmv[0]);
+#pragma unroll
+                    for (int k = 0; k + 1 < FL_VB; ++k) {
+                        tv[k] = tv[k + 1]; rcv[k] = rcv[k + 1]; bmv[k] = bmv[k + 1];
+                    }
+                }
             }
         }
         if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_p1 += d1 - d0; d0 = d1; }
@@ -1873,7 +2020,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         // bucket, seven instructions per sample, the record by row reductions; four buckets per wave step, the
         // steps dealt over the 16 waves (a lane per bucket here took 800 instructions for ONE pass, 8 k cycles in a
         // lone wave: the sixteen points of a bucket are the parallelism a few reached buckets have)
-        const int E = sh.nwork;
+        const int E = min(sh.nwork, FL_WORK);
         const int row = lane >> 4, col = lane & 15;
         for (int g0 = wave * 4; g0 < E; g0 += 64 * FL_P2) {
           // the points of up to FL_P2 steps of this wave in flight together (a step is one dependent trip to L2)
@@ -1883,20 +2030,22 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
           for (int k = 0; k < FL_P2; ++k) {
               const int ee = g0 + 64 * k + row;
               bv[k] = (int)work[3 * (ee < E ? ee : 0)];
-              ptv[k] = TP[(size_t)bv[k] * FL_R + col];
+              ptv[k] = TP[(size_t)(bv[k] >= 0 ? bv[k] : 0) * FL_R + col];
           }
 #pragma unroll
           for (int k = 0; k < FL_P2; ++k) {
             const int e0 = g0 + 64 * k;
             if (e0 >= E)
                 break;
-            const bool act = e0 + row < E;
-            const uint32_t *e = work + 3 * (act ? e0 + row : 0);
-            const int b = bv[k];
+            const bool inl = e0 + row < E;
+            const uint32_t *e = work + 3 * (inl ? e0 + row : 0);
+            const bool act = inl && bv[k] >= 0;                 // (a voided slot: its tile was updated on the spot)
+            const int b = act ? bv[k] : 0;
             unsigned long long mine = act ? (((unsigned long long)e[2] << 32) | e[1]) : 0ull;
             float4 *__restrict__ pp = TP + (size_t)b * FL_R + col;
             const float4 pt = ptv[k];
-            float nt = pt.w;            while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
+            float nt = pt.w;
+            while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
                 const bool go = mine != 0;
                 const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
                 mine &= mine - 1;
@@ -1922,8 +2071,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             if (act && nt != pt.w)
                 ((float *)pp)[3] = nt;
             if (winner) {
-                bmax[b] = best;
-                barg[b] = (uint8_t)col;
+                st_bm(b, best, col);
                 ((uint32_t *)(a.rec + b))[3] = (uint32_t)run;
                 atomicMax(&tmx[b >> 6], best);
                 atomicMax(&trn[b >> 6], run);
@@ -1933,11 +2081,30 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_p2 += d1 - d0; d0 = d1; }
         __syncthreads();
         if (prof) { d1 = __builtin_amdgcn_s_memtime(); c_b2 += d1 - d0; d0 = d1; }
-        if (tid == 0)
+        if (tid == 0) {
             sh.nwork = 0;
+            sh.nvis = 0;
+            sh.vnext = 0;
+        }
+        if constexpr (L3) {
+            // the touched super-tiles' maxima from their tiles' (final behind the barrier above)
+            for (unsigned long long touched = touched0; touched; touched &= touched - 1) {
+                const int u = (__builtin_ctzll(touched) >> 2) * 16 + wave;
+                const int t = u * 16 + (lane & 15);
+                int vm = lane < 16 && t < ntile ? tmx[t] : (int)0x80000000;
+                int vr = lane < 16 && t < ntile ? trn[t] : (int)0x80000000;
+                tpu3_wave_max_i32_fast_x2(vm, vr);
+                if (lane == 0) {
+                    gmx[u] = vm;
+                    grn[u] = vr;
+                }
+            }
+            __syncthreads();
+        }
     };
 
     int J = 1, r = 1;
+    int thr_keep = (int)0x80000000;                 // the candidate threshold carried from round to round
     for (int round = 0;; ++round) {
         const int par = round & 1;
         if (prof) c0 = __builtin_amdgcn_s_memtime();
@@ -1951,16 +2118,60 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             int vm = (int)0x80000000, vr = (int)0x80000000;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vm = max(vm, tmx[i * 64 + lane]);
-                vr = max(vr, trn[i * 64 + lane]);
+                vm = max(vm, gmx[i * 64 + lane]);
+                vr = max(vr, grn[i * 64 + lane]);
             }
             gbest = tpu3_wave_max_i32_fast(vm);
             rstar = tpu3_wave_max_i32_fast(vr);
         }
-        const int tmax = tvalid ? tmx[tq] : (int)0x80000000;
+        const int tmax = tvalid ? gmx[tq] : (int)0x80000000;
+        // the buckets of this wave's units in `ul` (a ballot over the quads' first lanes): body(bucket of this lane,
+        // its maximum, its best point's position) per tile.  L3: only the tiles whose maximum passes `pred`, listed
+        // first (a slice of the idle work list per wave) so that four tiles' loads are in flight together -- a
+        // dependent round trip per tile was 44 k cycles of a 118 k round.
+        auto for_tiles = [&](unsigned long long ul, auto pred, auto body) __attribute__((always_inline)) {
+            if constexpr (!L3) {
+                for (; ul; ul &= ul - 1) {
+                    const int b = (((int)__builtin_ctzll(ul) >> 2) * 16 + wave) * 64 + lane;
+                    body(b, bmax[b], (int)barg[b]);
+                }
+            } else {
+                uint32_t *wl = work + wave * 256;
+                int cnt = 0;
+                for (; ul; ul &= ul - 1) {
+                    const int t = (((int)__builtin_ctzll(ul) >> 2) * 16 + wave) * 16 + (lane & 15);
+                    const bool ok = lane < 16 && t < ntile && pred(tmx[t]);
+                    const unsigned long long om = __ballot(ok);
+                    if (ok)
+                        wl[cnt + __builtin_popcountll(om & ((1ull << lane) - 1ull))] = (uint32_t)t;
+                    cnt += __builtin_popcountll(om);
+                }
+                for (int i0 = 0; i0 < cnt; i0 += FL_CB) {
+                    int bv[FL_CB], mv[FL_CB], av[FL_CB];
+#pragma unroll
+                    for (int k = 0; k < FL_CB; ++k) {
+                        bv[k] = (int)wl[i0 + k < cnt ? i0 + k : i0] * 64 + lane;
+                        mv[k] = a.bm0[bv[k]];
+                        av[k] = (int)a.ba0[bv[k]];
+                    }
+#pragma unroll 1
+                    for (int i = i0; i < cnt && i < i0 + FL_CB; ++i) {
+                        body(bv[0], mv[0], av[0]);
+#pragma unroll
+                        for (int k = 0; k + 1 < FL_CB; ++k) {
+                            bv[k] = bv[k + 1]; mv[k] = mv[k + 1]; av[k] = av[k + 1];
+                        }
+                    }
+                }
+            }
+        };
         bool ties_top = gbest <= rstar;             // no bucket beats every runner-up: plain arg-max, tie rule
-        int thr = rstar;
+        // Any threshold >= R* is valid, and the buckets above a FIXED threshold only get fewer: the last round's,
+        // steered to list 100 .. 300 buckets, spares most rounds the bisection passes an overfull list costs (the
+        // buckets above R* alone number thousands at 3.8 M points).
+        int thr = L3 ? max(rstar, thr_keep < gbest ? thr_keep : rstar) : rstar;
         int total = 0;
+        bool raised = false;
         for (;;) {
             // the buckets with bmax > thr (ties_top: == gbest) of this wave's tiles
             unsigned long long tl = __ballot(tvalid && quad == 0 && (ties_top ? tmax == gbest : tmax > thr));
@@ -1969,19 +2180,17 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     sh.minkey = 0xFFFFFFFFu;
                 __syncthreads();
             }
-            while (tl) {
-                const int L = __builtin_ctzll(tl);
-                tl &= tl - 1;
-                const int t = (L >> 2) * 16 + wave, b = t * 64 + lane;
-                const int bm = bmax[b];
+            if (PROF) c_pass += 1;
+            auto tile_pred = [&](int v) __attribute__((always_inline)) { return ties_top ? v == gbest : v > thr; };
+            for_tiles(tl, tile_pred, [&](int b, int bm, int ba) __attribute__((always_inline)) {
                 const bool c = ties_top ? bm == gbest : bm > thr;
                 const unsigned long long cm = __ballot(c);
                 if (!cm)
-                    continue;
+                    return;
                 if (ties_top) {
                     if (c)
-                        atomicMin(&sh.minkey, TK[(size_t)b * FL_R + barg[b]]);
-                    continue;
+                        atomicMin(&sh.minkey, TK[(size_t)b * FL_R + ba]);
+                    return;
                 }
                 // (no memory access here: an entry is the maximum and the bucket; wave 0 fetches the coordinates of
                 // the ranked list in one round trip -- with the point loads in this loop every wave paid a dependent
@@ -1993,33 +2202,40 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
                 if (c && pos < FL_LIST) {
                     cl[pos * 2] = (uint32_t)bm;
-                    cl[pos * 2 + 1] = ((uint32_t)b << 4) | barg[b];
+                    cl[pos * 2 + 1] = ((uint32_t)b << 4) | (uint32_t)ba;
                 }
-            }
+            });
             __syncthreads();
             if (ties_top) {
                 // second sweep: the bucket holding the smallest key among the maxima enters, alone
                 const uint32_t mk = sh.minkey;
                 unsigned long long t2 = __ballot(tvalid && quad == 0 && tmax == gbest);
-                while (t2) {
-                    const int L = __builtin_ctzll(t2);
-                    t2 &= t2 - 1;
-                    const int t = (L >> 2) * 16 + wave, b = t * 64 + lane;
-                    if (bmax[b] == gbest) {
-                        const size_t w = (size_t)b * FL_R + barg[b];
+                for_tiles(t2, tile_pred, [&](int b, int bm, int ba) __attribute__((always_inline)) {
+                    if (bm == gbest) {
+                        const size_t w = (size_t)b * FL_R + ba;
                         if (TK[w] == mk) {
                             cl[0] = (uint32_t)gbest;
-                            cl[1] = ((uint32_t)b << 4) | barg[b];
+                            cl[1] = ((uint32_t)b << 4) | (uint32_t)ba;
                         }
                     }
-                }
+                });
                 __syncthreads();
                 total = 1;
                 break;
             }
             total = sh.ncand[par];
-            if (total <= FL_LIST)
-                break;
+            if (total <= FL_LIST) {
+                if (total >= FL_CAP || thr <= rstar || raised)
+                    break;
+                // too few for a full round: lower the threshold and collect again
+                __syncthreads();
+                if (tid == 0)
+                    sh.ncand[par] = 0;
+                const int gap = gbest - thr;
+                thr = gap < 0x20000000 ? max(rstar, thr - 3 * gap) : rstar;
+                __syncthreads();
+                continue;
+            }
             // more candidates than the list holds (the first rounds): raise the threshold (any threshold >= R* is valid)
             // and collect again
             __syncthreads();
@@ -2027,11 +2243,17 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 sh.ncand[par] = 0;
                 sh.stat[2] += 1;
             }
+            raised = true;
             if (gbest - thr <= 1)
                 ties_top = true;
             else
                 thr += (gbest - thr) >> 1;
             __syncthreads();
+        }
+        if (PROF) c_tot += total;
+        if (!ties_top) {
+            const int gap = gbest - thr;
+            thr_keep = total >= 2 * FL_CAP + FL_CAP / 2 ? thr : (gap < 0x40000000 ? thr - gap : (int)0x80000000);
         }
         if (prof) { c1 = __builtin_amdgcn_s_memtime(); c_coll += c1 - c0; c0 = c1; }
         // wave 0: the FL_CAP best of the list (a few bisection steps on the values it holds in registers -- the list
@@ -2052,7 +2274,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             int thr2 = (int)0x80000000, nsel = total;
             if (total > FL_CAP) {
                 int lo = rstar, hi = gbest, chi = 0;                // count(> lo) > FL_CAP >= count(> hi) = chi
-                for (int it = 0; it < 16 && hi - lo > 1; ++it) {
+                for (int it = 0; it < 24 && hi - lo > 1; ++it) {
                     const int mid = lo + ((hi - lo) >> 1);
                     int c = 0;
 #pragma unroll
@@ -2062,7 +2284,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                         lo = mid;
                     } else {
                         hi = mid; chi = c;
-                        if (c >= FL_CAP / 2)
+                        if (c >= FL_CAP - FL_CAP / 16)
                             break;
                     }
                 }
@@ -2086,6 +2308,9 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             const bool live = lane < nsel;
             const int cM = live ? sh.mrow[lane] : (int)0x80000000;
             const uint32_t cB = cl[2 * FL_LIST + (live ? lane : 0)];
+            // ONE round trip for the coordinates and keys of the whole list, the ranking below in its shadow
+            const float4 sp4 = TP[live ? cB : 0];
+            const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
             if (!live)
                 sh.mrow[lane] = (int)0x80000000;
             int rank = 0;
@@ -2106,24 +2331,26 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 }
             }
             if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
-                const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
-                sh.pkey[par][lane] = cK;
+                uint32_t *kt = cl + 2 * FL_LIST + FL_CAP;
+                kt[lane] = cK;
                 rank = 0;
-                for (int i = 0; i < nsel; ++i) {
-                    const int mi = sh.mrow[i];
-                    const uint32_t ki = sh.pkey[par][i];
-                    rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
+                for (int c0 = 0; c0 < nsel; c0 += 8) {
+                    const int4 m0 = *(const int4 *)(sh.mrow + c0), m1 = *(const int4 *)(sh.mrow + c0 + 4);
+                    const uint4 k0 = *(const uint4 *)(kt + c0), k1 = *(const uint4 *)(kt + c0 + 4);
+                    const int m8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                    const uint32_t k8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        rank += (m8[v] > cM || (m8[v] == cM && k8[v] < cK)) ? 1 : 0;
                 }
                 if (lane == 0) sh.stat[3] += 1;
             }
-            // into rank order, then ONE round trip for the coordinates and keys of the whole list
-            if (live)
-                cl[2 * FL_LIST + FL_CAP + rank] = cB;
-            const uint32_t sB = cl[2 * FL_LIST + FL_CAP + (live ? lane : 0)];
-            const float4 sp4 = TP[live ? sB : 0];
-            okey = TK[live ? sB : 0];
-            if (live)
-                *(float4 *)sh.pick[par][lane] = sp4;            // (.w = the running distance = the bucket's maximum)
+            // into rank order
+            if (live) {
+                *(float4 *)sh.pick[par][rank] = sp4;            // (.w = the running distance = the bucket's maximum)
+                sh.pkey[par][rank] = cK;
+            }
+            okey = sh.pkey[par][lane < nsel ? lane : 0];
             if (lane == 0) {
                 const int jm = nsel < left ? nsel : left;
                 sh.npick[par] = jm;
@@ -2139,17 +2366,16 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 sh.minkey = 0xFFFFFFFFu;
             __syncthreads();
             unsigned long long t2 = __ballot(tvalid && quad == 0 && tmax == gbest);
-            for (unsigned long long tt = t2; tt; tt &= tt - 1) {
-                const int b = ((__builtin_ctzll(tt) >> 2) * 16 + wave) * 64 + lane;
-                if (bmax[b] == gbest)
-                    atomicMin(&sh.minkey, TK[(size_t)b * FL_R + barg[b]]);
-            }
+            auto top_pred = [&](int v) __attribute__((always_inline)) { return v == gbest; };
+            for_tiles(t2, top_pred, [&](int b, int bm, int ba) __attribute__((always_inline)) {
+                if (bm == gbest)
+                    atomicMin(&sh.minkey, TK[(size_t)b * FL_R + ba]);
+            });
             __syncthreads();
             const uint32_t mk = sh.minkey;
-            for (unsigned long long tt = t2; tt; tt &= tt - 1) {
-                const int b = ((__builtin_ctzll(tt) >> 2) * 16 + wave) * 64 + lane;
-                if (bmax[b] == gbest) {
-                    const size_t w = (size_t)b * FL_R + barg[b];
+            for_tiles(t2, top_pred, [&](int b, int bm, int ba) __attribute__((always_inline)) {
+                if (bm == gbest) {
+                    const size_t w = (size_t)b * FL_R + ba;
                     if (TK[w] == mk) {
                         *(float4 *)sh.pick[par][0] = TP[w];
                         sh.pkey[par][0] = mk;
@@ -2157,7 +2383,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                         sh.jclear = 1;
                     }
                 }
-            }
+            });
             __syncthreads();
             jmax = 1;
             if (wave == 0)
@@ -2192,6 +2418,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         }
         __syncthreads();
         J = sh.jclear;
+        if (PROF) { c_nsel += jmax; c_cut += J < jmax ? 1 : 0; }
         if (wave == 0) {
             if (lane < J)
                 a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
@@ -2213,6 +2440,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         for (int i = 0; i < 8; ++i)
             a0.prof[i] = sh.stat[i];
         a0.prof[8] = c_p1; a0.prof[9] = c_b1; a0.prof[10] = c_p2; a0.prof[11] = c_b2;
+        a0.prof[12] = c_pass; a0.prof[13] = c_tot; a0.prof[14] = c_nsel; a0.prof[15] = c_cut;
     }
 }
 
@@ -2279,10 +2507,11 @@ bool fb_plan(int b, int n, FbPlan &p)
     }
     p.ng = p.ncell / FB_GS;
     p.npad = p.nb * bsz;
-    // 25 601 .. 262 144 points: the tile form (TPU3_FL=0: tuning hook, the 64-point-bucket kernel instead)
-    static const int use_fl = getenv("TPU3_FL") ? atoi(getenv("TPU3_FL")) : 1;
-    p.fl = use_fl && !p.rb_rows && !p.l3;
+    // 25 601 .. 262 144 points: the tile form; beyond (config C5), its three-level variant.  TPU3_FL=0 / TPU3_FL=1
+    // (tuning hooks): the 64-point-bucket kernel instead for all / for the three-level sizes.
+    static const int use_fl = getenv("TPU3_FL") ? atoi(getenv("TPU3_FL")) : 2;
     p.ntile = (n + FL_TP - 1) / FL_TP;
+    p.fl = use_fl && !p.rb_rows && (!p.l3 || (use_fl >= 2 && p.ntile <= FL_TMAX));
     p.fl_rec = p.fl_bm = p.fl_ba = p.fl_tt = 0;
     if (p.fl) {
         p.npad = p.ntile * FL_TP;
@@ -2471,8 +2700,9 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         a0.prof = g_tile_stats;
         g_tile_stats = nullptr;
         hipLaunchKernelGGL(fl_init_kernel, dim3(p.ntile, b), dim3(64), 0, s, a0);
-        const size_t lds = fl_lds_bytes(p.ntile);
-        void (*kern)(FbArgs) = a0.prof ? fl_main_kernel<true> : fl_main_kernel<false>;
+        const size_t lds = fl_lds_bytes(p.ntile, p.l3);
+        void (*kern)(FbArgs) = p.l3 ? (a0.prof ? fl_main_kernel<true, true> : fl_main_kernel<false, true>)
+                                    : (a0.prof ? fl_main_kernel<true, false> : fl_main_kernel<false, false>);
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return (int)e;

@@ -371,10 +371,11 @@ int tpu3_scatter_add_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c,
  * One-shot. */
 int tpu3_debug_fps_bucket_events(void *start, void *stop);
 int tpu3_debug_fps_level_stats(unsigned long long *stats);
-/* tpu3_debug_fps_tile_stats: the NEXT FPS call that takes the tile-form kernel (25 601 .. 262 144 points: a lane per
- * 16-point bucket) writes 8 device words: rounds, samples, rounds whose candidate list overflowed, rounds with equal
- * maxima among the candidates, wave 0's cycles in update / candidate collection / ranking, its tile visits (first
- * set of the batch).  One-shot; host-side state only. */
+/* tpu3_debug_fps_tile_stats: the NEXT FPS call that takes the tile-form kernel (25 601 .. 4 194 304 points: a lane
+ * per 16-point bucket) writes 16 device words: rounds, samples, threshold bisections, rounds with equal maxima among
+ * the candidates, wave 0's cycles in update / candidate collection / ranking, its tile visits, the update's split
+ * (phase 1, barrier, phase 2, barrier), collection passes, candidates listed, candidates ranked, rounds cut by the
+ * clearance test (first set of the batch).  One-shot; host-side state only. */
 int tpu3_debug_fps_tile_stats(unsigned long long *stats);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,
                                   int32_t *idx, void *workspace, size_t workspace_bytes,

@@ -16,7 +16,7 @@ if os.environ.get("REAL"):
     gg = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "c2_x16.npz"))
     x = torch.from_numpy(np.ascontiguousarray(gg["pred_concat"].transpose(0, 2, 1))).to(dev)
     n = x.shape[1]
-stats = torch.zeros(12, dtype=torch.int64, device=dev)
+stats = torch.zeros(16, dtype=torch.int64, device=dev)
 lib.tpu3_debug_fps_tile_stats(ctypes.c_void_p(stats.data_ptr()))
 idx = ops.fps(x, m)
 torch.cuda.synchronize()
@@ -24,6 +24,7 @@ st = stats.cpu().numpy()
 print("rounds %d samples %d (%.2f per round), overflow rounds %d, tie rounds %d" % (st[0], st[1], st[1] / max(1, st[0]), st[2], st[3]))
 print("wave 0 per round: apply %.0f cycles (%.1f tile visits), collect %.0f, rank %.0f" % (st[4] / max(1, st[0]), st[7] / max(1, st[0]), st[5] / max(1, st[0]), st[6] / max(1, st[0])))
 print("   apply split: phase 1 %.0f, barrier %.0f, phase 2 %.0f, barrier %.0f" % tuple(st[8 + i] / max(1, st[0]) for i in range(4)))
+print("   per round: %.2f collect passes, %.0f listed, %.1f selected, %.2f of the rounds cut by clearance" % tuple(st[12 + i] / max(1, st[0]) for i in range(4)))
 print("distinct picks:", int(idx.unique().numel()), "of", m)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
