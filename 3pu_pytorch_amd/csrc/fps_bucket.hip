@@ -1597,6 +1597,7 @@ constexpr int FL_WORK = 4096;            // work list entries: fewer than FL_DEN
 constexpr int FL_DENSE = 16;             // a tile with this many reached buckets is updated on the spot
 constexpr int FL_P2 = 3;                 // phase-2 steps of a wave whose points are fetched together
 constexpr int FL_VIS = 4096;             // L3: entries of the visit list (reached tiles of a round: all of them at most)
+constexpr bool FL_DEAL2 = false;         // two levels: the reached tiles dealt out over the waves too
 constexpr int FL_CB = 8;                 // L3: tiles of a wave whose maxima are fetched together when candidates are listed
 constexpr int FL_VB = 4;                 // L3: visits of a wave whose records are fetched together
 constexpr int FL_TMAX = 4096;            // tiles of the three-level form (256 super-tiles of 16): 4 194 304 points
@@ -1621,7 +1622,7 @@ static_assert(offsetof(FlShared, cand) % 16 == 0 && offsetof(FlShared, mrow) % 1
               "vector reads of the lists");
 constexpr size_t fl_lds_bytes(int ntile, bool l3)
 {
-    return (l3 ? (size_t)FL_TMAX * 8 + FL_VIS * 12 : (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15)) + 512 * 4 +
+    return (l3 ? (size_t)FL_TMAX * 8 + FL_VIS * 12 : (((size_t)ntile * 64 * 5 + 15) & ~(size_t)15) + 256 * 12) + 512 * 4 +
            (size_t)FL_WORK * 12 + sizeof(FlShared) + 64;
 }
 
@@ -1697,7 +1698,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
     int *grn = L3 ? gmx + 256 : trn;
     uint32_t *work = (uint32_t *)(grn + 256);                                           // [FL_WORK][3]
     uint32_t *vis = work + FL_WORK * 3;                                                 // L3: [FL_VIS][3], the visit list
-    FlShared &sh = *(FlShared *)(vis + (L3 ? FL_VIS * 3 : 0));
+    FlShared &sh = *(FlShared *)(vis + (L3 ? FL_VIS * 3 : 256 * 3));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = a.lb;
     float4 *__restrict__ TP = a.sp;
@@ -1938,13 +1939,22 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
         // 600 cycles of work, and the waves' shares differ by 2x: the reached tiles go on a visit list, a barrier, and
         // every wave takes every 16th entry, four visits' loads in flight.
         const unsigned long long touched0 = __ballot((mlo | mhi) != 0 && quad == 0);
-        if constexpr (!L3) {
+        if constexpr (!L3 && !FL_DEAL2) {
             for (unsigned long long touched = touched0; touched; touched &= touched - 1) {
                 const int L = __builtin_ctzll(touched);
                 const int u = (L >> 2) * 16 + wave;
                 const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
                 const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
                 visit_tile(u, ((unsigned long long)shi << 32) | slo, a.rec[u * 64 + lane], bmax[u * 64 + lane]);
+            }
+        } else if constexpr (!L3) {
+            int base = 0;
+            if (lane == 0 && touched0)
+                base = atomicAdd(&sh.nvis, (int)__builtin_popcountll(touched0));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((mlo | mhi) != 0 && quad == 0) {
+                uint32_t *v = vis + 3 * (base + __builtin_popcountll(touched0 & ((1ull << lane) - 1ull)));
+                v[0] = (uint32_t)tq; v[1] = mlo; v[2] = mhi;
             }
         } else {
             // the touched super-tiles' 16 tiles, a lane each and FOUR super-tiles per step (their tile boxes are one
@@ -1982,7 +1992,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 }
             }
         }
-        if constexpr (L3) {
+        if constexpr (L3 || FL_DEAL2) {
             __syncthreads();
             const int nv = sh.nvis;
             for (;;) {
@@ -1999,7 +2009,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                     const int i = i0 + k;
                     tv[k] = (int)vis[3 * (i < nv ? i : i0)];
                     rcv[k] = a.rec[tv[k] * 64 + lane];
-                    bmv[k] = a.bm0[tv[k] * 64 + lane];
+                    bmv[k] = L3 ? a.bm0[tv[k] * 64 + lane] : bmax[tv[k] * 64 + lane];
                 }
                 // (ONE copy of the visit: the batch rotates through the first slot)
 #pragma unroll 1

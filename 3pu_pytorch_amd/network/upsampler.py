@@ -64,48 +64,45 @@ class Net(torch.nn.Module):
         self.trace = None
 
     # ------------------------------------------------------------------------------------------
-    # training: the reference's flow (:52-58, :83-105), one random kNN patch per batch element
+    # training: one random kNN patch per batch element and level (reference :52-58, :83-105, :126-147)
     # ------------------------------------------------------------------------------------------
     def extract_xyz_feature_patch(self, batch_xyz, k, gt_xyz=None, gt_k=None):
-        """Training-mode patch extraction: Bx3xN -> Bx3xk (+ ground-truth patch Bx3xgt_k)."""
-        batch_size, _, num_point = batch_xyz.size()
-        seed_idx = torch.randint(low=0, high=num_point, size=[batch_size, 1], dtype=torch.int32,
-                                 layout=torch.strided, device=batch_xyz.device)
-        batch_seed_point = operations.gather_points(batch_xyz, seed_idx)
-        batch_xyz, _, _ = operations.group_knn(k, batch_seed_point, batch_xyz, unique=False, NCHW=True)
-        batch_xyz = torch.cat(torch.unbind(batch_xyz, dim=2), dim=0)
-        if gt_xyz is not None and gt_k is not None:
-            gt_xyz, _, _ = operations.group_knn(gt_k, batch_seed_point, gt_xyz, unique=False)
-            gt_xyz = torch.cat(torch.unbind(gt_xyz, dim=2), dim=0)
-        else:
-            gt_xyz = None
-        return batch_xyz, gt_xyz
+        """Training-mode patch extraction (the reference's method name, :44): every element of the batch draws
+        one seed point; its k nearest points of the cloud are the patch, its gt_k nearest points of the
+        ground truth the target.  Bx3xN -> Bx3xk, (Bx3xgt_k | None).
+        The seed draw is the reference's (:53: one int32 randint of shape (B,1) on the cloud's device), so a
+        recorded seed stream replays bit for bit."""
+        count, _, size = batch_xyz.shape
+        pick = torch.randint(0, size, (count, 1), dtype=torch.int32, device=batch_xyz.device)
+        centre = operations.gather_points(batch_xyz, pick)                      # (B,3,1)
 
-    def _forward_train(self, xyz, ratio, gt):
-        batch_size, _, num_point = xyz.size()
-        num_levels = int(log(ratio, self.step_ratio))
-        max_num_point = min(num_point, self.max_num_point)
-        for l in range(1, num_levels + 1):
-            curr_ratio = self.step_ratio ** l
-            if l > 1:
-                if xyz.size(-1) > max_num_point:
-                    gt_k = max_num_point * ratio // curr_ratio * self.step_ratio
-                    patch_xyz, gt = self.extract_xyz_feature_patch(
-                        xyz, max_num_point, gt_k=gt_k, gt_xyz=gt)
-                else:
-                    patch_xyz = xyz
-                patch_xyz_normalized, centroid, radius = operations.normalize_point_batch(
-                    patch_xyz, NCHW=True)
-                xyz, features = self.levels['level_%d' % l](
-                    patch_xyz, patch_xyz_normalized, previous_level4=(old_xyz, old_features))
-                xyz = xyz * radius + centroid
-                old_xyz = patch_xyz
-                old_features = features
+        def around(points, n_near, **layout):
+            near, _, _ = operations.group_knn(n_near, centre, points, unique=False, **layout)     # (B,3,1,n_near)
+            return near[:, :, 0, :]
+        patch = around(batch_xyz, k, NCHW=True)
+        target = around(gt_xyz, gt_k) if (gt_xyz is not None and gt_k is not None) else None
+        return patch, target
+
+    def _forward_train(self, cloud, ratio, truth):
+        depth = int(log(ratio, self.step_ratio))
+        cap = min(cloud.size(-1), self.max_num_point)       # points a level sees at most
+        carry = None                                        # (what the previous level saw, its features)
+        for at in range(1, depth + 1):
+            level = self.levels['level_%d' % at]
+            if carry is None:
+                seen = cloud
+                cloud, feat = level(seen, seen, previous_level4=None)
             else:
-                old_xyz = xyz
-                xyz, features = self.levels['level_%d' % l](xyz, xyz, previous_level4=None)
-                old_features = features
-        return xyz, gt
+                seen = cloud
+                if cloud.size(-1) > cap:
+                    # the ground truth shrinks with the patch: cap * ratio / step_ratio^(at-1) points
+                    target_size = cap * ratio // self.step_ratio ** at * self.step_ratio
+                    seen, truth = self.extract_xyz_feature_patch(cloud, cap, gt_xyz=truth, gt_k=target_size)
+                unit, centre, scale = operations.normalize_point_batch(seen, NCHW=True)
+                cloud, feat = level(seen, unit, previous_level4=carry)
+                cloud = cloud * scale + centre
+            carry = (seen, feat)
+        return cloud, truth
 
     # ------------------------------------------------------------------------------------------
     # inference: all patches of the batch advance level by level together
