@@ -1710,8 +1710,6 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
             barg[i] = a.ba0[i];
         }
     // a bucket's maximum / position of its best point: LDS, or (L3) the arrays the init kernel wrote, updated in place
-    auto ld_bm = [&](int b) __attribute__((always_inline)) { return L3 ? a.bm0[b] : bmax[b]; };
-    auto ld_ba = [&](int b) __attribute__((always_inline)) { return L3 ? (int)a.ba0[b] : (int)barg[b]; };
     auto st_bm = [&](int b, int best, int arg) __attribute__((always_inline)) {
         if constexpr (L3) {
             a.bm0[b] = best;

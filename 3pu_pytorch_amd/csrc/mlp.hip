@@ -890,7 +890,148 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(int blocks, in
         dw[e] = s;
 }
 
+// ---- any per-point layer of a Level (training): dW and db together --------------------------------------------
+// The prep convolutions, the lift and the regressor layers (3 .. 265 inputs, 3 .. 128 outputs over B*N or B*N*r
+// = 9 984 / 19 968 rows at config C3): autograd's weight gradient is a vendor GEMM of 65 .. 150 us (one or three
+// 32 x 32 tiles over K = 10^4) and its bias gradient a separate reduction.  Here the (cout x cin+1) block is cut
+// into 16-output x 64-input pieces (the bias rides along as the input column that is 1 everywhere), every piece
+// of every row range is one workgroup of the streaming kernel above, and the second stage adds the ranges'
+// pieces in a fixed order.
+struct WgradWideArgs {
+    long m;
+    int cin, cout, xs, dys;
+    const float *x, *dy;
+    float *partial;                      // (blocks, og * 16, cg * 64)
+    long rows_per_block;
+    int cg, og;                          // column groups of 64 (cin + 1 columns), output groups of 16
+};
+
+__global__ __launch_bounds__(256) void linear_wgrad_wide_kernel(WgradWideArgs a)
+{
+    constexpr int T = 4;
+    __shared__ float xs[WG_ROWS][16 * T + 1];
+    __shared__ float dys[WG_ROWS][17];
+    __shared__ v4f red[4][T][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int o0 = (blockIdx.y / a.cg) * 16, c0 = (blockIdx.y % a.cg) * 64;
+    const long r_lo = (long)blockIdx.x * a.rows_per_block;
+    const long r_hi = r_lo + a.rows_per_block < a.m ? r_lo + a.rows_per_block : a.m;
+    v4f acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (long r0 = r_lo; r0 < r_hi; r0 += WG_ROWS) {
+        __syncthreads();
+        for (int e = tid; e < WG_ROWS * 64; e += 256) {
+            const int r = e >> 6, c = c0 + (e & 63);
+            xs[r][e & 63] = r0 + r < r_hi ? (c < a.cin ? a.x[(r0 + r) * a.xs + c] : (c == a.cin ? 1.f : 0.f)) : 0.f;
+        }
+        for (int e = tid; e < WG_ROWS * 16; e += 256) {
+            const int r = e >> 4, o = o0 + (e & 15);
+            dys[r][e & 15] = (r0 + r < r_hi && o < a.cout) ? a.dy[(r0 + r) * a.dys + o] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < WG_ROWS / 16; ++s) {
+            const int r = wave * 16 + 4 * s + g;
+            const float av = dys[r][i];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xs[r][16 * t + i], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        red[wave][t][lane] = acc[t];
+    __syncthreads();
+    if (wave == 0) {
+        const int cpad = a.cg * 64;
+        float *p = a.partial + ((size_t)blockIdx.x * (a.og * 16) + o0) * cpad + c0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const v4f v = (red[0][t][lane] + red[1][t][lane]) + (red[2][t][lane] + red[3][t][lane]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                p[(size_t)(4 * g + q) * cpad + 16 * t + i] = v[q];
+        }
+    }
+}
+
+// a thread per element of [dW | db]: the row ranges' pieces in order (coalesced over the elements)
+__global__ __launch_bounds__(256) void linear_wgrad_wide_reduce_kernel(int blocks, int cin, int cout, int cg, int og,
+                                                                       const float *__restrict__ partial,
+                                                                       float *__restrict__ dw, float *__restrict__ db)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cout * (cin + 1))
+        return;
+    const int o = e / (cin + 1), c = e - o * (cin + 1);
+    const size_t cpad = (size_t)cg * 64, step = (size_t)og * 16 * cpad;
+    const float *p = partial + (size_t)o * cpad + c;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b)
+        s += p[b * step];
+    if (c < cin)
+        dw[(size_t)o * cin + c] = s;
+    else if (db)
+        db[o] = s;
+}
+
+struct WgradWidePlan {
+    int cg, og;
+    long blocks, rpb;
+    size_t bytes;
+};
+
+WgradWidePlan wgrad_wide_plan(long m, int cin, int cout)
+{
+    WgradWidePlan p;
+    p.cg = (cin + 1 + 63) / 64;
+    p.og = (cout + 15) / 16;
+    long blocks = 2048 / (p.cg * p.og);                     // ~2048 workgroups in flight
+    const long most = (m + 4 * WG_ROWS - 1) / (4 * WG_ROWS);
+    if (blocks > most) blocks = most;
+    if (blocks < 1) blocks = 1;
+    p.rpb = (m + blocks - 1) / blocks;
+    p.rpb = (p.rpb + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    if (p.rpb < WG_ROWS) p.rpb = WG_ROWS;
+    p.blocks = m > 0 ? (m + p.rpb - 1) / p.rpb : 1;
+    p.bytes = (size_t)p.blocks * p.og * 16 * p.cg * 64 * sizeof(float);
+    return p;
+}
+
 } // namespace
+
+extern "C" size_t tpu3_linear_wgrad_bias_workspace_bytes(long m, int cin, int cout)
+{
+    if (m < 0 || cin <= 0 || cout <= 0) return 0;
+    return wgrad_wide_plan(m, cin, cout).bytes;
+}
+
+extern "C" int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
+                                          int x_stride, const float *dy, int dy_stride, float *dw, float *db,
+                                          void *workspace, size_t workspace_bytes)
+{
+    if (m < 0 || cin <= 0 || cout <= 0 || x_stride < cin || dy_stride < cout) return TPU3_EINVAL;
+    if (cin > 1023 || cout > 1024) return TPU3_ELIMIT;
+    if (!dw) return TPU3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) {
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)cin * cout * sizeof(float), s);
+        if (e == hipSuccess && db)
+            e = hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), s);
+        return (int)e;
+    }
+    if (!x || !dy) return TPU3_EINVAL;
+    const WgradWidePlan p = wgrad_wide_plan(m, cin, cout);
+    if (!workspace || workspace_bytes < p.bytes) return TPU3_EINVAL;
+    WgradWideArgs a{m, cin, cout, x_stride, dy_stride, x, dy, (float *)workspace, p.rpb, p.cg, p.og};
+    hipLaunchKernelGGL(linear_wgrad_wide_kernel, dim3((unsigned)p.blocks, (unsigned)(p.cg * p.og)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(linear_wgrad_wide_reduce_kernel, dim3((cout * (cin + 1) + 255) / 256), dim3(256), 0, s,
+                       (int)p.blocks, cin, cout, p.cg, p.og, (const float *)workspace, dw, db);
+    return tpu3_launch_status();
+}
 
 extern "C" size_t tpu3_linear_wgrad_workspace_bytes(long m)
 {

@@ -50,6 +50,51 @@ class _SkinnyLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _PointwiseLayer(torch.autograd.Function):
+    """y = act(x W^T + b), act = identity | ReLU, for the per-point layers of a Level in training (lift, prep
+    convolutions, regressor).  Forward and dX are vendor GEMMs; dW and db come from ONE streaming pass over
+    (x, dy) (tpu3_linear_wgrad_bias_f32, deterministic) instead of autograd's 65 .. 150 us skinny GEMM plus a
+    column reduction, and the ReLU mask is applied to dy once for all three."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = F.linear(x, weight, bias)
+        if relu:
+            y = torch.relu_(y)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = gy.contiguous()
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        g2 = g.reshape(-1, g.size(-1))
+        gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            res = operations.BACKEND.linear_wgrad_bias(x.reshape(-1, x.size(-1)), g2)
+            if res is None:
+                gw, gb = g2.t().matmul(x.reshape(-1, x.size(-1))), g2.sum(dim=0)
+            else:
+                gw, gb = res
+        return gx, gw, gb, None
+
+
+def pointwise_train(layer, x):
+    """Training shortcut of a pointwise Conv1d / Conv2d (activation None / ReLU, bias, no normalisation) on a
+    device: one autograd node, see _PointwiseLayer.  None = not applicable."""
+    conv = layer.conv
+    if (not torch.is_grad_enabled() or not x.is_cuda or layer.activation not in (None, "relu") or conv.bias is None
+            or not conv.weight.requires_grad or x.dtype != torch.float32 or x.numel() // x.size(-1) < 1024
+            or not hasattr(operations.BACKEND, "linear_wgrad_bias")):
+        return None
+    w = conv.weight
+    return _PointwiseLayer.apply(x, w.view(w.size(0), w.size(1)), conv.bias, layer.activation == "relu")
+
+
 class _GatherRows(torch.autograd.Function):
     """knn_point = x[b, idx] (group_knn's differentiable gather, reference operations.py:209-211) with the backward
     as ONE atomic scatter-add launch: torch's index backward sorts the 3e5 indices of every DenseEdgeConv block
@@ -464,6 +509,11 @@ class Conv2d(nn.Module):
         y = _fused_linear(self, x, also)
         if y is not None:
             return y
+        y = pointwise_train(self, x)
+        if y is not None:
+            if also is not None:
+                also.copy_(y)
+            return y
         x = linear_1x1(self.conv, x)
         if self.activation is not None:
             x = self.act(x)
@@ -504,6 +554,9 @@ class Conv1d(nn.Module):
     def forward_cl(self, x):
         assert self.pointwise()
         y = _fused_linear(self, x)
+        if y is not None:
+            return y
+        y = pointwise_train(self, x)
         if y is not None:
             return y
         x = linear_1x1(self.conv, x)

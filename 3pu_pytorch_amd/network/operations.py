@@ -465,6 +465,24 @@ class HipBackend(object):
                                               dy.stride(0), L.ptr(dw), L.ptr(ws), need), "tpu3_linear_wgrad_f32")
         return dw
 
+    def linear_wgrad_bias(self, x, dy, want_bias=True):
+        """x (M, C_in), dy (M, C_out) f32 rows with unit channel stride -> (dW (C_out, C_in) = dy^T x,
+        db (C_out) = column sums of dy | None): tpu3_linear_wgrad_bias_f32, any layer width of a Level."""
+        m, cin = x.shape
+        cout = dy.size(1)
+        if cin > 1023 or cout > 1024 or x.stride(1) != 1 or dy.stride(1) != 1 or x.dtype != torch.float32:
+            return None
+        lib = L.lib()
+        need = lib.tpu3_linear_wgrad_bias_workspace_bytes(m, cin, cout)
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+        with torch.cuda.device(x.device):
+            L.check(lib.tpu3_linear_wgrad_bias_f32(L.stream_of(x), m, cin, cout, L.ptr(x), x.stride(0), L.ptr(dy),
+                                                   dy.stride(0), L.ptr(dw), L.ptr(db), L.ptr(ws), need),
+                    "tpu3_linear_wgrad_bias_f32")
+        return dw, db
+
     def regress_tail(self, a, c, w2, b2, w3, b3, w4, b4, residual, mfma=L.MFMA_F32):
         """a (M,128), c (r,128), residual (M,3) -> (M*r, 3); see tpu3_regress_tail_f32."""
         m, r = a.size(0), c.size(0)

@@ -324,6 +324,18 @@ int tpu3_linear_wgrad_f32(tpu3_stream_t stream, long m, int cin, int cout, const
                           const float *dy, int dy_stride, float *dw, void *workspace, size_t workspace_bytes);
 size_t tpu3_linear_wgrad_workspace_bytes(long m);
 
+/* Training: weight AND bias gradient of any kernel-size-1 convolution of a Level (network/upsampler.py:209-224:
+ * layer0 3 -> 24, layerK_prep 84/144/204 -> 24, up_layer 265 -> 128 -> 128, fc_layer1 128 -> 64, fc_layer2 64 -> 3;
+ * what autograd computes for their nn.Conv1d / nn.Conv2d, model.py:53-66):
+ *   dw[o][c] = sum_i dy[i][o] * x[i][c],  db[o] = sum_i dy[i][o]   (db may be null)
+ * x (m, x_stride), dy (m, dy_stride) rows with unit channel stride, dw (cout, cin) row-major.  cin <= 1023,
+ * cout <= 1024 (else TPU3_ELIMIT).  Deterministic (two stages, no atomics); workspace =
+ * tpu3_linear_wgrad_bias_workspace_bytes(m, cin, cout) device bytes.  fp32 MFMA. */
+int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                               const float *dy, int dy_stride, float *dw, float *db, void *workspace,
+                               size_t workspace_bytes);
+size_t tpu3_linear_wgrad_bias_workspace_bytes(long m, int cin, int cout);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,

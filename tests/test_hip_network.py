@@ -910,6 +910,39 @@ def test_linear_small_matches_torch(dev, m, cin, cout, relu, off):
     assert ops.BACKEND.linear_small(wide[:, 1:1 + cin], w, b, relu) is None
 
 
+@pytest.mark.parametrize("m,cin,cout,relu", [(9984, 3, 24, False), (9984, 204, 24, True), (19968, 265, 128, True),
+                                             (19968, 128, 64, True), (19968, 64, 3, False), (1111, 63, 17, True)])
+def test_linear_wgrad_bias_and_pointwise_layer(dev, m, cin, cout, relu):
+    """tpu3_linear_wgrad_bias_f32 (dW and db of any per-point layer of a Level, strided rows) against fp64; the
+    autograd node built on it (network/layers.py _PointwiseLayer) against plain autograd of the same layer."""
+    ops, layers = pkg("network.operations"), pkg("network.layers")
+    g = torch.Generator(device="cpu").manual_seed(m + cin)
+    x = torch.randn(m, cin + 4, generator=g).to(dev)[:, :cin]
+    dy = torch.randn(m, cout + 1, generator=g).to(dev)[:, :cout]
+    dw, db = ops.BACKEND.linear_wgrad_bias(x, dy)
+    ref = dy.double().t() @ x.double()
+    assert dw.shape == (cout, cin) and db.shape == (cout,)
+    assert ((dw.double() - ref).abs() / (ref.abs() + m ** 0.5)).max() < 1e-5
+    assert ((db.double() - dy.double().sum(0)).abs() / m ** 0.5).max() < 1e-5
+    dw2, db2 = ops.BACKEND.linear_wgrad_bias(x, dy)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                    # deterministic
+    layer = layers.Conv1d(cin, cout, 1, activation="relu" if relu else None).to(dev)
+    xa = x.contiguous().requires_grad_(True)
+    xb = x.contiguous().requires_grad_(True)
+    ya = layers.pointwise_train(layer, xa)
+    assert ya is not None
+    (ya * dy).sum().backward()
+    got = (xa.grad, layer.conv.weight.grad.clone(), layer.conv.bias.grad.clone())
+    layer.zero_grad()
+    yb = torch.nn.functional.linear(xb, layer.conv.weight.view(cout, cin), layer.conv.bias)
+    yb = torch.relu(yb) if relu else yb
+    (yb * dy).sum().backward()
+    assert (ya - yb).abs().max() < 1e-5
+    assert (got[0] - xb.grad).abs().max() < 1e-4
+    assert ((got[1].view(cout, cin) - layer.conv.weight.grad.view(cout, cin)).abs() / m ** 0.5).max() < 1e-4
+    assert ((got[2] - layer.conv.bias.grad).abs() / m ** 0.5).max() < 1e-4
+
+
 @pytest.mark.parametrize("m,cin,cout", [(319488, 48, 12), (20000, 36, 12), (70001, 64, 16), (100, 5, 3)])
 def test_linear_wgrad_matches_torch(dev, m, cin, cout):
     """tpu3_linear_wgrad_f32 (dW = dy^T x of a skinny layer over many rows) against fp64, reading

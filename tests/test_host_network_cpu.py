@@ -214,6 +214,52 @@ def test_net_train_forward_matches_reference(net_modules, ratio):
     np.testing.assert_allclose(pred.numpy(), g["pred_x%d" % ratio], rtol=0, atol=1e-5)
 
 
+def _train_grads(ups, device):
+    """The net_train_grad.npz case on `device`: (pred, gt, input gradient, {parameter: gradient})."""
+    g = golden("net_train_grad.npz")
+    net = _net(ups).train().to(device)
+    seeds = [torch.from_numpy(s) for s in g["seeds"]]
+    real = torch.randint
+    calls = []
+
+    def replay(*a, **kw):
+        calls.append(1)
+        return seeds[len(calls) - 1].clone().to(kw.get("device", "cpu"))
+    inp = torch.from_numpy(g["input"]).to(device).requires_grad_(True)
+    torch.randint = replay
+    try:
+        pred, gt = net(inp, ratio=8, gt=torch.from_numpy(g["gt"]).to(device))
+    finally:
+        torch.randint = real
+    assert len(calls) == len(seeds)
+    (pred * torch.from_numpy(g["w"]).to(device)).sum().backward()
+    grads = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    return g, pred, gt, inp.grad, grads
+
+
+def check_train_grads(g, pred, gt, ginp, grads, tol):
+    np.testing.assert_array_equal(gt.cpu().numpy(), g["gtout"])
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], rtol=0, atol=1e-5)
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad_level")}
+    assert sorted(ref) == sorted(grads)
+    worst = 0.0
+    for name, r in ref.items():
+        mine = grads[name].cpu().numpy()
+        scale = max(1e-6, float(np.abs(r).max()))
+        worst = max(worst, float(np.abs(mine - r).max()) / scale)
+    assert worst < tol, worst
+    gi = g["grad_input"]
+    assert float(np.abs(ginp.cpu().numpy() - gi).max()) / float(np.abs(gi).max()) < tol
+
+
+def test_net_train_backward_matches_reference(net_modules):
+    """Gradients of the reference's training forward (ratio 8: level 3's previous cloud is a network output, so
+    the inter-level skip's gathered neighbour COORDINATES carry a gradient too, reference operations.py:209-211):
+    every parameter of levels 1-3 and the input, max error relative to the tensor's largest gradient."""
+    _, ups = net_modules
+    check_train_grads(*_train_grads(ups, "cpu"), tol=2e-4)
+
+
 def test_net_train_backward_reaches_every_level(net_modules):
     _, ups = net_modules
     net = _net(ups).train()
