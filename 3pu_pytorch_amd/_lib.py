@@ -40,6 +40,9 @@ SIGNATURES = {
     "tpu3_knn_unique_workspace_bytes": (_sz, [_i, _i]),
     "tpu3_interlevel_skip_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _i,
                                       _vp, _sz]),
+    "tpu3_interlevel_skip_train_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp,
+                                            _vp, _sz]),
+    "tpu3_interlevel_skip_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp]),
     "tpu3_interlevel_skip_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpu3_linear_small_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i]),
     "tpu3_dec_train_fwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

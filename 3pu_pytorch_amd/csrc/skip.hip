@@ -46,6 +46,7 @@ struct SkipArgs {
     int slices, slice_len;           // workgroups per patch, points per workgroup
     float *dist;                     // scratch (B,n,2K): spatial then feature distances
     float *mins;                     // scratch (B,n,2): min_k of either
+    float *wout;                     // training: (B,n,K) receives the normalised weights, else null
 };
 
 // workgroup -> (patch, slice).  Workgroups are dealt round-robin to the 8 XCDs, each with its own
@@ -385,6 +386,8 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
             tot += w[kk] + 1e-5f;
         }
         const float mine_w = mine / tot;
+        if (a.wout && lane < K)
+            a.wout[((size_t)b * n + i) * K + lane] = mine_w;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk)
             w[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_w), kk));
@@ -467,6 +470,52 @@ int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec)
 
 constexpr int SK_SLICE_POINTS = 52;      // 312-point patches: 6 workgroups of 13 points per wave
 
+// Training, backward.  The reference detaches both distances (network/upsampler.py:244-245), so the weights are
+// constants of the step and x_out = x + scale * sum_k w_k f_k has two gradients: g itself for x, and for the previous
+// level's features a scatter  gprev[nbr_k] += scale * w_k * g_i  -- a wave per point, lanes across the channels,
+// hardware float atomics (the rows of a previous patch are hit ~5 times each, in no fixed order).
+struct SkipBwdArgs {
+    int n, k, c, m;
+    long points;                     // b * n
+    const float *g;                  // (b,n,c)
+    const float *w;                  // (b,n,k)
+    const int32_t *pts_of;           // (b) or null
+    const void *idx;
+    int idx64;
+    float scale;
+    float *gprev;                    // (bp,m,c), accumulated
+};
+
+__global__ __launch_bounds__(SK_THREADS) void skip_bwd_kernel(SkipBwdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * (SK_THREADS / 64) + (threadIdx.x >> 6);
+    if (p >= a.points)
+        return;
+    const int b = (int)(p / a.n);
+    const int pb = a.pts_of ? a.pts_of[b] : b;
+    const float *G = a.g + (size_t)p * a.c;
+    float gv[SK_CPL];
+#pragma unroll
+    for (int u = 0; u < SK_CPL; ++u)
+        gv[u] = lane + 64 * u < a.c ? G[lane + 64 * u] : 0.f;
+    for (int kk = 0; kk < a.k; ++kk) {
+        const size_t e = (size_t)p * a.k + kk;
+        const long nb = a.idx64 ? (long)((const int64_t *)a.idx)[e] : (long)((const int32_t *)a.idx)[e];
+        const float w = a.scale * a.w[e];
+        float *D = a.gprev + ((size_t)pb * a.m + nb) * a.c;
+#pragma unroll
+        for (int u = 0; u < SK_CPL; ++u)
+            if (lane + 64 * u < a.c)
+                atomicAdd(D + lane + 64 * u, w * gv[u]);
+    }
+}
+
+int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, float *feat, int feat_stride,
+                 const float *prev_xyz, const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+                 int idx_elem_size, float scale, int patches_per_cloud, void *workspace, size_t workspace_bytes,
+                 float *wout);
+
 } // namespace
 
 extern "C" size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k)
@@ -482,12 +531,49 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
                                         int idx_elem_size, float scale, int patches_per_cloud, void *workspace,
                                         size_t workspace_bytes)
 {
+    return skip_forward((hipStream_t)stream, b, n, k, c, xyz, feat, feat_stride, prev_xyz, prev_feat, m, pts_of, idx,
+                        idx_elem_size, scale, patches_per_cloud, workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int tpu3_interlevel_skip_train_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
+                                              float *feat, int feat_stride, const float *prev_xyz,
+                                              const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+                                              int idx_elem_size, float scale, float *weights, void *workspace,
+                                              size_t workspace_bytes)
+{
+    if (!weights) return TPU3_EINVAL;
+    return skip_forward((hipStream_t)stream, b, n, k, c, xyz, feat, feat_stride, prev_xyz, prev_feat, m, pts_of, idx,
+                        idx_elem_size, scale, 0, workspace, workspace_bytes, weights);
+}
+
+extern "C" int tpu3_interlevel_skip_bwd_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *g,
+                                            const float *weights, int m, const int32_t *pts_of, const void *idx,
+                                            int idx_elem_size, float scale, float *gprev)
+{
+    if (b < 0 || n <= 0 || k <= 0 || k > SK_KMAX || c <= 0 || c > 64 * SK_CPL || m <= 0) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (b == 0) return TPU3_OK;
+    if (!g || !weights || !idx || !gprev) return TPU3_EINVAL;
+    const long points = (long)b * n;
+    const long blocks = (points + SK_THREADS / 64 - 1) / (SK_THREADS / 64);
+    if (blocks > 0x7FFFFFFF) return TPU3_ELIMIT;
+    SkipBwdArgs a{n, k, c, m, points, g, weights, pts_of, idx, idx_elem_size == 8, scale, gprev};
+    hipLaunchKernelGGL(skip_bwd_kernel, dim3((unsigned)blocks), dim3(SK_THREADS), 0, (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
+
+namespace {
+
+int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, float *feat, int feat_stride,
+                 const float *prev_xyz, const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+                 int idx_elem_size, float scale, int patches_per_cloud, void *workspace, size_t workspace_bytes,
+                 float *wout)
+{
     if (b < 0 || n <= 0 || k <= 0 || k > SK_KMAX || c <= 0 || c > 64 * SK_CPL || m <= 0) return TPU3_EINVAL;
     if (feat_stride < c || (idx_elem_size != 4 && idx_elem_size != 8)) return TPU3_EINVAL;
     if (b == 0) return TPU3_OK;
     if (!xyz || !feat || !prev_xyz || !prev_feat || !idx) return TPU3_EINVAL;
     const size_t need = tpu3_interlevel_skip_workspace_bytes(b, n, k);
-    hipStream_t s = (hipStream_t)stream;
     void *own = nullptr;
     if (!workspace || workspace_bytes < need) {     // caller gave no scratch: stream-ordered allocation
         const hipError_t e = hipMallocAsync(&own, need, s);
@@ -501,7 +587,7 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
     const int remap = per ? (b / per / 8) * 8 * per * slices : 0;
     float *dist = (float *)workspace;
     SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale,
-               per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k};
+               per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k, wout};
     // float4 rows: every row start must be 16-byte aligned
     const bool vec = c % 4 == 0 && c <= 288 && feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 &&
                      ((uintptr_t)prev_feat & 15) == 0;
@@ -523,3 +609,6 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
     }
     return r;
 }
+
+} // namespace
+

@@ -322,6 +322,32 @@ class HipBackend(object):
                 "tpu3_interlevel_skip_f32")
         return feat
 
+    def interlevel_skip_train(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2):
+        """Training forward of the skip connection: feat (B,N,C) updated in place, -> weights (B,N,K), the
+        normalised bilateral weights the backward needs (tpu3_interlevel_skip_train_f32)."""
+        B, N, C = feat.shape
+        K = idx.size(2)
+        need = L.lib().tpu3_interlevel_skip_workspace_bytes(B, N, K)
+        ws = torch.empty((need,), dtype=torch.uint8, device=feat.device)
+        weights = torch.empty((B, N, K), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            L.check(L.lib().tpu3_interlevel_skip_train_f32(
+                L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
+                L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale),
+                L.ptr(weights), L.ptr(ws), need), "tpu3_interlevel_skip_train_f32")
+        return weights
+
+    def interlevel_skip_backward(self, g, weights, idx, pts_of, prev_shape, scale=0.2):
+        """g (B,N,C) -> gradient of the previous level's features (Bp,M,C): scatter of scale * w_k * g_i
+        (tpu3_interlevel_skip_bwd_f32; float atomics)."""
+        B, N, C = g.shape
+        gprev = torch.zeros(prev_shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            L.check(L.lib().tpu3_interlevel_skip_bwd_f32(
+                L.stream_of(g), B, N, idx.size(2), C, L.ptr(g), L.ptr(weights), prev_shape[1], L.ptr(pts_of),
+                L.ptr(idx), idx.element_size(), float(scale), L.ptr(gprev)), "tpu3_interlevel_skip_bwd_f32")
+        return gprev
+
     def linear_small(self, x, weight, bias, relu, mfma=L.MFMA_F32):
         """Per-point linear layer with <= 32 outputs (fp16 operands: <= 128) on channel-last rows: x (..., C_in)
         with unit channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),

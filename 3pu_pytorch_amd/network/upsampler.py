@@ -247,6 +247,30 @@ class Net(torch.nn.Module):
         return self._forward_eval(xyz, ratio)
 
 
+class _SkipTrain(torch.autograd.Function):
+    """Inter-level skip connection of a Level under autograd: x (B,N,C) is updated in place by the fused forward,
+    which also leaves the weights (B,N,K); backward hands g to x and scatters 0.2 * w_k * g_i into the rows of the
+    previous level's features the point interpolated from."""
+
+    @staticmethod
+    def forward(ctx, x, prev_feat, xyz, prev_xyz, pts_of, idx):
+        weights = operations.BACKEND.interlevel_skip_train(xyz, x, prev_xyz, prev_feat, pts_of, idx)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(weights, idx, pts_of if pts_of is not None else idx)
+        ctx.owned = pts_of is not None
+        ctx.prev_shape = tuple(prev_feat.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        weights, idx, pts_of = ctx.saved_tensors
+        gprev = None
+        if ctx.needs_input_grad[1]:
+            gprev = operations.BACKEND.interlevel_skip_backward(g.contiguous(), weights, idx,
+                                                                pts_of if ctx.owned else None, ctx.prev_shape)
+        return g, gprev, None, None, None, None
+
+
 class Level(torch.nn.Module):
     """3PU per-level network (reference :192-374)."""
 
@@ -445,15 +469,24 @@ class Level(torch.nn.Module):
                 pts_of = layout["pts_of"].long()
             else:
                 pts_of = None
-            fused = (not torch.is_grad_enabled() and hasattr(operations.BACKEND, "interlevel_skip")
-                     and x.is_cuda and x.is_contiguous() and self.fm_knn <= 8 and x.size(-1) <= 320)
+            covered = x.is_cuda and x.is_contiguous() and self.fm_knn <= 8 and x.size(-1) <= 320
+            fused = not torch.is_grad_enabled() and hasattr(operations.BACKEND, "interlevel_skip") and covered
+            fused_train = (torch.is_grad_enabled() and hasattr(operations.BACKEND, "interlevel_skip_train")
+                           and covered and x.dtype == torch.float32)
             if not fused and not torch.is_grad_enabled():
                 operations.note_generic_path("inter-level skip with fm_knn=%d, %d channels (fused kernel: "
                                              "fm_knn <= 8, <= 320 channels)" % (self.fm_knn, x.size(-1)))
             with torch.no_grad():
                 knn_idx, _, knn_points = operations.knn_query(
                     self.fm_knn, xyz.detach(), prev_xyz.detach(), unique=True, layout=layout,
-                    want_dist=False, want_grouped=not fused, unique_cache=unique_cache)
+                    want_dist=False, want_grouped=not (fused or fused_train), unique_cache=unique_cache)
+            if fused_train:
+                # one autograd node (csrc/skip.hip): the weights are constants of the step (the reference detaches
+                # both distances, :244-245), so x gets g and the previous features a weighted scatter of g
+                x = _SkipTrain.apply(x, prev_feat.contiguous(), xyz.detach().contiguous(),
+                                     prev_xyz.detach().contiguous(),
+                                     None if pts_of is None else layout["pts_of"], knn_idx)
+                return self._regress(x, xyz_normalized, B, N)
             if fused:
                 operations.BACKEND.interlevel_skip(
                     xyz.contiguous(), x, prev_xyz.contiguous(), prev_feat.contiguous(),

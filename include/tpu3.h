@@ -270,6 +270,20 @@ int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, c
  * allocation inside) */
 size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 
+/* The same skip connection as ONE autograd node for training (model.py:53-66 runs network/upsampler.py:317-347 under
+ * autograd).  The reference detaches both distances (:244-245), so the weights are constants of the step:
+ *   forward  = tpu3_interlevel_skip_f32 that also stores the normalised weights, weights (b,n,k);
+ *   backward : the gradient of x_i is g_i itself; gprev (bp,m,c), ZEROED BY THE CALLER, accumulates
+ *              scale * weights[b,i,k] * g[b,i,:] at row idx[b,i,k] of previous cloud pts_of[b] (hardware float atomics,
+ *              summation order not fixed).  g (b,n,c) contiguous. */
+int tpu3_interlevel_skip_train_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz, float *feat,
+                                   int feat_stride, const float *prev_xyz, const float *prev_feat, int m,
+                                   const int32_t *pts_of, const void *idx, int idx_elem_size, float scale,
+                                   float *weights, void *workspace, size_t workspace_bytes);
+int tpu3_interlevel_skip_bwd_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *g,
+                                 const float *weights, int m, const int32_t *pts_of, const void *idx,
+                                 int idx_elem_size, float scale, float *gprev);
+
 /* Per-point linear layer with a small output width, inference (the "prep" convolutions of a
  * Level, network/upsampler.py:298,303,308: 84 / 144 / 204 -> 24 + ReLU; any kernel-size-1
  * nn.Conv1d / nn.Conv2d on channel-last data, network/layers.py:115-204):

@@ -237,17 +237,20 @@ def _train_grads(ups, device):
     return g, pred, gt, inp.grad, grads
 
 
-def check_train_grads(g, pred, gt, ginp, grads, tol):
+def check_train_grads(g, pred, gt, ginp, grads, tol, tol_median=None):
+    """Every parameter gradient against the fixture, error relative to the tensor's largest gradient: the worst
+    tensor below `tol`, the median tensor below `tol_median` (default: tol)."""
     np.testing.assert_array_equal(gt.cpu().numpy(), g["gtout"])
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], rtol=0, atol=1e-5)
     ref = {k[5:]: g[k] for k in g.files if k.startswith("grad_level")}
     assert sorted(ref) == sorted(grads)
-    worst = 0.0
+    errs = []
     for name, r in ref.items():
         mine = grads[name].cpu().numpy()
         scale = max(1e-6, float(np.abs(r).max()))
-        worst = max(worst, float(np.abs(mine - r).max()) / scale)
-    assert worst < tol, worst
+        errs.append(float(np.abs(mine - r).max()) / scale)
+    assert max(errs) < tol, max(errs)
+    assert float(np.median(errs)) < (tol if tol_median is None else tol_median), float(np.median(errs))
     gi = g["grad_input"]
     assert float(np.abs(ginp.cpu().numpy() - gi).max()) / float(np.abs(gi).max()) < tol
 
@@ -257,7 +260,7 @@ def test_net_train_backward_matches_reference(net_modules):
     the inter-level skip's gathered neighbour COORDINATES carry a gradient too, reference operations.py:209-211):
     every parameter of levels 1-3 and the input, max error relative to the tensor's largest gradient."""
     _, ups = net_modules
-    check_train_grads(*_train_grads(ups, "cpu"), tol=2e-4)
+    check_train_grads(*_train_grads(ups, "cpu"), tol=2e-5)          # measured 1.9e-6
 
 
 def test_net_train_backward_reaches_every_level(net_modules):
