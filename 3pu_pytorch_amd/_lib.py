@@ -56,6 +56,9 @@ SIGNATURES = {
     "tpu3_linear_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),
     "tpu3_linear_wgrad_bias_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz]),
     "tpu3_linear_wgrad_bias_workspace_bytes": (_sz, [ctypes.c_long, _i, _i]),
+    "tpu3_dec_train_wgrad_f32": (_i, [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "tpu3_dec_train_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),
+    "tpu3_linear_dgrad_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i]),
     "tpu3_regress_tail_f32": (_i, [_vp, ctypes.c_long, _i] + [_vp] * 10 + [_i]),
     "tpu3_knn_unique_compact_i32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_knn_graph_self_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp, _vp, _sz]),

@@ -978,6 +978,189 @@ __global__ __launch_bounds__(256) void linear_wgrad_wide_reduce_kernel(int block
         db[o] = s;
 }
 
+// The same gradient with the whole (cout x cin+1) block in ONE workgroup per row range (cout <= 128, cin <= 319: every
+// layer of a Level): a 64-row tile of x (all columns, the ones column, zero padding) and of dy sits in LDS, each
+// wave owns every fourth 16-column tile for all OG output groups -- x and dy are read from memory exactly once, an A
+// operand serves CTW matrix instructions, and a tile of the 265 -> 128 layer is 640 of them per wave against ~100
+// loads per thread (the piecewise kernel above re-reads x per output group and dy per column group and spends most
+// of its time staging: 150 us for that layer, the vendor GEMM's time).
+struct WgradAllArgs {
+    long m;
+    int cin, cout, xs, dys;
+    const float *x, *dy;
+    float *partial;                      // (blocks, OG * 16, ct * 16)
+    long rows_per_block;
+    int ct;                              // 16-column tiles of cin + 1 columns
+};
+
+template <int OG, int CTW>
+__global__ __launch_bounds__(256) void linear_wgrad_all_kernel(WgradAllArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    const int xc = a.ct * 16, xw = xc + 1, yw = OG * 16 + 1;
+    float *xs = wg_lds;                  // [64][xw]
+    float *dys = wg_lds + 64 * xw;       // [64][yw]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const long r_lo = (long)blockIdx.x * a.rows_per_block;
+    const long r_hi = r_lo + a.rows_per_block < a.m ? r_lo + a.rows_per_block : a.m;
+    v4f acc[OG][CTW];
+#pragma unroll
+    for (int og = 0; og < OG; ++og)
+#pragma unroll
+        for (int t = 0; t < CTW; ++t)
+            acc[og][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (long r0 = r_lo; r0 < r_hi; r0 += 64) {
+        __syncthreads();
+        // this wave's 16 rows, four at a time: all their loads in flight before the first store (a load, a wait and
+        // a store per element was 56 us per tile of the 265 -> 128 layer)
+        constexpr int YL = (OG * 16 + 63) / 64;
+        constexpr int RB = CTW == 1 ? 16 : CTW == 2 ? 8 : 4;        // rows per batch: ~30 loads per lane in flight
+        for (int rb = 0; rb < 16; rb += RB) {
+            float xv[RB][CTW], yv[RB][YL];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const long row = r0 + wave + 4 * (rb + j);
+                const bool live = row < r_hi;
+                const float *X = a.x + (live ? row : r_lo) * a.xs;
+                const float *Y = a.dy + (live ? row : r_lo) * a.dys;
+#pragma unroll
+                for (int u = 0; u < CTW; ++u) {
+                    const int c = lane + 64 * u;
+                    xv[j][u] = (live && c < a.cin) ? X[c] : ((live && c == a.cin) ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < YL; ++u) {
+                    const int o = lane + 64 * u;
+                    yv[j][u] = (live && o < a.cout) ? Y[o] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = wave + 4 * (rb + j);
+#pragma unroll
+                for (int u = 0; u < CTW; ++u)
+                    if (lane + 64 * u < xc)
+                        xs[r * xw + lane + 64 * u] = xv[j][u];
+#pragma unroll
+                for (int u = 0; u < YL; ++u)
+                    if (lane + 64 * u < OG * 16)
+                        dys[r * yw + lane + 64 * u] = yv[j][u];
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < 16; ++s) {
+            const float *xr = xs + (4 * s + g) * xw + i;
+            const float *yr = dys + (4 * s + g) * yw + i;
+#pragma unroll
+            for (int og = 0; og < OG; ++og) {
+                const float av = yr[og * 16];
+#pragma unroll
+                for (int t = 0; t < CTW; ++t)
+                    if (wave + 4 * t < a.ct)
+                        acc[og][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[(wave + 4 * t) * 16], acc[og][t], 0, 0, 0);
+            }
+        }
+    }
+    float *p = a.partial + (size_t)blockIdx.x * (OG * 16) * xc;
+#pragma unroll
+    for (int og = 0; og < OG; ++og)
+#pragma unroll
+        for (int t = 0; t < CTW; ++t)
+            if (wave + 4 * t < a.ct) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    p[(size_t)(og * 16 + 4 * g + q) * xc + (wave + 4 * t) * 16 + i] = acc[og][t][q];
+            }
+}
+
+// 64 elements of [dW | db] per workgroup, its four waves each a quarter of the row ranges' blocks (eight loads in
+// flight per lane), then the four sums in a fixed order
+__global__ __launch_bounds__(256) void linear_wgrad_all_reduce_kernel(int blocks, int cin, int cout, int opad, int cpad,
+                                                                      const float *__restrict__ partial,
+                                                                      float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool live = e < cout * (cin + 1);
+    const int o = live ? e / (cin + 1) : 0, c = live ? e - o * (cin + 1) : 0;
+    const size_t step = (size_t)opad * cpad;
+    const float *p = partial + (size_t)o * cpad + c;
+    const int per = (blocks + 3) / 4, b0 = q * per, b1 = min(blocks, b0 + per);
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        acc[u] = 0.f;
+    for (int b = b0; b < b1; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc[u] += (live && b + u < b1) ? p[(size_t)(b + u) * step] : 0.f;
+    }
+    part[q][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (q == 0 && live) {
+        const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (c < cin)
+            dw[(size_t)o * cin + c] = s;
+        else if (db)
+            db[o] = s;
+    }
+}
+
+struct WgradAllPlan {
+    bool ok;
+    int og, ct, ctw;
+    long blocks, rpb;
+    size_t lds, bytes;
+};
+
+WgradAllPlan wgrad_all_plan(long m, int cin, int cout)
+{
+    WgradAllPlan p;
+    p.ok = cout <= 128 && cin + 1 <= 320;
+    const int og = (cout + 15) / 16;
+    p.og = og <= 1 ? 1 : og <= 2 ? 2 : og <= 4 ? 4 : 8;
+    p.ct = (cin + 1 + 15) / 16;
+    p.ctw = (p.ct + 3) / 4;
+    // row ranges: ~160 workgroups for a Level's layers (10^4 rows: one or two tiles each); for the 3e5 edge rows of a
+    // DenseEdgeConv block (a streaming read of 107 MB) up to 1024 (four per compute unit), five tiles each
+    const long tiles = (m + 63) / 64;
+    long blocks = tiles < 160 ? tiles : 160;
+    if (tiles / 4 > blocks) blocks = tiles / 4 < 1024 ? tiles / 4 : 1024;
+    if (blocks < 1) blocks = 1;
+    p.rpb = ((tiles + blocks - 1) / blocks) * 64;
+    p.blocks = m > 0 ? (m + p.rpb - 1) / p.rpb : 1;
+    p.lds = (size_t)64 * (p.ct * 16 + 1 + p.og * 16 + 1) * sizeof(float);
+    p.bytes = (size_t)p.blocks * p.og * 16 * p.ct * 16 * sizeof(float);
+    return p;
+}
+
+template <int OG, int CTW>
+int wgrad_all_launch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a)
+{
+    auto kern = linear_wgrad_all_kernel<OG, CTW>;
+    if (p.lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(256), p.lds, s, a);
+    return TPU3_OK;
+}
+
+template <int OG>
+int wgrad_all_dispatch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a)
+{
+    switch (p.ctw) {
+    case 1: return wgrad_all_launch<OG, 1>(s, p, a);
+    case 2: return wgrad_all_launch<OG, 2>(s, p, a);
+    case 3: return wgrad_all_launch<OG, 3>(s, p, a);
+    case 4: return wgrad_all_launch<OG, 4>(s, p, a);
+    default: return wgrad_all_launch<OG, 5>(s, p, a);
+    }
+}
+
 struct WgradWidePlan {
     int cg, og;
     long blocks, rpb;
@@ -1003,10 +1186,87 @@ WgradWidePlan wgrad_wide_plan(long m, int cin, int cout)
 
 } // namespace
 
+namespace {
+
+// Input gradient of a per-point layer with FEW outputs (the lift and the prep convolutions, 24 outputs: autograd's
+// GEMM has K = 24 and runs a 256-deep tile, 56 us): dx[i][c] = sum_o dy[i][o] * w[o][c].  The weight sits in LDS, a
+// wave takes four rows at a time, lanes across the columns; a row of dy is read by the first lanes and handed round
+// with v_readlane.  Bound by the write of dx (8 MB for 9984 x 204).
+constexpr int DG_OMAX = 32, DG_CMAX = 320, DG_ROWS = 4;
+
+struct DgradArgs {
+    long m;
+    int cin, cout, dys, dxs;
+    const float *dy, *w;
+    float *dx;
+};
+
+__global__ __launch_bounds__(256) void linear_dgrad_small_kernel(DgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float dg_w[];       // [cout][cin]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < a.cout * a.cin; e += 256)
+        dg_w[e] = a.w[e];
+    __syncthreads();
+    const long stride = (long)gridDim.x * 4 * DG_ROWS;
+    for (long r0 = ((long)blockIdx.x * 4 + wave) * DG_ROWS; r0 < a.m; r0 += stride) {
+        float gv[DG_ROWS];
+#pragma unroll
+        for (int j = 0; j < DG_ROWS; ++j)
+            gv[j] = (r0 + j < a.m && lane < a.cout) ? a.dy[(r0 + j) * a.dys + lane] : 0.f;
+        float acc[DG_ROWS][DG_CMAX / 64];
+#pragma unroll
+        for (int j = 0; j < DG_ROWS; ++j)
+#pragma unroll
+            for (int u = 0; u < DG_CMAX / 64; ++u)
+                acc[j][u] = 0.f;
+        for (int o = 0; o < a.cout; ++o) {
+            float g[DG_ROWS];
+#pragma unroll
+            for (int j = 0; j < DG_ROWS; ++j)
+                g[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv[j]), o));
+#pragma unroll
+            for (int u = 0; u < DG_CMAX / 64; ++u) {
+                const int c = lane + 64 * u;
+                const float wv = c < a.cin ? dg_w[o * a.cin + c] : 0.f;
+#pragma unroll
+                for (int j = 0; j < DG_ROWS; ++j)
+                    acc[j][u] = __builtin_fmaf(g[j], wv, acc[j][u]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DG_ROWS; ++j)
+            if (r0 + j < a.m) {
+#pragma unroll
+                for (int u = 0; u < DG_CMAX / 64; ++u)
+                    if (lane + 64 * u < a.cin)
+                        a.dx[(r0 + j) * a.dxs + lane + 64 * u] = acc[j][u];
+            }
+    }
+}
+
+} // namespace
+
+extern "C" int tpu3_linear_dgrad_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *dy, int dy_stride,
+                                     const float *w, float *dx, int dx_stride)
+{
+    if (m < 0 || cin <= 0 || cout <= 0 || dy_stride < cout || dx_stride < cin) return TPU3_EINVAL;
+    if (cout > DG_OMAX || cin > DG_CMAX) return TPU3_ELIMIT;
+    if (m == 0) return TPU3_OK;
+    if (!dy || !w || !dx) return TPU3_EINVAL;
+    long blocks = (m + 4 * DG_ROWS - 1) / (4 * DG_ROWS);
+    if (blocks > 1024) blocks = 1024;
+    DgradArgs a{m, cin, cout, dy_stride, dx_stride, dy, w, dx};
+    hipLaunchKernelGGL(linear_dgrad_small_kernel, dim3((unsigned)blocks), dim3(256),
+                       (size_t)cin * cout * sizeof(float), (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
+
 extern "C" size_t tpu3_linear_wgrad_bias_workspace_bytes(long m, int cin, int cout)
 {
     if (m < 0 || cin <= 0 || cout <= 0) return 0;
-    return wgrad_wide_plan(m, cin, cout).bytes;
+    const WgradAllPlan q = wgrad_all_plan(m, cin, cout);
+    return q.ok ? q.bytes : wgrad_wide_plan(m, cin, cout).bytes;
 }
 
 extern "C" int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
@@ -1024,12 +1284,111 @@ extern "C" int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin,
         return (int)e;
     }
     if (!x || !dy) return TPU3_EINVAL;
+    const WgradAllPlan q = wgrad_all_plan(m, cin, cout);
+    if (q.ok) {
+        if (!workspace || workspace_bytes < q.bytes) return TPU3_EINVAL;
+        WgradAllArgs b{m, cin, cout, x_stride, dy_stride, x, dy, (float *)workspace, q.rpb, q.ct};
+        int r;
+        switch (q.og) {
+        case 1: r = wgrad_all_dispatch<1>(s, q, b); break;
+        case 2: r = wgrad_all_dispatch<2>(s, q, b); break;
+        case 4: r = wgrad_all_dispatch<4>(s, q, b); break;
+        default: r = wgrad_all_dispatch<8>(s, q, b); break;
+        }
+        if (r) return r;
+        hipLaunchKernelGGL(linear_wgrad_all_reduce_kernel, dim3((cout * (cin + 1) + 63) / 64), dim3(256), 0, s,
+                           (int)q.blocks, cin, cout, q.og * 16, q.ct * 16, (const float *)workspace, dw, db);
+        return tpu3_launch_status();
+    }
     const WgradWidePlan p = wgrad_wide_plan(m, cin, cout);
     if (!workspace || workspace_bytes < p.bytes) return TPU3_EINVAL;
     WgradWideArgs a{m, cin, cout, x_stride, dy_stride, x, dy, (float *)workspace, p.rpb, p.cg, p.og};
     hipLaunchKernelGGL(linear_wgrad_wide_kernel, dim3((unsigned)p.blocks, (unsigned)(p.cg * p.og)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(linear_wgrad_wide_reduce_kernel, dim3((cout * (cin + 1) + 255) / 256), dim3(256), 0, s,
                        (int)p.blocks, cin, cout, p.cg, p.og, (const float *)workspace, dw, db);
+    return tpu3_launch_status();
+}
+
+// ---- the weight and bias gradients of a DenseEdgeConv block from what its backward kernel leaves behind ---------
+// (csrc/dec_train.hip: G (edges,36) = [g2 | g1 | g0], Z (edges,48) = [h1 | h0 | d_j], S (points,36) = G summed over
+// a point's edges.)  Two streaming passes -- G^T Z over the 3e5 edges, S^T [x | 1] over the points -- and ONE kernel
+// that adds the row ranges' blocks and writes the three layers' gradients in their own layout:
+//   W_2 (12,48) = [G2^T Z[:, 0:24]  | S2^T x],  W_1 (12,36) = [G1^T Z[:, 12:24] | S1^T x],
+//   W_0 (12,48) = [S0^T x           | G0^T Z[:, 24:48]],  biases = column sums of S.
+namespace {
+
+__global__ __launch_bounds__(256) void dec_wgrad_assemble_kernel(int blocks_e, int blocks_p, const float *__restrict__ pe,
+                                                                 const float *__restrict__ pp, float *__restrict__ gw0,
+                                                                 float *__restrict__ gw1, float *__restrict__ gw2,
+                                                                 float *__restrict__ gb)
+{
+    // partial layouts: edges (blocks_e, 64, 64) (36 x 49 used), points (blocks_p, 64, 32) (36 x 25 used)
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    constexpr int N2 = 12 * 48, N1 = 12 * 36, N0 = 12 * 48, NB = 36;
+    const bool live = e < N2 + N1 + N0 + NB;
+    bool edge = false;
+    int row = 0, col = 0;
+    float *dst = gb;
+    if (e < N2) {
+        const int o = e / 48, c = e - o * 48;
+        edge = c < 24; row = o; col = edge ? c : c - 24; dst = gw2 + e;
+    } else if (e < N2 + N1) {
+        const int f = e - N2, o = f / 36, c = f - o * 36;
+        edge = c < 12; row = 12 + o; col = edge ? 12 + c : c - 12; dst = gw1 + f;
+    } else if (e < N2 + N1 + N0) {
+        const int f = e - N2 - N1, o = f / 48, c = f - o * 48;
+        edge = c >= 24; row = 24 + o; col = c; if (!edge) col = c;
+        dst = gw0 + f;
+    } else if (live) {
+        row = e - N2 - N1 - N0; col = 24; dst = gb + row;
+    }
+    const int blocks = edge ? blocks_e : blocks_p;
+    const size_t step = edge ? 64 * 64 : 64 * 32;
+    const float *p = (edge ? pe : pp) + (size_t)row * (edge ? 64 : 32) + col;
+    const int per = (blocks + 3) / 4, b0 = q * per, b1 = min(blocks, b0 + per);
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        acc[u] = 0.f;
+    for (int b = b0; b < b1; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc[u] += (live && b + u < b1) ? p[(size_t)(b + u) * step] : 0.f;
+    }
+    part[q][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (q == 0 && live)
+        *dst = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+} // namespace
+
+extern "C" size_t tpu3_dec_train_wgrad_workspace_bytes(long points)
+{
+    if (points <= 0) return 0;
+    return wgrad_all_plan(points * 32, 48, 36).bytes + wgrad_all_plan(points, 24, 36).bytes;
+}
+
+extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S,
+                                        const float *Z, const float *G, float *gw0, float *gw1, float *gw2, float *gb,
+                                        void *workspace, size_t workspace_bytes)
+{
+    if (points <= 0) return TPU3_EINVAL;
+    if (!x || !S || !Z || !G || !gw0 || !gw1 || !gw2 || !gb) return TPU3_EINVAL;
+    const WgradAllPlan pe = wgrad_all_plan(points * 32, 48, 36), pp = wgrad_all_plan(points, 24, 36);
+    if (!workspace || workspace_bytes < pe.bytes + pp.bytes) return TPU3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float *we = (float *)workspace, *wp = (float *)((char *)workspace + pe.bytes);
+    WgradAllArgs ae{points * 32, 48, 36, 48, 36, Z, G, we, pe.rpb, pe.ct};
+    WgradAllArgs ap{points, 24, 36, 24, 36, x, S, wp, pp.rpb, pp.ct};
+    int r = wgrad_all_launch<4, 1>(s, pe, ae);          // (49 columns: 4 tiles, one per wave; 36 outputs: 4 groups)
+    if (r) return r;
+    r = wgrad_all_launch<4, 1>(s, pp, ap);              // (25 columns: 2 tiles)
+    if (r) return r;
+    hipLaunchKernelGGL(dec_wgrad_assemble_kernel, dim3((12 * 48 * 2 + 12 * 36 + 36 + 63) / 64), dim3(256), 0, s,
+                       (int)pe.blocks, (int)pp.blocks, (const float *)we, (const float *)wp, gw0, gw1, gw2, gb);
     return tpu3_launch_status();
 }
 

@@ -72,7 +72,13 @@ class _PointwiseLayer(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         g2 = g.reshape(-1, g.size(-1))
-        gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if weight.size(0) <= 32 and hasattr(operations.BACKEND, "linear_dgrad"):
+                gx = operations.BACKEND.linear_dgrad(g2, weight.contiguous())
+                gx = gx.view(x.shape) if gx is not None else None
+            if gx is None:
+                gx = g.matmul(weight)
         gw = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             res = operations.BACKEND.linear_wgrad_bias(x.reshape(-1, x.size(-1)), g2)
@@ -125,9 +131,9 @@ def gather_neighbours(x, idx):
 
 class _FusedDECTrain(torch.autograd.Function):
     """The (24, 12, 3, k = 32) DenseEdgeConv block as ONE autograd node (csrc/dec_train.hip): forward and backward
-    are one launch each; the weight gradients of the edge parts go through the streaming kernel
-    tpu3_linear_wgrad_f32 on column slices of the two edge tensors the backward kernel leaves behind, those of the
-    x_i parts and the biases come from the per-point sums S."""
+    are one launch each; the weight and bias gradients come from the two edge tensors and the per-point sums S the
+    backward kernel leaves behind, in three more launches (tpu3_dec_train_wgrad_f32: two streaming passes and
+    one kernel that writes the layers' own layouts)."""
 
     @staticmethod
     def forward(ctx, x, idx, idx_off, w0, b0, w1, b1, w2, b2):
@@ -146,7 +152,11 @@ class _FusedDECTrain(torch.autograd.Function):
         weights = ctx.saved_tensors[3:]
         be = operations.BACKEND
         gx, G, Z, S = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
-        # edge parts: dW = G_slice^T Z_slice (streaming MFMA kernel, deterministic)
+        if hasattr(be, "dec_train_wgrad"):
+            gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, Z, G)
+            return (gx, None, None, gw0.view(ctx.shapes[0]), gb[24:36], gw1.view(ctx.shapes[1]), gb[12:24],
+                    gw2.view(ctx.shapes[2]), gb[0:12])
+        # (backends without the fused entry: the same sums piece by piece)
         g2h = be.linear_wgrad(Z[:, 0:24], G[:, 0:12])               # W_2[:, 0:24]  (inputs [h1, h0])
         g1h = be.linear_wgrad(Z[:, 12:24], G[:, 12:24])             # W_1[:, 0:12]  (input h0)
         g0b = be.linear_wgrad(Z[:, 24:48], G[:, 24:36])             # W_0[:, 24:48] (input x_j - x_i)

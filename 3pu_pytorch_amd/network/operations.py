@@ -322,6 +322,19 @@ class HipBackend(object):
                 "tpu3_interlevel_skip_f32")
         return feat
 
+    def linear_dgrad(self, dy, weight):
+        """dy (M, C_out) rows with unit channel stride, weight (C_out, C_in) contiguous -> dx (M, C_in) = dy W, or
+        None when the shape is not covered (C_out <= 32, C_in <= 320): tpu3_linear_dgrad_f32."""
+        m, cout = dy.shape
+        cin = weight.size(1)
+        if cout > 32 or cin > 320 or dy.stride(1) != 1 or dy.dtype != torch.float32 or not weight.is_contiguous():
+            return None
+        dx = torch.empty((m, cin), dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            L.check(L.lib().tpu3_linear_dgrad_f32(L.stream_of(dy), m, cin, cout, L.ptr(dy), dy.stride(0), L.ptr(weight),
+                                                  L.ptr(dx), cin), "tpu3_linear_dgrad_f32")
+        return dx
+
     def interlevel_skip_train(self, xyz, feat, prev_xyz, prev_feat, pts_of, idx, scale=0.2):
         """Training forward of the skip connection: feat (B,N,C) updated in place, -> weights (B,N,K), the
         normalised bilateral weights the backward needs (tpu3_interlevel_skip_train_f32)."""
@@ -402,6 +415,24 @@ class HipBackend(object):
                                                    *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), L.ptr(gx),
                                                    L.ptr(G), L.ptr(Z), L.ptr(S)), "tpu3_dec_train_bwd_f32")
         return gx, G, Z, S
+
+    def dec_train_wgrad(self, x, S, Z, G):
+        """The block's weight gradients (12,48), (12,36), (12,48) and bias gradients (36) = [b2 | b1 | b0] from the
+        backward kernel's tensors: tpu3_dec_train_wgrad_f32 (three launches)."""
+        points = S.size(0)
+        dev = x.device
+        lib = L.lib()
+        need = lib.tpu3_dec_train_wgrad_workspace_bytes(points)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        gw0 = torch.empty((12, 48), dtype=torch.float32, device=dev)
+        gw1 = torch.empty((12, 36), dtype=torch.float32, device=dev)
+        gw2 = torch.empty((12, 48), dtype=torch.float32, device=dev)
+        gb = torch.empty((36,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.tpu3_dec_train_wgrad_f32(L.stream_of(x), points, L.ptr(x), L.ptr(S), L.ptr(Z), L.ptr(G),
+                                                 L.ptr(gw0), L.ptr(gw1), L.ptr(gw2), L.ptr(gb), L.ptr(ws), need),
+                    "tpu3_dec_train_wgrad_f32")
+        return gw0, gw1, gw2, gb
 
     def gather_rows(self, x, idx):
         """x (B,N,C) f32 contiguous, idx (B,...) int32 / int64 -> (B,...,C) rows, or None when not covered."""

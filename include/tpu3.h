@@ -350,6 +350,12 @@ int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin, int cout, 
                                size_t workspace_bytes);
 size_t tpu3_linear_wgrad_bias_workspace_bytes(long m, int cin, int cout);
 
+/* Training: input gradient of a kernel-size-1 convolution with FEW outputs (layer0 and the layerK_prep convolutions,
+ * 24 outputs; autograd's `grad_output @ weight`):  dx[i][c] = sum_o dy[i][o] * w[o][c],  dy (m, dy_stride), w
+ * (cout, cin) row-major, dx (m, dx_stride).  cout <= 32, cin <= 320 (else TPU3_ELIMIT). */
+int tpu3_linear_dgrad_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *dy, int dy_stride,
+                          const float *w, float *dx, int dx_stride);
+
 /* network.operations.normalize_point_batch (network/operations.py:12-30) on NCHW data:
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
@@ -371,6 +377,14 @@ int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const flo
                            int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, const uint8_t *arg, const float *gy,
                            float *gx, float *G, float *Z, float *S);
+/* Weight and bias gradients of the block from the tensors tpu3_dec_train_bwd_f32 leaves behind (what autograd
+ * computes for the three nn.Conv2d of network/layers.py:53-61): gw0 (12,48), gw1 (12,36), gw2 (12,48) in the layers'
+ * own column order, gb (36) = [b2 | b1 | b0].  points = p * n.  Deterministic; workspace =
+ * tpu3_dec_train_wgrad_workspace_bytes(points). */
+int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S, const float *Z,
+                             const float *G, float *gw0, float *gw1, float *gw2, float *gb, void *workspace,
+                             size_t workspace_bytes);
+size_t tpu3_dec_train_wgrad_workspace_bytes(long points);
 
 /* The differentiable neighbour gather of group_knn (network/operations.py:209-211: torch.gather over the expanded
  * point tensor; its backward is an index accumulation) on channel-last rows, training:
