@@ -89,6 +89,15 @@ class _PointwiseLayer(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+def pointwise_linear_train(x, weight, bias):
+    """y = x W^T + b through _PointwiseLayer when the device kernels apply (weight may be a column slice of a
+    parameter), else plain F.linear."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.numel() // x.size(-1) >= 1024
+            and hasattr(operations.BACKEND, "linear_wgrad_bias")):
+        return _PointwiseLayer.apply(x, weight, bias, False)
+    return F.linear(x, weight, bias)
+
+
 def pointwise_train(layer, x):
     """Training shortcut of a pointwise Conv1d / Conv2d (activation None / ReLU, bias, no normalisation) on a
     device: one autograd node, see _PointwiseLayer.  None = not applicable."""

@@ -548,6 +548,16 @@ class Level(torch.nn.Module):
                                          "128 -> 128 -> 64 -> 3)" % (ratio, (a.size(-1), up2.conv.out_channels,
                                                                             fc1.conv.out_channels, fc2.conv.out_channels)))
             x = torch.relu_(a.unsqueeze(2) + c.view(1, 1, ratio, -1)).reshape(B, N * ratio, -1)
+        elif (torch.is_grad_enabled() and x.is_cuda and up1.pointwise() and up1.activation == "relu"
+              and up1.conv.bias is not None):
+            # training on a device: the same split of up_layer1 -- the per-point half once per point (half the rows
+            # in its forward, input- and weight-gradient products), the code half once per replica, and the
+            # (B, N*r, 265) concatenation with its backward never exists
+            w = up1.conv.weight.view(up1.conv.weight.size(0), -1)
+            cin = x.size(-1)
+            a = layers.pointwise_linear_train(x, w[:, :cin], up1.conv.bias)                     # (B,N,128)
+            c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])                # (r,128)
+            x = torch.relu_(a.unsqueeze(2) + c.view(1, 1, ratio, -1)).reshape(B, N * ratio, -1)
         else:
             code = code.permute(0, 2, 1).reshape(1, 1, ratio, code_length).expand(B, N, -1, -1)
             x = torch.cat([x.unsqueeze(2).expand(-1, -1, ratio, -1), code], dim=-1)
