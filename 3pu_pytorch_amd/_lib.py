@@ -40,11 +40,14 @@ SIGNATURES = {
     "tpu3_knn_unique_workspace_bytes": (_sz, [_i, _i]),
     "tpu3_interlevel_skip_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _i,
                                       _vp, _sz]),
+    "tpu3_interlevel_skip_st_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _i,
+                                         _vp, _sz, _i]),
     "tpu3_interlevel_skip_train_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp,
                                             _vp, _sz]),
     "tpu3_interlevel_skip_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp]),
     "tpu3_interlevel_skip_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpu3_linear_small_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i]),
+    "tpu3_linear_small_st_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "tpu3_dec_train_fwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_dec_train_bwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp]),
@@ -71,11 +74,14 @@ SIGNATURES = {
     "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i]),
+    "tpu3_dense_edge_conv_st_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _i, _i, _i]),
     "tpu3_dense_edge_conv_fold_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 MFMA_F32, MFMA_F16 = 0, 1        # TPU3_MFMA_* of include/tpu3.h
+STORE_F32, STORE_F16 = 0, 1      # TPU3_STORE_* of include/tpu3.h
 EINVAL, ELIMIT = -1, -2          # TPU3_EINVAL / TPU3_ELIMIT
 
 _lib = None

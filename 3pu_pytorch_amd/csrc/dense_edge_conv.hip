@@ -72,6 +72,7 @@ struct DecArgs {
     float *acc;                      // (P, n, acc_stride) partial sums of the later prep convolutions
     int acc_stride, seed_off, store_off;
     float *xnext;                    // (P, n, 24): relu of the first 24 outputs = the next block's input rows
+    int out_half;                    // `out` is a fp16 buffer (TPU3_STORE_F16; fp16-operand kernel only), stride in halves
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -456,8 +457,16 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
         for (int t0 = 0; t0 < 16 * 15; t0 += 64) {
             const int t = t0 + lane;
             const int pt = t / 15, q4 = t - pt * 15;
-            if (t < 16 * 15 && pb + pt < n)
-                *(f32x4 *)(O + (size_t)(pb + pt) * a.out_stride + 4 * q4) = *(const f32x4 *)(ST + pt * 60 + 4 * q4);
+            if (t < 16 * 15 && pb + pt < n) {
+                const f32x4 v = *(const f32x4 *)(ST + pt * 60 + 4 * q4);
+                if (a.out_half) {       // feature buffer stored as fp16: 15 eight-byte pieces of one 120-byte run
+                    typedef _Float16 dh4 __attribute__((ext_vector_type(4)));
+                    const dh4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *(dh4 *)((_Float16 *)a.out + ((size_t)blockIdx.x * n + pb + pt) * a.out_stride + 4 * q4) = h;
+                } else {
+                    *(f32x4 *)(O + (size_t)(pb + pt) * a.out_stride + 4 * q4) = v;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -929,6 +938,29 @@ int dec_launch(hipStream_t s, int patches, DecArgs &a)
 
 } // namespace
 
+extern "C" int tpu3_dense_edge_conv_st_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                           const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                           const float *w0, const float *b0, const float *w1, const float *b1,
+                                           const float *w2, const float *b2, void *out, int out_stride, int mfma,
+                                           int out_store)
+{
+    if (out_store == TPU3_STORE_F32)
+        return tpu3_dense_edge_conv_f32(stream, patches, n, k, x, idx, idx_elem_size, idx_stride, idx_off, w0, b0, w1,
+                                        b1, w2, b2, (float *)out, out_stride, mfma);
+    // fp16 rows come out of the fp16-operand kernel only (its results carry fp16-operand error already)
+    if (out_store != TPU3_STORE_F16 || mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
+    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
+    if (patches == 0) return TPU3_OK;
+    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return TPU3_EINVAL;
+    if (((uintptr_t)out % 8) != 0 || ((uintptr_t)x % 16) != 0) return TPU3_EINVAL;
+    if (patches > 2147483647 / (n > 0 ? n : 1)) return TPU3_ELIMIT;
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, (float *)out, out_stride,
+              nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 1};
+    return dec_launch<true>((hipStream_t)stream, patches, a);
+}
+
 extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
                                         const void *idx, int idx_elem_size, int idx_stride, int idx_off,
                                         const float *w0, const float *b0, const float *w1, const float *b1,
@@ -943,7 +975,7 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (((uintptr_t)out % 16) != 0 || ((uintptr_t)x % 16) != 0) return TPU3_EINVAL;
     if (patches > 65535 * 0 + 2147483647 / (n > 0 ? n : 1)) return TPU3_ELIMIT;       // patches * n must fit an int
     DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr,
-              0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+              0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0};
     hipStream_t s = (hipStream_t)stream;
     if (mfma == TPU3_MFMA_F16)
         return dec_launch<true>(s, patches, a);
@@ -977,6 +1009,6 @@ extern "C" int tpu3_dense_edge_conv_fold_f32(tpu3_stream_t stream, int patches, 
     if (patches > 2147483647 / n) return TPU3_ELIMIT;
     if (dec4_lds_bytes(n, fold_n) > 160 * 1024) return TPU3_ELIMIT;        // (callers then run the layers unfolded)
     DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, w0, b0, w1, b1, w2, b2, out, out_stride, nullptr,
-              fold_n, fold_w, fold_b, acc, acc_stride, seed_off, store_off, xnext};
+              fold_n, fold_w, fold_b, acc, acc_stride, seed_off, store_off, xnext, 0};
     return dec4_launch((hipStream_t)stream, patches, a);
 }

@@ -42,6 +42,19 @@ constexpr int LS_CIN_MAX = 320;           // weights staged in LDS: 32 x (320 + 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+// four input channels of a row: fp32 rows, or (XH) the fp16 rows of a feature buffer stored as TPU3_STORE_F16 -- the
+// value that enters the matrix instruction is the same fp16 number either way
+template <bool XH>
+__device__ __forceinline__ v4f ldx4(const float *row_f32, long off)
+{
+    if constexpr (XH) {
+        const h4 h = *(const h4 *)((const _Float16 *)row_f32 + off);
+        return (v4f){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        return ld4(row_f32 + off);
+    }
+}
+
 __device__ __forceinline__ h8 cat_h8(v4f lo, v4f hi)
 {
     h8 r;
@@ -56,7 +69,7 @@ __device__ __forceinline__ h8 cat_h8(v4f lo, v4f hi)
 // fp16-operand flavour (TPU3_MFMA_F16): two 16-channel slabs per v_mfma_f32_16x16x32_f16.  The eight k slots
 // of lane (pt, q) are the channels {16 s + 4 q + j} u {16 (s+1) + 4 q + j}, j < 4 -- the SAME two float4 pieces
 // the fp32 flavour fetches, converted in registers; weights likewise.  fp32 accumulate, fp32 rows in memory.
-template <int TOUT>
+template <int TOUT, bool XH = false>
 __global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 * TOUT][cin + 4], zero padded (fp32)
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         const long row = tile * 16 + pt;
-        const float *xr = a.x + (row < a.m ? row : a.m - 1) * a.xs;
+        const long xrow = (row < a.m ? row : a.m - 1) * a.xs;          // (elements of the stored type)
         v4f acc[TOUT];
 #pragma unroll
         for (int t = 0; t < TOUT; ++t)
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int ch = 16 * (s0 + u) + 4 * q;
-                bv[u] = ld4(xr + (ch < a.cin ? ch : 0));        // cin % 4 == 0
+                bv[u] = ldx4<XH>(a.x, xrow + (ch < a.cin ? ch : 0));        // cin % 4 == 0
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void linear_small_f16_kernel(LinArgs a)
 // linear_small_f16_kernel; the weights are converted ONCE per workgroup and staged in LDS as fp16
 // ([16 TOUT][cin + 8] halves: 70 KB for 128 x 264, two workgroups per compute unit), so the A operand of a
 // v_mfma_f32_16x16x32_f16 is two 8-byte LDS reads and no conversions.  fp32 accumulate, fp32 rows in memory.
-template <int TOUT>
+template <int TOUT, bool XH = false>
 __global__ __launch_bounds__(256) void linear_wide_f16_kernel(LinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256) void linear_wide_f16_kernel(LinArgs a)
     const h4 hzero = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         const long row = tile * 16 + pt;
-        const float *xr = a.x + (row < a.m ? row : a.m - 1) * a.xs;
+        const long xrow = (row < a.m ? row : a.m - 1) * a.xs;          // (elements of the stored type)
         v4f acc[TOUT];
 #pragma unroll
         for (int t = 0; t < TOUT; ++t)
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void linear_wide_f16_kernel(LinArgs a)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int ch = 16 * (s0 + u) + 4 * q;
-                bv[u] = ld4(xr + (ch < a.cin ? ch : 0));        // cin % 4 == 0
+                bv[u] = ldx4<XH>(a.x, xrow + (ch < a.cin ? ch : 0));        // cin % 4 == 0
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -729,9 +742,33 @@ extern "C" int tpu3_linear_lift_f32(tpu3_stream_t stream, long m, int cin, int c
 }
 
 
+namespace {
+int linear_small_impl(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride, const float *w,
+                      const float *bias, int relu, float *y, int y_stride, int mfma, bool xh);
+}
+
 extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x,
                                      int x_stride, const float *w, const float *bias, int relu, float *y,
                                      int y_stride, int mfma)
+{
+    return linear_small_impl(stream, m, cin, cout, x, x_stride, w, bias, relu, y, y_stride, mfma, false);
+}
+
+extern "C" int tpu3_linear_small_st_f32(tpu3_stream_t stream, long m, int cin, int cout, const void *x,
+                                        int x_stride, const float *w, const float *bias, int relu, float *y,
+                                        int y_stride, int mfma, int x_store)
+{
+    if (x_store != TPU3_STORE_F32 && x_store != TPU3_STORE_F16) return TPU3_EINVAL;
+    // fp16 rows only feed fp16-operand matrix instructions (rounding them again would be exact; widening them for the
+    // fp32 flavour would claim a precision the rows do not have)
+    if (x_store == TPU3_STORE_F16 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
+    return linear_small_impl(stream, m, cin, cout, (const float *)x, x_stride, w, bias, relu, y, y_stride, mfma,
+                             x_store == TPU3_STORE_F16);
+}
+
+namespace {
+int linear_small_impl(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride, const float *w,
+                      const float *bias, int relu, float *y, int y_stride, int mfma, bool xh)
 {
     if (mfma != TPU3_MFMA_F32 && mfma != TPU3_MFMA_F16) return TPU3_EINVAL;
     if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
@@ -742,7 +779,8 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
     if (x_stride < cin || y_stride < cout) return TPU3_EINVAL;
     if (m == 0) return TPU3_OK;
     if (!x || !w || !y) return TPU3_EINVAL;
-    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15) != 0) return TPU3_ELIMIT;
+    if ((((uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15) != 0 || ((uintptr_t)x & (xh ? 7 : 15)) != 0)
+        return TPU3_ELIMIT;
     LinArgs a{m, cin, cout, x_stride, y_stride, relu, x, w, bias, y};
     const long tiles = (m + 15) / 16;
     long blocks = (tiles + 3) / 4;
@@ -752,13 +790,26 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
         if (e != hipSuccess) return (int)e;
         if (blocks > 512) blocks = 512;
-        hipLaunchKernelGGL(linear_wide_f16_kernel<8>, dim3((unsigned)blocks), dim3(256), ldsw, (hipStream_t)stream, a);
+        if (xh) {
+            const hipError_t e2 = hipFuncSetAttribute((const void *)linear_wide_f16_kernel<8, true>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            if (e2 != hipSuccess) return (int)e2;
+            hipLaunchKernelGGL((linear_wide_f16_kernel<8, true>), dim3((unsigned)blocks), dim3(256), ldsw,
+                               (hipStream_t)stream, a);
+        } else {
+            hipLaunchKernelGGL(linear_wide_f16_kernel<8>, dim3((unsigned)blocks), dim3(256), ldsw, (hipStream_t)stream, a);
+        }
         return tpu3_launch_status();
     }
     if (blocks > 256 * 8) blocks = 256 * 8;       // persistent: the weights are staged once per workgroup
     const int tout = cout <= 16 ? 1 : 2;
     const size_t lds = (size_t)16 * tout * (cin + 4) * sizeof(float);
-    if (mfma == TPU3_MFMA_F16) {
+    if (mfma == TPU3_MFMA_F16 && xh) {
+        if (tout == 1)
+            hipLaunchKernelGGL((linear_small_f16_kernel<1, true>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((linear_small_f16_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    } else if (mfma == TPU3_MFMA_F16) {
         if (tout == 1)
             hipLaunchKernelGGL(linear_small_f16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
         else
@@ -769,6 +820,7 @@ extern "C" int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int 
         hipLaunchKernelGGL(linear_small_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }
+} // namespace
 
 extern "C" int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const float *a, const float *c,
                                      const float *w2, const float *b2, const float *w3, const float *b3,

@@ -34,9 +34,9 @@ struct SkipArgs {
     int feat_stride;                 // row stride of feat (floats)
     int m;                           // rows of the previous cloud slab
     const float *xyz;                // (B,n,3)
-    float *feat;                     // (B,n,feat_stride) in/out, first c channels
+    void *feat;                      // (B,n,feat_stride) in/out, first c channels; fp32 or (store = f16) fp16 rows
     const float *prev_xyz;           // (Bp,m,3)
-    const float *prev_feat;          // (Bp,m,c)
+    const void *prev_feat;           // (Bp,m,c), same element type as feat
     const int32_t *pts_of;           // (B) or null
     const void *idx;                 // (B,n,k)
     int idx64;
@@ -66,6 +66,27 @@ __device__ __forceinline__ void skip_item(const SkipArgs &a, int &b, int &slice)
 }
 
 typedef float sk_f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sk_h4 __attribute__((ext_vector_type(4)));
+
+// four channels of a feature row: fp32 rows as they are, fp16 rows (activation storage mode f16) widened on load
+// and rounded on store -- the arithmetic in between is the same fp32 code
+template <bool NT>
+__device__ __forceinline__ sk_f4 sk_ld4(const float *row, int i4)
+{
+    return NT ? __builtin_nontemporal_load((const sk_f4 *)row + i4) : ((const sk_f4 *)row)[i4];
+}
+template <bool NT>
+__device__ __forceinline__ sk_f4 sk_ld4(const _Float16 *row, int i4)
+{
+    const sk_h4 h = NT ? __builtin_nontemporal_load((const sk_h4 *)row + i4) : ((const sk_h4 *)row)[i4];
+    return (sk_f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void sk_st4(float *row, int i4, sk_f4 v) { __builtin_nontemporal_store(v, (sk_f4 *)row + i4); }
+__device__ __forceinline__ void sk_st4(_Float16 *row, int i4, sk_f4 v)
+{
+    const sk_h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    __builtin_nontemporal_store(h, (sk_h4 *)row + i4);
+}
 #define SK_DPP(V, CTRL, RM) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, RM, 0xF, false))
 // sum over the wave by DPP (no LDS traffic); every lane of the LAST row ends with the total
 __device__ __forceinline__ float sk_wave_sum(float v)
@@ -156,9 +177,9 @@ __device__ __forceinline__ int sk_lane_neighbour(const int (&nbr)[K], int tk)
 
 // (the bodies take their pointers as __restrict__ parameters: once inlined, the index loads are known not to be
 // clobbered by the kernel's stores and stay scalar loads)
-template <int K, bool VEC, bool TAIL>
+template <int K, bool VEC, bool TAIL, typename T>
 __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__restrict__ idx_p,
-                                               const float *__restrict__ feat_p, float *__restrict__ dist_p,
+                                               const T *__restrict__ feat_p, float *__restrict__ dist_p,
                                                float *__restrict__ mins_p)
 {
     const int n = a.n, C = a.c;
@@ -169,9 +190,9 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // i, the neighbour rows: SGPRs
     const int i_lo = slice * a.slice_len, i_hi = min(n, i_lo + a.slice_len);
     const float *XYZ = a.xyz + (size_t)b * n * 3;
-    const float *F = feat_p + (size_t)b * n * a.feat_stride;
+    const T *F = feat_p + (size_t)b * n * a.feat_stride;
     const float *PX = a.prev_xyz + (size_t)pb * a.m * 3;
-    const float *PF = a.prev_feat + (size_t)pb * a.m * C;
+    const T *PF = (const T *)a.prev_feat + (size_t)pb * a.m * C;
     float2 *DS = (float2 *)dist_p + (size_t)b * n * K;              // (spatial, feature) per neighbour
     float2 *MN = (float2 *)mins_p + (size_t)b * n;
     const int C4 = C >> 2;
@@ -190,10 +211,10 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
         const int i = i_lo + wave;
         sk_neighbours<K>(a, idx_p, ((size_t)b * n + i) * K, nbr);
         if (VEC) {
-            const sk_f4 *X4 = (const sk_f4 *)(F + (size_t)i * a.feat_stride);
-            x0 = __builtin_nontemporal_load(X4 + l0);
+            const T *X4 = F + (size_t)i * a.feat_stride;
+            x0 = sk_ld4<true>(X4, l0);
             if (TAIL && L.small)
-                xt = __builtin_nontemporal_load(X4 + 64 + L.tj);
+                xt = sk_ld4<true>(X4, 64 + L.tj);
         }
     }
     for (int i = i_lo + wave; i < i_hi; i += STEP) {
@@ -208,21 +229,21 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
             sk_f4 r[K];
 #pragma unroll
             for (int kk = 0; kk < K; ++kk)
-                r[kk] = ((const sk_f4 *)(PF + (size_t)nbr[kk] * C))[l0];
+                r[kk] = sk_ld4<false>(PF + (size_t)nbr[kk] * C, l0);
             if (L.small) {
                 const float *pp = L.tjr == 0 ? PX + (size_t)nb * 3 : XYZ + (size_t)i * 3;
                 p0 = pp[0];
                 p1 = pp[1];
                 p2 = pp[2];
                 if (TAIL)
-                    rt = ((const sk_f4 *)(PF + (size_t)nb * C))[64 + L.tj];
+                    rt = sk_ld4<false>(PF + (size_t)nb * C, 64 + L.tj);
             }
             {
                 sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
-                const sk_f4 *X4n = (const sk_f4 *)(F + (size_t)inx * a.feat_stride);
-                x0n = __builtin_nontemporal_load(X4n + l0);
+                const T *X4n = F + (size_t)inx * a.feat_stride;
+                x0n = sk_ld4<true>(X4n, l0);
                 if (TAIL && L.small)
-                    xtn = __builtin_nontemporal_load(X4n + 64 + L.tj);
+                    xtn = sk_ld4<true>(X4n, 64 + L.tj);
             }
             float ts = 0.f;
             if (TAIL) {
@@ -255,16 +276,16 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
 #pragma unroll
             for (int u = 0; u < SK_CPL; ++u) {
                 const int c = lane + 64 * u;
-                xv[u] = c < C ? F[(size_t)i * a.feat_stride + c] : 0.f;
+                xv[u] = c < C ? (float)F[(size_t)i * a.feat_stride + c] : 0.f;
             }
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
                 acc[kk] = 0.f;
-                const float *row = PF + (size_t)nbr[kk] * C;
+                const T *row = PF + (size_t)nbr[kk] * C;
 #pragma unroll
                 for (int u = 0; u < SK_CPL; ++u) {
                     const int c = lane + 64 * u;
-                    const float d = c < C ? xv[u] - row[c] : 0.f;
+                    const float d = c < C ? xv[u] - (float)row[c] : 0.f;
                     acc[kk] += d * d;
                 }
             }
@@ -295,15 +316,15 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
     }
 }
 
-template <int K, bool VEC, bool TAIL>
+template <int K, bool VEC, bool TAIL, typename T = float>
 __global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
 {
-    skip_dist_body<K, VEC, TAIL>(a, a.idx, a.feat, a.dist, a.mins);
+    skip_dist_body<K, VEC, TAIL, T>(a, a.idx, (const T *)a.feat, a.dist, a.mins);
 }
 
-template <int K, bool VEC, bool TAIL>
+template <int K, bool VEC, bool TAIL, typename T>
 __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *__restrict__ idx_p,
-                                                float *__restrict__ feat_p, const float *__restrict__ prev_p,
+                                                T *__restrict__ feat_p, const T *__restrict__ prev_p,
                                                 const float *__restrict__ dist_p, const float *__restrict__ mins_p)
 {
     const int n = a.n, C = a.c;
@@ -313,8 +334,8 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // i, the neighbour rows: SGPRs
     const int i_lo = slice * a.slice_len, i_hi = min(n, i_lo + a.slice_len);
-    float *F = feat_p + (size_t)b * n * a.feat_stride;
-    const float *PF = prev_p + (size_t)pb * a.m * C;
+    T *F = feat_p + (size_t)b * n * a.feat_stride;
+    const T *PF = prev_p + (size_t)pb * a.m * C;
     const float2 *DS = (const float2 *)dist_p + (size_t)b * n * K;
     const float2 *MN = (const float2 *)mins_p + (size_t)b * n;
     // ---- h = mean over the patch's points of the distance to the closest of the K neighbours; every wave of
@@ -342,10 +363,10 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
         const int i = i_lo + wave;
         sk_neighbours<K>(a, idx_p, ((size_t)b * n + i) * K, nbr);
         if (VEC) {
-            const sk_f4 *X4 = (const sk_f4 *)(F + (size_t)i * a.feat_stride);
-            x0 = __builtin_nontemporal_load(X4 + l0);
+            const T *X4 = F + (size_t)i * a.feat_stride;
+            x0 = sk_ld4<true>(X4, l0);
             if (TAIL && L.small)
-                xt = __builtin_nontemporal_load(X4 + 64 + L.tj);
+                xt = sk_ld4<true>(X4, 64 + L.tj);
         }
     }
     for (int i = i_lo + wave; i < i_hi; i += STEP) {
@@ -353,26 +374,26 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
         const int inx = i + STEP < i_hi ? i + STEP : i;
         int nbrn[K];
         sk_f4 x0n = {0.f, 0.f, 0.f, 0.f}, xtn = {0.f, 0.f, 0.f, 0.f};
-        sk_f4 *X4 = (sk_f4 *)(F + (size_t)i * a.feat_stride);
+        T *X4 = F + (size_t)i * a.feat_stride;
         sk_f4 r[K];
         if (VEC) {
 #pragma unroll
             for (int kk = 0; kk < K; ++kk)
-                r[kk] = ((const sk_f4 *)(PF + (size_t)nbr[kk] * C))[l0];
+                r[kk] = sk_ld4<false>(PF + (size_t)nbr[kk] * C, l0);
         }
         float2 ds = make_float2(0.f, 0.f);
         sk_f4 rt = {0.f, 0.f, 0.f, 0.f};
         if (L.small) {
             ds = DS[(size_t)i * K + lk];
             if (VEC && TAIL)
-                rt = ((const sk_f4 *)(PF + (size_t)nb * C))[64 + L.tj];
+                rt = sk_ld4<false>(PF + (size_t)nb * C, 64 + L.tj);
         }
         sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
         if (VEC && inx != i) {      // (the row of `i` itself is about to be rewritten: never re-read it)
-            const sk_f4 *X4n = (const sk_f4 *)(F + (size_t)inx * a.feat_stride);
-            x0n = __builtin_nontemporal_load(X4n + l0);
+            const T *X4n = F + (size_t)inx * a.feat_stride;
+            x0n = sk_ld4<true>(X4n, l0);
             if (TAIL && L.small)
-                xtn = __builtin_nontemporal_load(X4n + 64 + L.tj);
+                xtn = sk_ld4<true>(X4n, 64 + L.tj);
         }
         // weights (reference :340-342): w = ws*wf;  w /= sum_k (w + 1e-5).  Lane 8 j + kk evaluates neighbour kk
         // (two divisions, two exponentials, then one more division) and group 0's results are broadcast -- the
@@ -402,7 +423,7 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
             s0.x = __builtin_fmaf(a.scale, s0.x, x0.x); s0.y = __builtin_fmaf(a.scale, s0.y, x0.y);
             s0.z = __builtin_fmaf(a.scale, s0.z, x0.z); s0.w = __builtin_fmaf(a.scale, s0.w, x0.w);
             if (v0)
-                __builtin_nontemporal_store(s0, X4 + lane);
+                sk_st4(X4, lane, s0);
             if (TAIL) {
                 // lane 8 j + kk holds float4 64 + j of neighbour kk: weight it, add up the eight lanes of the group
                 const float wt = L.tact ? mine_w : 0.f;
@@ -412,7 +433,7 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
                 t.x = __builtin_fmaf(a.scale, t.x, xt.x); t.y = __builtin_fmaf(a.scale, t.y, xt.y);
                 t.z = __builtin_fmaf(a.scale, t.z, xt.z); t.w = __builtin_fmaf(a.scale, t.w, xt.w);
                 if (L.tk == 0 && L.tj_live)
-                    __builtin_nontemporal_store(t, X4 + 64 + L.tj);
+                    sk_st4(X4, 64 + L.tj, t);
             }
         } else {
             float s[SK_CPL];
@@ -421,20 +442,20 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
                 s[u] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const float *row = PF + (size_t)nbr[kk] * C;
+                const T *row = PF + (size_t)nbr[kk] * C;
 #pragma unroll
                 for (int u = 0; u < SK_CPL; ++u) {
                     const int c = lane + 64 * u;
                     if (c < C)
-                        s[u] = kk == 0 ? w[kk] * row[c] : s[u] + w[kk] * row[c];
+                        s[u] = kk == 0 ? w[kk] * (float)row[c] : s[u] + w[kk] * (float)row[c];
                 }
             }
 #pragma unroll
             for (int u = 0; u < SK_CPL; ++u) {
                 const int c = lane + 64 * u;
                 if (c < C) {
-                    float *p = F + (size_t)i * a.feat_stride + c;
-                    *p = a.scale * s[u] + *p;
+                    T *p = F + (size_t)i * a.feat_stride + c;
+                    *p = (T)(a.scale * s[u] + (float)*p);
                 }
             }
         }
@@ -446,15 +467,25 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
     }
 }
 
-template <int K, bool VEC, bool TAIL>
+template <int K, bool VEC, bool TAIL, typename T = float>
 __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
 {
-    skip_apply_body<K, VEC, TAIL>(a, a.idx, a.feat, a.prev_feat, a.dist, a.mins);
+    skip_apply_body<K, VEC, TAIL, T>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, a.dist, a.mins);
 }
 
 template <int K>
-int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec)
+int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool half)
 {
+    if (half) {         // fp16 rows: the float4-per-lane forms only (the caller checked the alignment)
+        if (a.c > 256) {
+            hipLaunchKernelGGL((skip_dist_kernel<K, true, true, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+            hipLaunchKernelGGL((skip_apply_kernel<K, true, true, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((skip_dist_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+            hipLaunchKernelGGL((skip_apply_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
+        }
+        return tpu3_launch_status();
+    }
     if (vec && a.c > 256) {
         hipLaunchKernelGGL((skip_dist_kernel<K, true, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
         hipLaunchKernelGGL((skip_apply_kernel<K, true, true>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
@@ -511,10 +542,10 @@ __global__ __launch_bounds__(SK_THREADS) void skip_bwd_kernel(SkipBwdArgs a)
     }
 }
 
-int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, float *feat, int feat_stride,
-                 const float *prev_xyz, const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, void *feat, int feat_stride,
+                 const float *prev_xyz, const void *prev_feat, int m, const int32_t *pts_of, const void *idx,
                  int idx_elem_size, float scale, int patches_per_cloud, void *workspace, size_t workspace_bytes,
-                 float *wout);
+                 float *wout, int store = TPU3_STORE_F32);
 
 } // namespace
 
@@ -533,6 +564,17 @@ extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int 
 {
     return skip_forward((hipStream_t)stream, b, n, k, c, xyz, feat, feat_stride, prev_xyz, prev_feat, m, pts_of, idx,
                         idx_elem_size, scale, patches_per_cloud, workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int tpu3_interlevel_skip_st_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
+                                           void *feat, int feat_stride, const float *prev_xyz, const void *prev_feat,
+                                           int m, const int32_t *pts_of, const void *idx, int idx_elem_size,
+                                           float scale, int patches_per_cloud, void *workspace,
+                                           size_t workspace_bytes, int store)
+{
+    if (store != TPU3_STORE_F32 && store != TPU3_STORE_F16) return TPU3_EINVAL;
+    return skip_forward((hipStream_t)stream, b, n, k, c, xyz, feat, feat_stride, prev_xyz, prev_feat, m, pts_of, idx,
+                        idx_elem_size, scale, patches_per_cloud, workspace, workspace_bytes, nullptr, store);
 }
 
 extern "C" int tpu3_interlevel_skip_train_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,
@@ -564,10 +606,10 @@ extern "C" int tpu3_interlevel_skip_bwd_f32(tpu3_stream_t stream, int b, int n, 
 
 namespace {
 
-int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, float *feat, int feat_stride,
-                 const float *prev_xyz, const float *prev_feat, int m, const int32_t *pts_of, const void *idx,
+int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, void *feat, int feat_stride,
+                 const float *prev_xyz, const void *prev_feat, int m, const int32_t *pts_of, const void *idx,
                  int idx_elem_size, float scale, int patches_per_cloud, void *workspace, size_t workspace_bytes,
-                 float *wout)
+                 float *wout, int store)
 {
     if (b < 0 || n <= 0 || k <= 0 || k > SK_KMAX || c <= 0 || c > 64 * SK_CPL || m <= 0) return TPU3_EINVAL;
     if (feat_stride < c || (idx_elem_size != 4 && idx_elem_size != 8)) return TPU3_EINVAL;
@@ -588,20 +630,24 @@ int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, fl
     float *dist = (float *)workspace;
     SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale,
                per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k, wout};
-    // float4 rows: every row start must be 16-byte aligned
-    const bool vec = c % 4 == 0 && c <= 288 && feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 &&
-                     ((uintptr_t)prev_feat & 15) == 0;
+    // float4 rows: every row start must be 16-byte aligned (fp16 rows: four channels = 8 bytes per lane)
+    const bool half = store == TPU3_STORE_F16;
+    const uintptr_t amask = half ? 7 : 15;
+    const bool vec = c % 4 == 0 && c <= 288 && feat_stride % 4 == 0 && ((uintptr_t)feat & amask) == 0 &&
+                     ((uintptr_t)prev_feat & amask) == 0;
+    if (half && !vec)
+        return TPU3_ELIMIT;
     const int blocks = b * slices;
     int r;
     switch (k) {
-    case 1: r = skip_launch<1>(s, blocks, a, vec); break;
-    case 2: r = skip_launch<2>(s, blocks, a, vec); break;
-    case 3: r = skip_launch<3>(s, blocks, a, vec); break;
-    case 4: r = skip_launch<4>(s, blocks, a, vec); break;
-    case 5: r = skip_launch<5>(s, blocks, a, vec); break;
-    case 6: r = skip_launch<6>(s, blocks, a, vec); break;
-    case 7: r = skip_launch<7>(s, blocks, a, vec); break;
-    default: r = skip_launch<8>(s, blocks, a, vec); break;
+    case 1: r = skip_launch<1>(s, blocks, a, vec, half); break;
+    case 2: r = skip_launch<2>(s, blocks, a, vec, half); break;
+    case 3: r = skip_launch<3>(s, blocks, a, vec, half); break;
+    case 4: r = skip_launch<4>(s, blocks, a, vec, half); break;
+    case 5: r = skip_launch<5>(s, blocks, a, vec, half); break;
+    case 6: r = skip_launch<6>(s, blocks, a, vec, half); break;
+    case 7: r = skip_launch<7>(s, blocks, a, vec, half); break;
+    default: r = skip_launch<8>(s, blocks, a, vec, half); break;
     }
     if (own) {
         const hipError_t e = hipFreeAsync(own, s);

@@ -270,6 +270,13 @@ class HipBackend(object):
             w.append(conv.weight.detach().reshape(conv.weight.size(0), -1).contiguous())
             w.append(conv.bias.detach().contiguous())
         with torch.cuda.device(x.device):
+            if out.dtype == torch.float16:      # the level's feature buffer stored as fp16 (activation storage "f16")
+                L.check(L.lib().tpu3_dense_edge_conv_st_f32(
+                    L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
+                    L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
+                    L.ptr(out), out.stride(1), int(mfma), L.STORE_F16), "tpu3_dense_edge_conv_st_f32")
+                return out
+            L.require_dtype(out, torch.float32, "out")
             L.check(L.lib().tpu3_dense_edge_conv_f32(
                 L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
                 L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
@@ -306,15 +313,22 @@ class HipBackend(object):
         """Fused skip connection (inference): feat (B,N,C) is updated in place
         (x_i += scale * sum_k w_k f_k with the reference's bilateral weights).  per_cloud: patches
         [i*per_cloud, (i+1)*per_cloud) share a previous cloud (scheduling hint, 0 = unknown)."""
+        half = feat.dtype == torch.float16        # feature buffers stored as fp16 (activation storage "f16")
         for t, nm in ((xyz, "xyz"), (feat, "feat"), (prev_xyz, "prev_xyz"), (prev_feat, "prev_feat")):
             L.require_device(t, nm)
-            L.require_dtype(t, torch.float32, nm)
+            L.require_dtype(t, torch.float16 if half and nm.endswith("feat") else torch.float32, nm)
         L.require_device(idx, "idx")
         B, N, C = feat.shape
         K = idx.size(2)
         need = L.lib().tpu3_interlevel_skip_workspace_bytes(B, N, K)
         ws = torch.empty((need,), dtype=torch.uint8, device=feat.device)
         with torch.cuda.device(feat.device):
+            if half:
+                L.check(L.lib().tpu3_interlevel_skip_st_f32(
+                    L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
+                    L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale),
+                    int(per_cloud), L.ptr(ws), need, L.STORE_F16), "tpu3_interlevel_skip_st_f32")
+                return feat
             L.check(L.lib().tpu3_interlevel_skip_f32(
                 L.stream_of(feat), B, N, K, C, L.ptr(xyz), L.ptr(feat), feat.stride(1), L.ptr(prev_xyz),
                 L.ptr(prev_feat), prev_xyz.size(1), L.ptr(pts_of), L.ptr(idx), idx.element_size(), float(scale),
@@ -366,8 +380,10 @@ class HipBackend(object):
         with unit channel stride and ONE row stride (a channel slice of a contiguous buffer is fine),
         weight (C_out, C_in) -> (..., C_out), or None when the shape is not covered."""
         cin, cout = x.size(-1), weight.size(0)
+        half = x.dtype == torch.float16           # rows of a feature buffer stored as fp16: fp16-operand kernels only
         if (cout > (128 if int(mfma) == int(L.MFMA_F16) else 32) or cin > 320 or cin % 4 or cout % 4
-                or x.stride(-1) != 1 or x.dtype != torch.float32):
+                or x.stride(-1) != 1 or x.dtype not in (torch.float32, torch.float16)
+                or (half and int(mfma) != int(L.MFMA_F16))):
             return None
         rs = x.stride(-2)
         lead = x.shape[:-1]
@@ -380,11 +396,16 @@ class HipBackend(object):
             if d != 1 and st != exp:
                 return None
             exp *= d
-        if rs % 4 or (x.data_ptr() & 15) or (weight.data_ptr() & 15):
+        if rs % 4 or (x.data_ptr() & (7 if half else 15)) or (weight.data_ptr() & 15):
             return None
         w = weight.contiguous()
         y = torch.empty(lead + (cout,), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
+            if half:
+                L.check(L.lib().tpu3_linear_small_st_f32(L.stream_of(x), m, cin, cout, L.ptr(x), rs, L.ptr(w),
+                                                         L.ptr(bias), 1 if relu else 0, L.ptr(y), cout, int(mfma),
+                                                         L.STORE_F16), "tpu3_linear_small_st_f32")
+                return y
             L.check(L.lib().tpu3_linear_small_f32(L.stream_of(x), m, cin, cout, L.ptr(x), rs, L.ptr(w),
                                                   L.ptr(bias), 1 if relu else 0, L.ptr(y), cout, int(mfma)),
                     "tpu3_linear_small_f32")

@@ -164,13 +164,23 @@ class Net(torch.nn.Module):
     def reset_small_cloud_events(self):
         self._small_cloud_counts = {}
 
-    def set_mlp_precision(self, precision):
+    def set_mlp_precision(self, precision, activations=None):
         """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):
         "f32" -- fp32 operands (default; what the parity tests pin), or "f16" -- operands rounded to fp16,
         fp32 accumulate (BASELINE config C5: "fp16 feature MLPs on MFMA").  FPS, every kNN, the Chamfer
-        distance and the 3 -> 24 coordinate embedding (layer0) stay fp32 either way.  Explicit: a layer shape the f16 kernels do not cover raises."""
+        distance and the 3 -> 24 coordinate embedding (layer0) stay fp32 either way.  Explicit: a layer shape the f16 kernels do not cover raises.
+        activations: storage of every Level's (B,N,264) feature buffer, "f32" (default) or -- with precision "f16"
+        only -- "f16": the rows are written, gathered by the next level's skip connection and read by the prep
+        convolutions / up_layer1 as fp16 (half the bytes of the HBM-bound kernels).  The matrix kernels see the same
+        fp16 operands either way; only the skip connection's arithmetic sees rounded rows."""
         if precision not in ("f32", "f16"):
             raise ValueError("mlp precision must be 'f32' or 'f16'")
+        activations = activations or "f32"
+        if activations not in ("f32", "f16") or (activations == "f16" and precision != "f16"):
+            raise ValueError("activation storage must be 'f32', or 'f16' together with mlp precision 'f16'")
+        for m in self.modules():
+            if isinstance(m, Level):
+                m.activation_storage = activations
         for m in self.modules():
             if isinstance(m, (layers.Conv1d, layers.Conv2d)) and m.conv.in_channels < 16:
                 continue            # layer0 embeds the xyz coordinates themselves (3 -> 24): kept in fp32
@@ -275,6 +285,7 @@ class Level(torch.nn.Module):
     """3PU per-level network (reference :192-374)."""
 
     mlp_precision = "f32"       # see Net.set_mlp_precision
+    activation_storage = "f32"  # see Net.set_mlp_precision(activations=...)
     # inference: fold layer{2,3,4}_prep into the write-out of the DenseEdgeConv blocks before them (fp32 kernels)
     fold_preps = os.environ.get("TPU3_FOLD_PREPS", "1") not in ("0", "")
 
@@ -335,6 +346,9 @@ class Level(torch.nn.Module):
     # skip connection and the regressor (25 GB / 10 GB for the 15 360 level-4 patches of 8 clouds)
     max_patches = int(os.environ.get("TPU3_MAX_PATCHES", "4096"))
 
+    def _feat_dtype(self):
+        return torch.float16 if getattr(self, "activation_storage", "f32") == "f16" else torch.float32
+
     def _fold_plan(self, blocks, widths, c0):
         """Per DenseEdgeConv block i = 0..2 the operands of HipBackend.dense_edge_conv_fold, or None when the layers
         are not the standard ones.  prep_j (j = i+1 .. 3) reads the concatenation [y_j-1 | ... | y_0 | x0]; block i's
@@ -393,7 +407,7 @@ class Level(torch.nn.Module):
         # every chunk writes its features straight into its rows of one (B,N,264) buffer
         blocks = (self.layer1, self.layer2, self.layer3, self.layer4)
         total = self.layer0.conv.out_channels + sum(b.in_channels + b.n * b.growth_rate for b in blocks)
-        feat_all = xyz_normalized.new_empty((B, xyz_normalized.size(1), total))
+        feat_all = xyz_normalized.new_empty((B, xyz_normalized.size(1), total), dtype=self._feat_dtype())
         outs = []
         ucache = {} if hasattr(operations.BACKEND, "knn_graph") else None     # de-dup state of `previous`
         for lo, hi in zip(bounds[:-1], bounds[1:]):
@@ -429,9 +443,13 @@ class Level(torch.nn.Module):
                 y, _ = blk.forward_cl(x if prep is None else prep.forward_cl(x), layout=graph_layout)
                 x = torch.cat([y, x], dim=-1)
         else:
-            feat = feat_buf if feat_buf is not None else xyz_normalized.new_empty((B, N, total))
+            feat = feat_buf if feat_buf is not None else xyz_normalized.new_empty((B, N, total), dtype=self._feat_dtype())
             lo = total - c0
-            x0 = self.layer0.forward_cl(xyz_normalized, also=feat[..., lo:])     # x0 and its slice in one pass
+            if feat.dtype == torch.float32:
+                x0 = self.layer0.forward_cl(xyz_normalized, also=feat[..., lo:])     # x0 and its slice in one pass
+            else:
+                x0 = self.layer0.forward_cl(xyz_normalized)
+                feat[..., lo:].copy_(x0)                                             # (rounded to the stored type)
             plan = self._fold_plan(blocks, widths, c0) if self.fold_preps and x0.is_cuda else None
             acc = xyz_normalized.new_empty((B, N, 48)) if plan is not None else None
             inp, folded = x0, False
@@ -506,7 +524,8 @@ class Level(torch.nn.Module):
         point_features = x
         # feature expansion: every point r times, followed by its 1-d / 2-d code (:350-361)
         _, code_length, ratio = self.code.size()
-        code = self.code.to(device=x.device, dtype=x.dtype)                  # (1,L,r)
+        # (fp16 feature buffers: only the rows are fp16, everything computed from them is fp32)
+        code = self.code.to(device=x.device, dtype=torch.float32 if x.dtype == torch.float16 else x.dtype)   # (1,L,r)
         up1 = self.up_layer.up_layer1
         if not torch.is_grad_enabled() and up1.pointwise() and up1.activation == "relu":
             # inference: W [x_i ; code_j] = W_x x_i + W_c code_j -- the 264-channel part is the same

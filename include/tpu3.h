@@ -42,6 +42,12 @@ typedef void *tpu3_stream_t; /* hipStream_t */
 #define TPU3_MFMA_F32 0    /* fp32 inputs, fp32 accumulate (v_mfma_f32_16x16x4_f32): the default path   */
 #define TPU3_MFMA_F16 1    /* inputs rounded to fp16, fp32 accumulate (v_mfma_f32_16x16x{16,32}_f16)    */
 
+/* Storage of a Level's feature buffer (the (B,N,264) dense concatenation, network/upsampler.py:293-311) for config C5
+ * (BASELINE.json configs[4]: "fp16 feature MLPs"): the *_st_* entry points below read / write its rows in either type,
+ * everything else about them is the entry point without the suffix.  Strides count elements of the stored type. */
+#define TPU3_STORE_F32 0
+#define TPU3_STORE_F16 1
+
 /* Library identification: "3pu-hip <version> gfx950". */
 const char *tpu3_version(void);
 
@@ -233,6 +239,12 @@ int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n, int k, co
                              const void *idx, int idx_elem_size, int idx_stride, int idx_off,
                              const float *w0, const float *b0, const float *w1, const float *b1,
                              const float *w2, const float *b2, float *out, int out_stride, int mfma);
+/* The same block writing its rows into a feature buffer stored as `out_store` (TPU3_STORE_F16: mfma must be
+ * TPU3_MFMA_F16, out 8-byte aligned, out_stride in halves). */
+int tpu3_dense_edge_conv_st_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x, const void *idx,
+                                int idx_elem_size, int idx_stride, int idx_off, const float *w0, const float *b0,
+                                const float *w1, const float *b1, const float *w2, const float *b2, void *out,
+                                int out_stride, int mfma, int out_store);
 
 /* The same block with the NEXT prep convolutions folded into its write-out (fp32, lane-per-point kernel; reference
  * network/upsampler.py:298-311: layer{2,3,4}_prep = Conv1d(84 / 144 / 204 -> 24) + ReLU over the level's dense
@@ -270,6 +282,14 @@ int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, c
  * allocation inside) */
 size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k);
 
+/* tpu3_interlevel_skip_f32 on a feature buffer stored as `store` (feat AND prev_feat; fp32 arithmetic on the widened
+ * rows, the updated row rounded on its way back).  TPU3_STORE_F16: c % 4 == 0, c <= 288, 8-byte aligned rows (else
+ * TPU3_ELIMIT). */
+int tpu3_interlevel_skip_st_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz, void *feat,
+                                int feat_stride, const float *prev_xyz, const void *prev_feat, int m,
+                                const int32_t *pts_of, const void *idx, int idx_elem_size, float scale,
+                                int patches_per_cloud, void *workspace, size_t workspace_bytes, int store);
+
 /* The same skip connection as ONE autograd node for training (model.py:53-66 runs network/upsampler.py:317-347 under
  * autograd).  The reference detaches both distances (:244-245), so the weights are constants of the step:
  *   forward  = tpu3_interlevel_skip_f32 that also stores the normalised weights, weights (b,n,k);
@@ -295,6 +315,12 @@ int tpu3_interlevel_skip_bwd_f32(tpu3_stream_t stream, int b, int n, int k, int 
  * in memory). */
 int tpu3_linear_small_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                           const float *w, const float *bias, int relu, float *y, int y_stride, int mfma);
+/* The same layer reading its input rows from a feature buffer stored as `x_store` (TPU3_STORE_F16: mfma must be
+ * TPU3_MFMA_F16 -- the fp16 value that enters the matrix instruction is the stored one; x 8-byte aligned, x_stride in
+ * halves).  y stays fp32. */
+int tpu3_linear_small_st_f32(tpu3_stream_t stream, long m, int cin, int cout, const void *x, int x_stride,
+                             const float *w, const float *bias, int relu, float *y, int y_stride, int mfma,
+                             int x_store);
 
 /* Per-point linear layer with a WIDE output, inference: the per-point half of up_layer1
  * (network/upsampler.py:222 `up_layer1 = Conv2d(265, 128, ...)`, applied at :363 to [features ; code]: the first

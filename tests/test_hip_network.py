@@ -1098,6 +1098,82 @@ def test_regress_tail_fp16_mfma_within_derived_bound(dev, m, r):
     assert ratio <= 1.0, ratio
 
 
+def test_fp16_feature_buffer_kernels(dev):
+    """Activation storage "f16" (Net.set_mlp_precision("f16", activations="f16")), kernel by kernel:
+    * the fp16-operand per-point layers reading fp16 rows give BIT FOR BIT what they give on the same values held
+      in fp32 rows (the number that enters the matrix instruction is the stored one) -- prep convolutions and the
+      264 -> 128 half of up_layer1, reading a channel slice of a (m,264) buffer;
+    * DenseEdgeConv writing into an fp16 buffer = its fp32 rows rounded to fp16;
+    * the skip connection on fp16 rows = the fp32 kernel on the widened rows, rounded on the way back (its
+      arithmetic is the same fp32 code)."""
+    ops, L, layers = pkg("network.operations"), pkg("_lib"), pkg("network.layers")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    m = 3001
+    buf16 = torch.randn(m, 264, generator=g).to(dev).half()
+    buf32 = buf16.float()
+    for lo, cin, cout in ((180, 84, 24), (60, 204, 24), (0, 264, 128)):
+        w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        y16 = ops.BACKEND.linear_small(buf16[:, lo:lo + cin], w, b, True, mfma=L.MFMA_F16)
+        y32 = ops.BACKEND.linear_small(buf32[:, lo:lo + cin], w, b, True, mfma=L.MFMA_F16)
+        assert y16 is not None and y16.dtype == torch.float32 and torch.equal(y16, y32)
+    assert ops.BACKEND.linear_small(buf16[:, :84], w[:24, :84].contiguous(), b[:24], True) is None     # fp32 flavour: no
+    # DenseEdgeConv into a slice of an fp16 buffer
+    P, N = 5, 312
+    x = torch.randn(P, N, 24, generator=g).to(dev)
+    conv = layers.DenseEdgeConv(24, growth_rate=12, n=3, k=32).to(dev)
+    conv.mlp_precision = "f16"
+    with torch.no_grad():
+        o32 = torch.zeros(P, N, 264, device=dev)
+        o16 = torch.zeros(P, N, 264, device=dev, dtype=torch.float16)
+        _, idx = conv.forward_cl(x, out=o32[..., 144:204])
+        conv.forward_cl(x, out=o16[..., 144:204])
+    assert torch.equal(o16[..., 144:204], o32[..., 144:204].half())
+    assert float(o16[..., :144].abs().max()) == 0 and float(o16[..., 204:].abs().max()) == 0
+    # skip connection on fp16 rows
+    B, M, C, K = 3, 400, 264, 5
+    xyz = torch.randn(B, N, 3, generator=g).to(dev)
+    pxyz = torch.randn(B, M, 3, generator=g).to(dev)
+    f16 = torch.randn(B, N, C, generator=g).to(dev).half()
+    pf16 = (0.5 * torch.randn(B, M, C, generator=g)).to(dev).half()
+    idx5, _, _ = ops.knn_query(K, xyz, pxyz, unique=True, want_dist=False, want_grouped=False)
+    want = ops.BACKEND.interlevel_skip(xyz, f16.float().contiguous(), pxyz, pf16.float().contiguous(), None, idx5).half()
+    got = ops.BACKEND.interlevel_skip(xyz, f16.clone(), pxyz, pf16, None, idx5)
+    assert got.dtype == torch.float16 and torch.equal(got, want)
+
+
+def test_level_with_fp16_feature_buffers(dev):
+    """A Level with fp16 operands, feature buffers stored as fp16 against the same Level with fp32 buffers: the
+    matrix kernels see identical operands; what differs is (i) the rows the skip connection computes on and (ii)
+    the rounding of the row it writes back -- relative 2^-11 each on values of order 1, through a regressor whose
+    layers have gain of order 1: the level's output coordinates agree to 4e-4 of the patch radius (measured, printed
+    below), inside the fp16-operand error itself."""
+    ups, ops = pkg("network.upsampler"), pkg("network.operations")
+    net = _net(dev)
+    g = golden("level_forward.npz")
+    lvl1, lvl2 = net.levels["level_1"], net.levels["level_2"]
+    patch = torch.from_numpy(g["patch"]).to(dev).transpose(2, 1).contiguous()
+    p3 = torch.from_numpy(g["l2_in"]).to(dev).transpose(2, 1).contiguous()
+    p3n = torch.from_numpy(g["l2_in_norm"]).to(dev).transpose(2, 1).contiguous()
+    outs = {}
+    with torch.no_grad():
+        for act in ("f32", "f16"):
+            net.set_mlp_precision("f16", activations=act)
+            x1, f1 = lvl1.forward_cl(patch, patch, None)
+            assert f1.dtype == (torch.float16 if act == "f16" else torch.float32)
+            x2, f2 = lvl2.forward_cl(p3, p3n, (patch, f1, None), owner=torch.zeros(3, dtype=torch.int32, device=dev),
+                                     groups=1)
+            outs[act] = (x1.float(), f1.float(), x2.float(), f2.float())
+    net.set_mlp_precision("f32")
+    a, b = outs["f32"], outs["f16"]
+    d1, df1 = float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max() / a[1].abs().max())
+    d2, df2 = float((a[2] - b[2]).abs().max()), float((a[3] - b[3]).abs().max() / a[3].abs().max())
+    print("fp16 buffers vs fp32 buffers: level 1 xyz %.2e, features %.2e rel; level 2 xyz %.2e, features %.2e rel"
+          % (d1, df1, d2, df2))
+    assert df1 <= 2.0 ** -11 and d1 == 0.0            # level 1: no skip -- the rows are only rounded once, at the store
+    assert d2 < 1e-3 and df2 < 1.5e-3                 # measured 4.2e-4 / 6.9e-4
+
+
 def test_config_c5_full_size_fp16_mlps(orc, dev):
     """BASELINE config C5 at FULL size: one 80 000-point cloud, num_point = 1024 (234 outer patches of 1024
     points, inner patches of 312), up_ratio 16 -> 1.28 M points, feature MLPs on fp16-operand MFMA
@@ -1115,7 +1191,7 @@ def test_config_c5_full_size_fp16_mlps(orc, dev):
     assert P == 234
     ops.GENERIC_PATH_EVENTS.clear()
     merged32 = pipe.upsample(net, cloud, 1024, 16, 3, final_fps=False)
-    net.set_mlp_precision("f16")
+    net.set_mlp_precision("f16", activations="f16")        # fp16 operands, feature buffers stored as fp16
     merged16 = pipe.upsample(net, cloud, 1024, 16, 3, final_fps=False)
     out16 = pipe.upsample(net, cloud, 1024, 16, 3)
     net.set_mlp_precision("f32")

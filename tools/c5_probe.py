@@ -9,6 +9,10 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev).eval()
 cloud = bench.poisson_sphere(0, 80000, dev, ops)
+mode = os.environ.get("C5_MODE", "f32")             # f32 | f16 (fp16 operands) | f16a (+ fp16 feature buffers)
+if mode != "f32":
+    net.set_mlp_precision("f16", activations="f16" if mode == "f16a" else "f32")
+print("mode", mode)
 for final in (False, True):
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
