@@ -17,7 +17,8 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 class KnnLayout(ctypes.Structure):
     """tpu3_knn_layout (include/tpu3.h)."""
     _fields_ = [("n_arr", _vp), ("m_arr", _vp), ("pts_of", _vp), ("grp", _vp),
-                ("bp", _i), ("groups", _i), ("cand", _vp), ("cand_count", _vp)]
+                ("bp", _i), ("groups", _i), ("cand", _vp), ("cand_count", _vp),
+                ("tile_pts", _vp), ("tile_idx", _vp), ("tile_box", _vp)]
 
 
 # name -> (restype, argtypes); exactly the functions include/tpu3.h declares
@@ -61,6 +62,9 @@ SIGNATURES = {
     "tpu3_linear_wgrad_bias_workspace_bytes": (_sz, [ctypes.c_long, _i, _i]),
     "tpu3_dec_train_wgrad_f32": (_i, [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "tpu3_dec_train_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),
+    "tpu3_knn_tiles_build_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "tpu3_knn_tiles_workspace_bytes": (_sz, [_i, _i]),
+    "tpu3_knn_tiles_query_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "tpu3_linear_dgrad_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i]),
     "tpu3_regress_tail_f32": (_i, [_vp, ctypes.c_long, _i] + [_vp] * 10 + [_i]),
     "tpu3_knn_unique_compact_i32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -71,6 +75,7 @@ SIGNATURES = {
     "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),
     "tpu3_debug_fps_level_stats": (_i, [_vp]),
     "tpu3_debug_fps_tile_stats": (_i, [_vp]),
+    "tpu3_debug_knn_tiles_stats": (_i, [_vp]),
     "tpu3_debug_fps_bucket_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i]),

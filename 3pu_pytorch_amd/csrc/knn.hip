@@ -1538,7 +1538,10 @@ extern "C" int tpu3_knn_f32(tpu3_stream_t stream, int b, int m, int n, int c, in
             // verify -- max(D) and the reference arithmetic; both follow-ups early-exit on uws[1] == 0
             a.mode = 1;
             a.cand = L.cand; a.cand_count = L.cand_count;
-            r = dispatch_insert(s, b, a);
+            if (c == 3 && k <= 8 && L.cand && L.tile_pts && L.tile_idx && L.tile_box)
+                r = tpu3_knn_tiles_query_f32(stream, b, m, n, k, query, &L, uws, idx, idx_elem_size, dist);   // csrc/knn_tiles.hip
+            else
+                r = dispatch_insert(s, b, a);
             if (r) return r;
             a.cand = nullptr; a.cand_count = nullptr;
             KnnArgs d = a;

@@ -47,6 +47,13 @@ class HipBackend(object):
     name = "hip-gfx950"
 
     COMPACT_MIN_N = 1024      # unique=True: point sets this large get a first-occurrence list
+    # ... and, for 3-d points, k <= 8 and LARGE sets, spatial tiles of it (csrc/knn_tiles.hip): a wave of queries then
+    # searches ~9 tiles of 64 instead of the whole list.  It pays from ~16 k rows (a whole cloud's previous level, as
+    # Net.forward searches it); the batched pipeline's previous sets are ONE outer patch's inner patches (3120 / 6240
+    # rows, 10 - 20 tiles of which a wave needs 6 - 9: measured 1.0 vs 0.4 - 0.65 ms per call) and stay with the
+    # brute-force kernel.  TPU3_KNN_TILES=0: tuning hook
+    knn_tiles = os.environ.get("TPU3_KNN_TILES", "1") not in ("0", "")
+    KNN_TILES_MIN_N = 16384
 
     # Self kNN graphs can run optimistically: only the one-pass kernel, which raises a device-side event when a
     # query saw a second zero distance (rows may be duplicated: the exact path is then required).  OFF by
@@ -129,6 +136,7 @@ class HipBackend(object):
                     # groups) must start from the state tpu3_knn_unique_prepare_f32 left them in
                     dup, cand, cand_count = st["dup"], st["cand"], st["cand_count"]
                     uws = st["uws"].clone()
+                    tiles = st.get("tiles")
                 else:
                     dup = torch.empty((bp, n), dtype=torch.uint8, device=dev)
                     uws = torch.empty((4 + groups,), dtype=torch.int32, device=dev)
@@ -145,16 +153,32 @@ class HipBackend(object):
                         L.check(lib.tpu3_knn_unique_compact_i32(s, bp, n, L.ptr(n_arr_t), L.ptr(dup), L.ptr(uws),
                                                                 L.ptr(cand), L.ptr(cand_count)),
                                 "tpu3_knn_unique_compact_i32")
+                    tiles = None
+                    if cand is not None and c == 3 and k <= 8 and self.knn_tiles and n >= self.KNN_TILES_MIN_N:
+                        # small k in a large 3-d set (the inter-level search): the candidates in Morton-ordered tiles
+                        # of 64 with their boxes -- a wave of queries then searches only the tiles near it
+                        nt = (n + 63) // 64
+                        tiles = (torch.empty((bp, nt * 64, 4), dtype=torch.float32, device=dev),
+                                 torch.empty((bp, nt * 64), dtype=torch.int32, device=dev),
+                                 torch.empty((bp, nt, 8), dtype=torch.float32, device=dev))
+                        tneed = lib.tpu3_knn_tiles_workspace_bytes(bp, n)
+                        tws = torch.empty((tneed,), dtype=torch.uint8, device=dev)
+                        L.check(lib.tpu3_knn_tiles_build_f32(s, bp, n, L.ptr(points), L.ptr(n_arr_t), L.ptr(cand),
+                                                             L.ptr(cand_count), L.ptr(uws), L.ptr(tiles[0]),
+                                                             L.ptr(tiles[1]), L.ptr(tiles[2]), L.ptr(tws), tneed),
+                                "tpu3_knn_tiles_build_f32")
                     if unique_cache is not None:
                         # `points` itself is kept: the key holds its address, which must not be recycled
                         unique_cache["state"] = dict(key=key, points=points, dup=dup, uws=uws.clone(), cand=cand,
-                                                     cand_count=cand_count)
+                                                     cand_count=cand_count, tiles=tiles)
                 if cand is not None:
                     if lay is None:
                         lay = L.KnnLayout()
                         lay.bp, lay.groups = bp, 1
                         lay_ref = ctypes.byref(lay)
                     lay.cand, lay.cand_count = L.ptr(cand), L.ptr(cand_count)
+                    if tiles is not None and c == 3 and k <= 8:
+                        lay.tile_pts, lay.tile_idx, lay.tile_box = L.ptr(tiles[0]), L.ptr(tiles[1]), L.ptr(tiles[2])
             L.check(lib.tpu3_knn_f32(s, b, m, n, c, k, L.ptr(query), L.ptr(points), lay_ref, L.ptr(dup),
                                      L.ptr(uws), L.ptr(idx), 8, L.ptr(dist), L.ptr(grouped)),
                     "tpu3_knn_f32")

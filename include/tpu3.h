@@ -146,6 +146,12 @@ typedef struct {
      * only those rows (same result; the merged cloud of overlapping patches holds every point ~5x). */
     const int32_t *cand;
     const int32_t *cand_count;
+    /* optional, with cand / cand_count, 3-d points and k <= 8 (the inter-level search, fm_knn = 5): the candidates in
+     * Morton-ordered tiles of 64 with their boxes, from tpu3_knn_tiles_build_f32.  tpu3_knn_f32 then searches, per
+     * wave of 64 queries, only the tiles whose box can hold a neighbour (same result, ~8 of ~310 tiles). */
+    const float *tile_pts;          /* (bp, tiles*64, 4): x, y, z, |p|^2       tiles = ceil(n / 64) */
+    const int32_t *tile_idx;        /* (bp, tiles*64): row of each member, -1 beyond the list */
+    const float *tile_box;          /* (bp, tiles, 8): lo xyz, hi xyz, max |p|^2, members */
 } tpu3_knn_layout;
 
 /* Number of u32 words of the unique=True scratch `uws` for `groups` groups (>= 1). */
@@ -219,6 +225,21 @@ size_t tpu3_knn_unique_workspace_bytes(int bp, int n);
 int tpu3_knn_unique_compact_i32(tpu3_stream_t stream, int bp, int n, const int32_t *n_arr,
                                 const uint8_t *dup, const uint32_t *uws, int32_t *cand,
                                 int32_t *cand_count);
+
+/* Spatial tiles of the candidate lists above (see tpu3_knn_layout.tile_*), 3-d points only: per point set a bounding
+ * box, 30-bit Morton codes, ONE device radix sort over all sets, then the tiles' rows and boxes.  points (bp,n,3);
+ * cand / cand_count / uws as left by tpu3_knn_unique_prepare_f32 + tpu3_knn_unique_compact_i32 (uws[0] == 0: no
+ * duplicates, every live row is a candidate); tile_pts (bp*tiles*64*4 f32, 16-byte aligned), tile_idx (bp*tiles*64
+ * i32), tile_box (bp*tiles*8 f32, 16-byte aligned) with tiles = ceil(n / 64); workspace =
+ * tpu3_knn_tiles_workspace_bytes(bp, n) device bytes.
+ * tpu3_knn_tiles_query_f32 is the pruned search itself (the first pass of tpu3_knn_f32, which calls it when the layout
+ * carries tiles): query (b,m,3), k <= 8; a query that cannot verify the unique=True rule raises uws[1]. */
+int tpu3_knn_tiles_build_f32(tpu3_stream_t stream, int bp, int n, const float *points, const int32_t *n_arr,
+                             const int32_t *cand, const int32_t *cand_count, const uint32_t *uws, float *tile_pts,
+                             int32_t *tile_idx, float *tile_box, void *workspace, size_t workspace_bytes);
+size_t tpu3_knn_tiles_workspace_bytes(int bp, int n);
+int tpu3_knn_tiles_query_f32(tpu3_stream_t stream, int b, int m, int n, int k, const float *query,
+                             const tpu3_knn_layout *layout, uint32_t *uws, void *idx, int idx_elem_size, float *dist);
 
 /* Fused DenseEdgeConv block, inference (network/layers.py:44-64 for in_channels 24, growth 12,
  * 3 dense layers -- the configuration of every Level, network/upsampler.py:210-223):
@@ -443,6 +464,10 @@ int tpu3_debug_fps_level_stats(unsigned long long *stats);
  * (phase 1, barrier, phase 2, barrier), collection passes, candidates listed, candidates ranked, rounds cut by the
  * clearance test (first set of the batch).  One-shot; host-side state only. */
 int tpu3_debug_fps_tile_stats(unsigned long long *stats);
+/* tpu3_debug_knn_tiles_stats: the NEXT pruned inter-level search (tpu3_knn_tiles_query_f32) ADDS to four device u32
+ * words: waves, tiles searched, tiles tested query by query, tiles per point set (summed over the waves).  One-shot;
+ * host-side state only. */
+int tpu3_debug_knn_tiles_stats(unsigned *words);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,
                                   int32_t *idx, void *workspace, size_t workspace_bytes,
                                   unsigned long long *prof);

@@ -1,6 +1,8 @@
 """-m gpu: parity of the HIP kernels (through the drop-in modules / C ABI) with the CPU oracle on
 the same seeded inputs.  Integer outputs are compared bit-exactly; float outputs bit-exactly
 where the arithmetic is pinned, otherwise within the stated tolerance."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -572,6 +574,71 @@ def test_knn_layout_shared_points_groups_and_ragged(orc, dev, n):
             np.testing.assert_array_equal(dist[i, :mi], rd[0, off:off + mi])
             np.testing.assert_array_equal(grouped[i, :mi], pn[0][ri[0, off:off + mi]])
             off += mi
+
+
+@pytest.mark.parametrize("case", ["surface", "lattice_ties", "volume_k8", "ragged"])
+def test_knn_spatial_tiles_equal_brute_force(orc, dev, case):
+    """csrc/knn_tiles.hip (the inter-level search, 3-d points, k <= 8: Morton tiles of the first-occurrence list, a
+    wave of 64 queries searches only the tiles near it) against the brute-force kernel on the same call -- indices AND
+    distances bit for bit -- and, on a slice, against the oracle:
+      surface       overlapping patches of a sphere cloud (every point ~4 times), queries = perturbed points
+      lattice_ties  points on an integer lattice: many exactly equal distances, ties to the lower row
+      volume_k8     uniform points in a cube, k = 8
+      ragged        shared point sets (pts_of), live counts for points and queries, a set without duplicates"""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(11)
+    k, layout = 5, None
+    if case == "surface":
+        base = sphere(3, 6000, 2)
+        pick = rng.integers(0, 6000, size=(2, 20000))
+        pts = np.stack([base[i][pick[i]] for i in range(2)])                       # (2,20000,3) with repeats
+        q = (pts[:, rng.integers(0, 20000, size=3 * 312)] * np.float32(1.01)
+             + rng.standard_normal((2, 936, 3)).astype(np.float32) * np.float32(0.004))
+        q = q.reshape(2 * 3, 312, 3)
+        layout = dict(pts_of=_t(np.array([0, 0, 0, 1, 1, 1], np.int32), dev),
+                      grp=_t(np.array([0, 0, 0, 1, 1, 1], np.int32), dev), groups=2)
+    elif case == "lattice_ties":
+        g = np.stack(np.meshgrid(*[np.arange(13)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        pts = np.concatenate([g, g[:803]])[None] * np.float32(0.125)               # 3000 rows, 803 repeated
+        pts = pts[:, rng.permutation(pts.shape[1])]
+        q = (g[rng.integers(0, len(g), size=500)] * np.float32(0.125) + np.float32(0.0625))[None]     # cell centres
+    elif case == "volume_k8":
+        k = 8
+        pts = rng.random((1, 40000, 3)).astype(np.float32)
+        pts[0, 30000:] = pts[0, :10000]
+        q = rng.random((1, 700, 3)).astype(np.float32)
+    else:
+        pts = sphere(5, 5000, 3)
+        pts[0, 2500:] = pts[0, :2500]
+        pts[1, 4000:] = pts[1, 1000:2000]                                         # set 2: no duplicates at all
+        n_arr = np.array([5000, 4500, 3000], np.int32)
+        pts_of = np.array([0, 1, 1, 2, 2], np.int32)
+        m_arr = np.array([312, 100, 312, 64, 1], np.int32)
+        q = sphere(6, 312, 5) + rng.standard_normal((5, 312, 3)).astype(np.float32) * np.float32(0.01)
+        layout = dict(n_arr=_t(n_arr, dev), m_arr=_t(m_arr, dev), pts_of=_t(pts_of, dev), grp=_t(pts_of.copy(), dev),
+                      groups=3)
+    qd, pd = _t(q.astype(np.float32), dev), _t(pts, dev)
+    be = ops.BACKEND
+    assert be.knn_tiles
+    keep, be.KNN_TILES_MIN_N = be.KNN_TILES_MIN_N, 0          # (the small cases too: the default starts at 16 k rows)
+    try:
+        st = torch.zeros(4, dtype=torch.int32, device=dev)
+        pkg("_lib").lib().tpu3_debug_knn_tiles_stats(ctypes.c_void_p(st.data_ptr()))
+        idx, dist, _ = ops.knn_query(k, qd, pd, unique=True, layout=layout, want_grouped=False)
+        assert int(st[0]) > 0                                   # the pruned kernel is what ran
+        be.knn_tiles = False
+        idx0, dist0, _ = ops.knn_query(k, qd, pd, unique=True, layout=layout, want_grouped=False)
+    finally:
+        be.knn_tiles, be.KNN_TILES_MIN_N = True, keep
+    if case == "ragged":
+        for i, mi in enumerate(m_arr):
+            assert torch.equal(idx[i, :mi], idx0[i, :mi]) and torch.equal(dist[i, :mi], dist0[i, :mi])
+    else:
+        assert torch.equal(idx, idx0) and torch.equal(dist, dist0)
+    if case in ("lattice_ties", "volume_k8"):
+        ri, rd = orc.knn(k, q[:, :200].astype(np.float32), pts, True)
+        np.testing.assert_array_equal(idx[:, :200].cpu().numpy(), ri)
+        np.testing.assert_array_equal(dist[:, :200].cpu().numpy(), rd)
 
 
 def test_group_knn_signature_and_views(orc, dev):
