@@ -86,22 +86,26 @@ class Net(torch.nn.Module):
     def _forward_train(self, cloud, ratio, truth):
         depth = int(log(ratio, self.step_ratio))
         cap = min(cloud.size(-1), self.max_num_point)       # points a level sees at most
-        carry = None                                        # (what the previous level saw, its features)
+        carry = None                # (what the previous level saw, its features), both channel-last: the (B,264,N)
+        # layout of the reference's features exists only at Level.forward's boundary -- between the levels of one
+        # training forward it would be two 10 MB transposes per level and direction
         for at in range(1, depth + 1):
             level = self.levels['level_%d' % at]
+            seen = cloud
             if carry is None:
-                seen = cloud
-                cloud, feat = level(seen, seen, previous_level4=None)
+                seen_cl = seen.transpose(2, 1).contiguous()
+                out_cl, feat_cl = level.forward_cl(seen_cl, seen_cl, None)
+                cloud = out_cl.transpose(2, 1).contiguous()
             else:
-                seen = cloud
                 if cloud.size(-1) > cap:
                     # the ground truth shrinks with the patch: cap * ratio / step_ratio^(at-1) points
                     target_size = cap * ratio // self.step_ratio ** at * self.step_ratio
                     seen, truth = self.extract_xyz_feature_patch(cloud, cap, gt_xyz=truth, gt_k=target_size)
                 unit, centre, scale = operations.normalize_point_batch(seen, NCHW=True)
-                cloud, feat = level(seen, unit, previous_level4=carry)
-                cloud = cloud * scale + centre
-            carry = (seen, feat)
+                seen_cl = seen.transpose(2, 1).contiguous()
+                out_cl, feat_cl = level.forward_cl(seen_cl, unit.transpose(2, 1).contiguous(), carry + (None,))
+                cloud = out_cl.transpose(2, 1).contiguous() * scale + centre
+            carry = (seen_cl, feat_cl)
         return cloud, truth
 
     # ------------------------------------------------------------------------------------------
