@@ -120,9 +120,11 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
     kernel; every ms_per_step is the MEDIAN over the steps of that kernel's per-step sum, the spread is reported."""
     be = ops.BACKEND
     kt = KernelTimer(be)
-    kt.wrap("dense_edge_conv", lambda x, idx, off, k, mlps, out, **kw: (x.shape[0], x.shape[1], k))
-    # (blocks 1-3 of a Level: the same kernel with the later prep convolutions folded into its write-out)
-    kt.wrap("dense_edge_conv_fold", lambda x, idx, off, k, *rest, **kw: (x.shape[0], x.shape[1], k))
+    kt.wrap("dense_edge_conv", lambda x, idx, off, k, mlps, out, **kw: (x.shape[0], x.shape[1], k, 0))
+    # (blocks 1-3 of a Level: the same kernel with the later prep convolutions folded into its write-out -- fold_n =
+    # 72 / 48 / 24 more outputs over the block's 60-channel row)
+    kt.wrap("dense_edge_conv_fold", lambda x, idx, off, k, mlps, out, fold_w, *rest, **kw:
+            (x.shape[0], x.shape[1], k, fold_w.shape[0]))
     kt.wrap("knn_graph", lambda k, x, layout=None: (x.shape[0], x.shape[1], x.shape[2], k))
     kt.wrap("regress_tail", lambda a, c, *rest, **kw: (a.shape[0], c.shape[0]))
     kt.wrap("linear_small", lambda x, w, b, relu, **kw: (x.numel() // x.shape[-1], x.shape[-1], w.shape[0]))
@@ -152,17 +154,18 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
         # executed matrix-core work of the lane-per-point kernel (csrc/dense_edge_conv.hip, dec_fused4_kernel): per
         # 64-point step 108 v_mfma_f32_4x4x1 (512 FLOP each) per neighbour slot + 288 per-point ones (centre terms, z
         # and c2 tables); no padded rows or k slots -- the only padding is the lanes beyond n in a patch's last step
+        # + (folded launches) 60 input channels x fold_n / 4 output groups more of them for the prep convolutions
         steps = lambda n: -(-n // 64)
-        ex = sum(p * steps(n) * (108 * k + 288) * 512.0 for p, n, k in shp)
-        useful = sum(p * n * (108 * k + 288) * 8.0 for p, n, k in shp)           # 512 / 64 lanes = 8 FLOP per lane
-        alg = sum(p * n * k * 3168.0 for p, n, k in shp)               # SURVEY 8a a9 (un-hoisted formulation)
+        ex = sum(p * steps(n) * (108 * k + 288 + 15 * f) * 512.0 for p, n, k, f in shp)
+        useful = sum(p * n * (108 * k + 288 + 15 * f) * 8.0 for p, n, k, f in shp)        # 512 / 64 lanes = 8 FLOP per lane
+        alg = sum(p * n * (k * 3168.0 + 120.0 * f) for p, n, k, f in shp)   # SURVEY 8a a9 (un-hoisted) + the prep convolutions
         ach = ex / (ms * 1e-3) / 1e12
         out.append({"kernel": "dec_fused4_kernel (DenseEdgeConv, fp32 MFMA 4x4x1, lane per point), %d launches/step" % len(shp),
                     "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                     "useful_frac": useful / ex * ach / FP32_PEAK_TF,
-                    "basis": "executed v_mfma_f32_4x4x1 FLOPs of the block (hoisted formulation; the folded prep convolutions "
-                             "of 3 launches in 4 are extra vector work in the same launch, not counted); useful_frac discounts "
-                             "the idle lanes of a patch's last 64-point step (312 of 320)",
+                    "basis": "executed v_mfma_f32_4x4x1 FLOPs: the block (hoisted formulation) + the prep convolutions folded "
+                             "into 3 launches of 4 (60 x fold_n products per point); useful_frac discounts the idle lanes "
+                             "of a patch's last 64-point step (312 of 320)",
                     "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex,
                     "survey_model_flop_per_step": alg, "traffic": tr("dec_fused")})
     ms, shp, spread = kt.total("knn_graph")
@@ -562,7 +565,11 @@ def main():
                 "launch_ms": fps_ms, "operator_ms": op_ms,
                 "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
                 "us_per_round_floor": 2.5,
-                "floor_note": "a round (~34 samples of a cloud) is one dependent chain on ONE compute unit: tile prune -> "
+                "previous_round": {"kernel": "fm_main_kernel", "launch_ms": 121.8, "traffic": 27.19e9, "frac": 0.028,
+                                   "note": "both factors of `achieved` fell: the launch takes 0.47x the time and moves "
+                                           "0.41x the bytes, so the HBM fraction of this latency-bound kernel went DOWN "
+                                           "while it got 2.1x faster; us_per_sample is the figure that tracks its speed"},
+                "floor_note": "a round (~38 samples of a cloud) is one dependent chain on ONE compute unit: tile prune -> "
                               "bucket records of the reached tiles (L2 trip) -> the reached buckets' points (L2 trip) -> "
                               "candidate list -> the ranked candidates' coordinates (L2 trip) -> clearance, with five "
                               "workgroup barriers; three trips of ~0.5 us + ~1 us of instruction issue = 2.5 us per ROUND; "
