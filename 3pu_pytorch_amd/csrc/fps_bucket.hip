@@ -1183,23 +1183,29 @@ struct RlShared {
     int drop[2];                    // ... and the best of the surplus caps what may be accepted
 };
 
-constexpr size_t rl_lds_bytes(int r, bool zl)
+constexpr size_t rl_lds_bytes(int r, bool zl, int nw = 16)
 {
-    return (size_t)1024 * r * 2 + (zl ? (size_t)1024 * r * 4 : 0) + sizeof(RlShared) + 64;
+    return (nw == 16 ? (size_t)1024 * r * 2 : 0) + (zl ? (size_t)nw * 64 * r * 4 : 0) + sizeof(RlShared) + 64;
 }
 
-template <int R, bool PROF = false>
-__global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
+// NW waves per set.  16: a set is a whole compute unit (25 x 1024 points).  The sets of a launch are independent
+// dependent chains, each leaving most of its compute unit idle (a round is: a few of the waves update, one wave ranks),
+// so SEVERAL sets per compute unit finish sooner than one after the other: sets of 7169 .. 12 800 points run as 8 waves
+// of 25 points per lane (two sets per compute unit; their tie keys stay in memory -- read by ties and winners only --
+// so that a set's LDS is its z coordinates alone), sets of <= 7168 points keep 16 waves of <= 7 points per lane with the
+// registers capped at 64 (two per compute unit as well).  A 4-wave form (TPU3_RL_NW=4) exists for <= 6400 points.
+template <int R, bool PROF = false, int NW = 16>
+__global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_main_kernel(FbArgs a0)
 {
-    constexpr int NW = 16;
+    constexpr bool KG = NW < 16;                    // tie keys read from a.skey instead of an LDS copy
     constexpr bool ZL = rl_zl<R>();
     auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;     // PROF: apply, select, barrier 1, rank, barrier 2
     unsigned long long pr[5] = {0, 0, 0, 0, 0}, r0 = 0, r1 = 0;        // PROF, wave 0: ranking phases, candidates
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint16_t *i16 = (uint16_t *)smem;                               // original index of [wave][j][lane]
-    float *zl = (float *)(smem + (size_t)1024 * R * 2);             // (ZL) z of [wave][j][lane]
-    RlShared &sh = *(RlShared *)(zl + (ZL ? 1024 * R : 0));
+    uint16_t *i16 = (uint16_t *)smem;                               // (!KG) original index of [wave][j][lane]
+    float *zl = (float *)(smem + (KG ? 0 : (size_t)1024 * R * 2));  // (ZL) z of [wave][j][lane]
+    RlShared &sh = *(RlShared *)(zl + (ZL ? NW * 64 * R : 0));
     const FbArgs a = fb_elem(a0, blockIdx.x);
     if (a.n <= 0 || a.m <= 0)
         return;
@@ -1208,8 +1214,13 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
     uint16_t *kw = i16 + wave * R * 64 + lane;      // kw[64 * j]
     float *zw = zl + wave * R * 64 + lane;          // (ZL) zw[64 * j]
     auto key_at = [&](int j) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t v = kw[64 * j];
-        return v == 0xFFFFu ? 0xFFFFFFFFu : tpu3_fps_tiekey((int)v, lb);
+        if constexpr (KG) {
+            const int slot = tid * R + j;
+            return slot < a0.npad ? a.skey[slot] : 0xFFFFFFFFu;
+        } else {
+            const uint32_t v = kw[64 * j];
+            return v == 0xFFFFu ? 0xFFFFFFFFu : tpu3_fps_tiekey((int)v, lb);
+        }
     };
 
     // bucket `tid` = sorted points [tid R, tid R + R)
@@ -1230,7 +1241,8 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
         else
             pz[ZL ? 0 : j] = v.z;
         const bool alive = key != 0xFFFFFFFFu;
-        kw[64 * j] = alive ? (uint16_t)tpu3_fps_tiekey_to_index(key, lb) : (uint16_t)0xFFFFu;
+        if constexpr (!KG)
+            kw[64 * j] = alive ? (uint16_t)tpu3_fps_tiekey_to_index(key, lb) : (uint16_t)0xFFFFu;
         blx = alive ? fminf(blx, v.x) : blx; bly = alive ? fminf(bly, v.y) : bly; blz = alive ? fminf(blz, v.z) : blz;
         bhx = alive ? fmaxf(bhx, v.x) : bhx; bhy = alive ? fmaxf(bhy, v.y) : bhy; bhz = alive ? fmaxf(bhz, v.z) : bhz;
     }
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
             if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
             __syncthreads();
             {
-                const int sr = lane < 16 ? sh.h[par][lane].rmax : (int)0x80000000;
+                const int sr = lane < NW ? sh.h[par][lane].rmax : (int)0x80000000;
                 rstar = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sr), 0);
                 const bool is_cand = mine > rstar;
                 const unsigned long long cm = __ballot(is_cand);
@@ -1404,9 +1416,9 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
             // wave 0 ranks the candidates; the others wait at a second barrier and read the round's samples from LDS
             const int left = a.m - r;
             if (wave == 0) {
-                const FmHeader &hh = sh.h[par][lane & 15];
-                const int sd = lane < 16 ? hh.best : (int)0x80000000;
-                const uint32_t sk = lane < 16 ? hh.key : 0xFFFFFFFFu;
+                const FmHeader &hh = sh.h[par][lane & (NW - 1)];
+                const int sd = lane < NW ? hh.best : (int)0x80000000;
+                const uint32_t sk = lane < NW ? hh.key : 0xFFFFFFFFu;
                 const float hx = hh.x, hy = hh.y, hz = hh.z;
                 const int gbest = __builtin_amdgcn_readlane(tpu3_row_max_i32_fast(sd), 0);
                 const int nc = __builtin_amdgcn_readfirstlane(sh.ncand[par]);
@@ -1427,13 +1439,13 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
                 const bool usable = total >= 1 && __ballot(live && cM0 > gdrop) != 0;
                 if (!usable) {
                     // single sample: the plain arg-max over the waves' bests (the reference's tie rule)
-                    unsigned long long who = __ballot(lane < 16 && sd == gbest);
+                    unsigned long long who = __ballot(lane < NW && sd == gbest);
                     if (__builtin_popcountll(who) != 1) {
-                        const uint32_t wk = tpu3_row_min_u32(lane < 16 && sd == gbest ? sk : 0xFFFFFFFFu);
+                        const uint32_t wk = tpu3_row_min_u32(lane < NW && sd == gbest ? sk : 0xFFFFFFFFu);
                         const uint32_t win = (uint32_t)__builtin_amdgcn_readlane((int)wk, 0);
-                        who = __ballot(lane < 16 && sd == gbest && sk == win);
+                        who = __ballot(lane < NW && sd == gbest && sk == win);
                     }
-                    const int ww = __builtin_ctzll(who | (1ull << 63)) & 15;
+                    const int ww = __builtin_ctzll(who | (1ull << 63)) & (NW - 1);
                     qx = rl(hx, ww); qy = rl(hy, ww); qz = rl(hz, ww);
                     okey = (uint32_t)__builtin_amdgcn_readlane((int)sk, ww);
                     nj = 1;
@@ -1559,9 +1571,16 @@ __global__ __launch_bounds__(1024) void rl_main_kernel(FbArgs a0)
         }
     // final running distances, back in the caller's order
     rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
-        const uint32_t v = kw[64 * decltype(jc)::value];
-        if (v != 0xFFFFu)
-            a.temp[v] = pt[decltype(jc)::value];
+        constexpr int j = decltype(jc)::value;
+        if constexpr (KG) {
+            const uint32_t key = key_at(j);
+            if (key != 0xFFFFFFFFu)
+                a.temp[tpu3_fps_tiekey_to_index(key, lb)] = pt[j];
+        } else {
+            const uint32_t v = kw[64 * j];
+            if (v != 0xFFFFu)
+                a.temp[v] = pt[j];
+        }
     });
 }
 
@@ -2670,20 +2689,26 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         a0.prof = g_level_stats;
         g_level_stats = nullptr;
         hipError_t e = hipSuccess;
-#define RL_LAUNCH(RR, PP)                                                                                 \
+#define RL_LAUNCH(RR, PP, NWV)                                                                            \
     {                                                                                                     \
-        const size_t lds = rl_lds_bytes(RR, rl_zl<RR>());                                               \
-        e = hipFuncSetAttribute((const void *)rl_main_kernel<RR, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                \
+        const size_t lds = rl_lds_bytes(RR, rl_zl<RR>(), NWV);                                           \
+        e = hipFuncSetAttribute((const void *)rl_main_kernel<RR, PP, NWV>,                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
         if (e != hipSuccess) return (int)e;                                                               \
-        hipLaunchKernelGGL((rl_main_kernel<RR, PP>), dim3(b), dim3(1024), lds, s, a0);                    \
+        hipLaunchKernelGGL((rl_main_kernel<RR, PP, NWV>), dim3(b), dim3(NWV * 64), lds, s, a0);           \
     }
+        // waves per set (see rl_main_kernel).  TPU3_RL_NW=16: tuning hook, every set on 16 waves
+        static const int rl_nw = getenv("TPU3_RL_NW") ? atoi(getenv("TPU3_RL_NW")) : 0;
         const int rr = (n + 1023) / 1024;
-        if (rr <= 7) RL_LAUNCH(7, false)
-        else if (rr <= 13) RL_LAUNCH(13, false)
-        else if (rr <= 19) RL_LAUNCH(19, false)
-        else if (a0.prof) RL_LAUNCH(25, true)
-        else RL_LAUNCH(25, false)
+        // (measured, 1536 sets: 6240 points 2.91 ms on 16 waves with capped registers vs 3.01 ms on 4 waves;
+        // 12 480 points 6.81 ms on 8 waves vs 7.66 ms on 16; 24 960 points need all 1024 lanes)
+        if (rl_nw == 4 && !a0.prof && n <= 25 * 256) RL_LAUNCH(25, false, 4)
+        else if (rr <= 7) RL_LAUNCH(7, false, 16)
+        else if (rl_nw != 16 && !a0.prof && n <= 25 * 512) RL_LAUNCH(25, false, 8)
+        else if (rr <= 13) RL_LAUNCH(13, false, 16)
+        else if (rr <= 19) RL_LAUNCH(19, false, 16)
+        else if (a0.prof) RL_LAUNCH(25, true, 16)
+        else RL_LAUNCH(25, false, 16)
 #undef RL_LAUNCH
         return tpu3_launch_status();
     }
