@@ -392,10 +392,19 @@ __global__ __launch_bounds__(256) void kt_query_kernel(KtQueryArgs a)
     if (!live)
         return;
     const size_t o = ((size_t)b * a.m + qi) * a.k;
+    // A list that is not full after the search (a query with a NaN coordinate fails every `lo4 <= dlast` test; a set
+    // with fewer than k candidates fills up with the last tile's dead slots, row -1 at D = +inf) must never reach the
+    // gathers behind this kernel as row -1: the exact path redoes the call, and the row written here stays in range.
+    bool hole = false;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        hole |= i < a.k && (int)(uint32_t)kb[i] < 0;
+    if (hole)
+        a.uws[1] = 1u;
 #pragma unroll
     for (int i = 0; i < K; ++i)
         if (i < a.k) {
-            const int row = (int)(uint32_t)kb[i];
+            const int row = max((int)(uint32_t)kb[i], 0);
             if (a.idx64)
                 ((int64_t *)a.idx)[o + i] = (int64_t)row;
             else

@@ -60,7 +60,8 @@ class Net(torch.nn.Module):
         # number of streams, however many eval calls are made; see small_cloud_events)
         self._small_cloud_counts = {}
         # optional list: when set, the eval path appends one dict per level
-        # (patch_xyz (P,3,k) un-normalised inputs, out_norm (P,3,k*r) level output, patch_num)
+        # (patch_xyz (P,3,k) un-normalised inputs, out_norm (P,3,k*r) level output, patch_num,
+        #  cloud (B,k*r^l,3) the cloud held after the level, reference :163 / :156-159)
         self.trace = None
 
     # ------------------------------------------------------------------------------------------
@@ -210,6 +211,7 @@ class Net(torch.nn.Module):
                 xyz_cl, old_feat = level.forward_cl(xyz_cl, xyz_cl, None, owner=each, groups=B)
                 if self.trace is not None:
                     self.trace[-1]["out_norm"] = xyz_cl.transpose(2, 1)
+                    self.trace[-1]["cloud"] = xyz_cl
                 continue
             if xyz_cl.size(1) > max_num_point:
                 patches, patch_num = self._repatch(xyz_cl, max_num_point)      # (B,P,k,3)
@@ -241,6 +243,8 @@ class Net(torch.nn.Module):
                 m_count = (patch_num * (k * r)).contiguous()
                 idx = operations.fps(merged, num_output_point, n_arr=m_count, m_arr=None)
                 xyz_cl = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+            if self.trace is not None:
+                self.trace[-1]["cloud"] = xyz_cl            # (B, num_point * curr_ratio, 3): what the next level sees
         return xyz_cl.transpose(2, 1).contiguous()
 
     def forward(self, xyz, ratio=None, gt=None, **kwargs):
@@ -364,9 +368,22 @@ class Level(torch.nn.Module):
                 or any(p.conv.out_channels != 24 or p.activation != "relu" or not p.pointwise()
                        for p in preps)):
             return None
-        key = tuple(p.conv.weight._version for p in preps) + tuple(p.conv.weight.data_ptr() for p in preps)
+        # (weights AND biases: block 0 bakes the three biases in; a bias-only in-place edit must rebuild too)
+        key = tuple(t._version for p in preps for t in (p.conv.weight, p.conv.bias)) + \
+            tuple(t.data_ptr() for p in preps for t in (p.conv.weight, p.conv.bias))
         cached = getattr(self, "_fold_cache", None)
+        on_device = preps[0].conv.weight.is_cuda
+        here = torch.cuda.current_stream(preps[0].conv.weight.device) if on_device else None
         if cached is not None and cached[0] == key:
+            # the plan was BUILT by kernels on one stream; pipeline.upsample runs sub-batches of the same net on
+            # several streams: every other stream orders itself behind the build (advisor, round 3)
+            built_on, done = cached[2], cached[3]
+            if on_device and built_on != here.cuda_stream:
+                here.wait_event(done)
+                for e in cached[1]:
+                    for t in (e["w"], e["b"]):
+                        if t is not None:
+                            t.record_stream(here)
             return cached[1]
         W = [p.conv.weight.detach().reshape(24, -1) for p in preps]            # (24, 84), (24, 144), (24, 204)
         bs = [p.conv.bias.detach() for p in preps]
@@ -382,7 +399,11 @@ class Level(torch.nn.Module):
                          b=torch.cat(bs, dim=0).contiguous() if i == 0 else None,
                          seed_off=0 if i < 2 else 24, store_off=0 if i == 0 else 24)
             plan.append(entry)
-        self._fold_cache = (key, plan)
+        done = None
+        if on_device:
+            done = torch.cuda.Event()
+            done.record(here)
+        self._fold_cache = (key, plan, here.cuda_stream if on_device else None, done)
         return plan
 
     def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):

@@ -46,12 +46,23 @@ def extract_outer_patches(clouds, num_point, patch_num_ratio=3):
 
 
 @torch.no_grad()
-def upsample_patches(net, patches_cl, up_ratio):
+def upsample_patches(net, patches_cl, up_ratio, levels_out=None):
     """main.py:237-244 for all patches at once: (Q,num_point,3) channel-last, un-normalised ->
-    (Q, num_point*up_ratio, 3) de-normalised, and the normalised input patches (Q,3,num_point)."""
+    (Q, num_point*up_ratio, 3) de-normalised, and the normalised input patches (Q,3,num_point).
+    levels_out: optional list; receives the cloud every patch holds after each level, de-normalised like the final
+    output, (Q, 3, num_point * step^l) per level (parity diagnostics: tests/test_c2_parity.py)."""
     patch = patches_cl.transpose(2, 1).contiguous()
     patch, centroid, radius = operations.normalize_point_batch(patch, NCHW=True)
-    up = net.forward(patch, ratio=up_ratio)
+    if levels_out is not None:
+        saved, net.trace = net.trace, []
+    try:
+        up = net.forward(patch, ratio=up_ratio)
+        if levels_out is not None:
+            for rec in net.trace:
+                levels_out.append(rec["cloud"].transpose(2, 1) * radius + centroid)
+    finally:
+        if levels_out is not None:
+            net.trace = saved
     up = up * radius + centroid
     return up.transpose(2, 1).contiguous(), patch
 

@@ -58,13 +58,9 @@ def pkg(sub=None):
     return importlib.import_module("3pu_pytorch_amd" + ("." + sub if sub else ""))
 
 
-def poisson_sphere(seed, n, dev, ops):
-    """Blue-noise-like cloud: 8n uniform S^2 candidates thinned to n by FPS."""
-    g = torch.Generator().manual_seed(seed)
-    cand = torch.randn(1, 8 * n, 3, generator=g)
-    cand = (cand / cand.norm(dim=2, keepdim=True)).to(dev)
-    idx = ops.fps(cand, n)
-    return torch.gather(cand, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).transpose(2, 1).contiguous()
+def poisson_sphere(seed, n, dev, ops=None):
+    """Config C2's input (3pu_pytorch_amd/utils/workloads.py)."""
+    return pkg("utils.workloads").poisson_sphere(seed, n, dev)
 
 
 class KernelTimer(object):
@@ -344,22 +340,24 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
 
 def parity_block(ops, pipe, ups, dev, cpu_out, N=5000, npnt=312):
     """Config C1 on the device against the oracle-driven CPU output of the same cloud and weights."""
-    from oracle import cpu_baseline, oracle as orc
-    net = cpu_baseline.c1_net(ups).to(dev)
-    x = cpu_baseline.c1_cloud(0, N).to(dev)
-    out = pipe.upsample(net, x, npnt, 2, 3)                              # (1,3,2N)
-    mine = out.transpose(2, 1).contiguous()
-    ref = cpu_out.to(dev)
-    ml = pkg("network.model_loss")
-    d1, _, d2, _ = ml.nndistance(mine, ref)
-    close = min(float((d1.sqrt() <= 1e-5).float().mean()), float((d2.sqrt() <= 1e-5).float().mean()))
-    cd = float(orc.chamfer_loss(mine.cpu().numpy(), ref.cpu().numpy()))
-    # identical positions (same FPS order too)
-    same = float(((mine - ref).abs().amax(dim=2) <= 1e-5).float().mean())
-    return {"config": "C1: 1 cloud x %d pts, num_point=%d, up_ratio=2, one level, 48 patches -> FPS %d" % (N, npnt, 2 * N),
-            "chamfer_vs_oracle": cd, "set_close_1e-5": close, "position_wise_close_1e-5": same,
-            "note": "HIP path vs the oracle-driven CPU path (oracle/cpu_baseline.py) on the same cloud and weights; "
-                    "chamfer = mean squared NN distance both ways (model_loss.py:50-85)"}
+    from oracle import cpu_baseline
+    return pkg("utils.parity").c1_parity(dev, cpu_baseline.c1_net(ups).to(dev), cpu_baseline.c1_cloud(0, N), cpu_out, npnt)
+
+
+def parity_c2_block(dev):
+    """The metric's own configuration against the reference driver's fixture AND the reference-vs-reference controls
+    (tests/golden/c2_x16*.npz are data files; tests/test_c2_controls_cpu.py pins the controls on CPU)."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    fixtures = {}
+    for k in ("ref", "alt", "alt2", "alt3"):
+        path = os.path.join(gdir, "c2_x16%s.npz" % ("" if k == "ref" else "_" + k))
+        if os.path.exists(path):
+            fixtures[k] = np.load(path, allow_pickle=False)
+    ups = pkg("network.upsampler")
+    net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+    state = np.load(os.path.join(gdir, "net16_state.npz"), allow_pickle=False)
+    net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
+    return pkg("utils.parity").c2_parity(dev, net.to(dev).eval(), fixtures)
 
 
 def main():
@@ -616,9 +614,7 @@ def main():
             line["parity"] = parity_block(ops, pipe, ups, dev, cpu_out)
             try:
                 # the metric's own configuration against the reference-driven fixture (tests/golden/c2_x16.npz: data)
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import test_c2_parity
-                line["parity_c2"] = test_c2_parity.c2_parity(dev)
+                line["parity_c2"] = parity_c2_block(dev)
             except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
                 line["parity_c2"] = "failed: %s" % (str(e).splitlines()[0][:160])
         else:

@@ -109,3 +109,80 @@ def measure_c1(num_shape_point=5000, num_point=312, up_ratio=2, repeats=5, threa
 
 def measure(num_shape_point=5000, num_point=312, up_ratio=2):
     return measure_c1(num_shape_point, num_point, up_ratio)[0]
+
+
+def run_c2(golden_dir, threads=None):
+    """Config C2 (the metric's: 5000 -> 80 000 points, 16x, 48 outer patches) through the oracle-driven CPU path
+    -- the product's HOST logic (pipeline.py, network/*: every patch of a level in one batched call) over the C
+    oracle and torch-CPU convolutions -- on the cloud and weights of tests/golden/c2_x16.npz.  Returns a "run"
+    (oracle/parity_np.py) and the wall time.  Minutes on 8 cores."""
+    from . import oracle as orc
+    from .backend import OracleBackend
+    ops = importlib.import_module("3pu_pytorch_amd.network.operations")
+    ups = importlib.import_module("3pu_pytorch_amd.network.upsampler")
+    pipe = importlib.import_module("3pu_pytorch_amd.pipeline")
+    orc.build()
+    torch.set_num_threads(threads or min(os.cpu_count() or 1, 32))
+    g = np.load(os.path.join(golden_dir, "c2_x16.npz"))
+    state = np.load(os.path.join(golden_dir, "net16_state.npz"))
+    net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+    net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
+    net.eval()
+    saved = ops.BACKEND
+    ops.BACKEND = OracleBackend()
+    try:
+        t0 = time.perf_counter()
+        cloud = torch.from_numpy(g["cloud"])
+        seed_idx, patches, pidx = pipe.extract_outer_patches(cloud, 312, 3)
+        P = patches.size(1)
+        levels = []
+        with torch.no_grad():
+            up, _ = pipe.upsample_patches(net, patches.reshape(P, 312, 3), 16, levels_out=levels)
+        merged = up.reshape(1, P * up.size(1), 3)
+        idx = ops.fps(merged, 80000)
+        final = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+        dt = time.perf_counter() - t0
+    finally:
+        ops.BACKEND = saved
+    run = {"seed_idx": seed_idx.numpy(), "patch_idx": pidx.numpy()[0],
+           "lv1": levels[0].numpy(), "lv2": levels[1].numpy(), "lv3": levels[2].numpy(),
+           "pred_concat": merged.transpose(2, 1).contiguous().numpy(), "final": final.transpose(2, 1).contiguous().numpy()}
+    return run, dt
+
+
+def measure_c2(golden_dir, out_path=None):
+    """`python -m oracle.cpu_baseline --c2`: the oracle-driven CPU path against the reference driver's fixture and
+    against the two reference-vs-reference controls -> profiles/r04_c2_cpu_vs_ref.json."""
+    import json
+    from . import parity_np as pn
+    run, dt = run_c2(golden_dir)
+    ref = np.load(os.path.join(golden_dir, "c2_x16.npz"))
+    out = {"what": "config C2 through the oracle-driven CPU path (product host logic over oracle/ref_kernels.c + "
+                   "torch-CPU convolutions) against tests/golden/c2_x16.npz (the reference's own Python driver)",
+           "wall_s": dt, "torch": torch.__version__, "numpy": np.__version__,
+           "outer_seeds_bit_exact": bool((run["seed_idx"] == ref["seed_idx"]).all()),
+           "outer_patch_idx_bit_exact": bool((run["patch_idx"] == ref["patch_idx"]).all()),
+           "cpu_path_vs_ref": pn.compare_runs(run, ref)}
+    for name in ("c2_x16_alt.npz", "c2_x16_alt2.npz", "c2_x16_alt3.npz"):
+        path = os.path.join(golden_dir, name)
+        if os.path.exists(path):
+            alt = np.load(path)
+            out["ref_vs_" + name[7:-4]] = dict(pn.compare_runs(ref, alt), variant=str(alt["variant"]))
+            out["cpu_path_vs_" + name[7:-4]] = pn.compare_runs(run, alt)
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(out, f, indent=1)
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    if "--c2" in sys.argv:
+        r = measure_c2(os.path.join(root, "tests", "golden"), os.path.join(root, "profiles", "r04_c2_cpu_vs_ref.json"))
+        import json
+        print(json.dumps(r, indent=1))
+    else:
+        print(measure())

@@ -299,6 +299,28 @@ def test_net_train_backward_matches_reference_on_device(dev):
     host.check_train_grads(*host._train_grads(ups, dev), tol=2e-2, tol_median=1e-3)
 
 
+def test_net_train_backward_with_reference_graphs_on_device(dev, monkeypatch):
+    """The same fixture with the reference's twelve feature graphs (3 levels x 4 DenseEdgeConv blocks, recorded by
+    oracle/make_golden.py::make_train_grad_golden) replayed into dec_train_fwd / dec_train_bwd: nothing discrete is
+    left to differ, so every parameter gradient must agree with the reference's autograd to fp32 accuracy -- 1e-4 of
+    each tensor's largest gradient, against the 2e-2 the free-running test above needs for its flipped near-ties
+    (VERDICT round 3, item 1 vi).  Proves the attribution: the looseness above IS the graph flips."""
+    import test_host_network_cpu as host
+    ops, ups = pkg("network.operations"), pkg("network.upsampler")
+    g = golden("net_train_grad.npz")
+    graphs = [torch.from_numpy(g["graph%02d" % i].astype(np.int32)).to(dev) for i in range(12)]
+    calls = []
+
+    def replay(k, x, layout=None, optimistic=None):
+        calls.append((k, tuple(x.shape)))
+        return graphs[len(calls) - 1]
+    monkeypatch.setattr(ops.BACKEND, "knn_graph", replay, raising=False)
+    res = host._train_grads(ups, dev)
+    monkeypatch.undo()
+    assert calls == [(33, (2, 312, 24))] * 12
+    host.check_train_grads(*res, tol=1e-4)
+
+
 def test_training_step_runs_and_updates(dev):
     """config C3 shape: batch 32 patches, Chamfer fwd+bwd at n = m = 624, clip, Adam."""
     model_mod = pkg("model")
