@@ -18,10 +18,21 @@ of fp32 xyz at the point where the reference concatenates (`shard="clouds"`: the
 clouds; `shard="patches"`: the upsampled patches, after which the final FPS, which does not
 shard, runs replicated).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .network import operations
+
+# TPU3_FORCE_COLLECTIVES=1: take the sharded code paths -- shard_range, the MAX all-reduce of the event flags, the
+# all-gather -- whenever a process group exists, even at world size 1.  A single-GPU box can then run every RCCL call
+# of the N-rank path (tests/test_rccl_world1.py); at world size 1 the results are those of the unsharded call.
+FORCE_COLLECTIVES = os.environ.get("TPU3_FORCE_COLLECTIVES", "0") not in ("0", "")
+
+
+def _distributed(world):
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def num_outer_patches(num_shape_point, num_point, patch_num_ratio=3):
@@ -76,7 +87,7 @@ def _world():
 def _all_gather_cat(t):
     """all-gather equal-shaped tensors of every rank and concatenate along dim 0 (rank order)."""
     rank, world = _world()
-    if world == 1:
+    if not _distributed(world):
         return t
     t = t.contiguous()
     out = torch.empty((world * t.size(0),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -101,7 +112,7 @@ def _any_rank(flag, device):
     """True on every rank if `flag` is true on any rank (one MAX all-reduce of a single word; no-op without a
     process group).  Decisions that change the NUMBER of collectives a rank issues must be taken on this."""
     rank, world = _world()
-    if world == 1:
+    if not _distributed(world):
         return bool(flag)
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +209,9 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
         return out.transpose(2, 1).contiguous()
 
-    if (shard is None or world == 1) and net_streams and len(net_streams) > 1 and C > 1:
+    if not _distributed(world):
+        shard = None
+    if shard is None and net_streams and len(net_streams) > 1 and C > 1:
         cur = torch.cuda.current_stream()
         parts = []
         per = max(1, min(int(sub_batch), -(-C // len(net_streams))))
@@ -233,7 +246,7 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         for t in parts:
             t.record_stream(cur)
         merged = torch.cat(parts, dim=0)
-    elif shard is None or world == 1:
+    elif shard is None:
         _, patches, _ = extract_outer_patches(clouds, num_point, patch_num_ratio)
         P = patches.size(1)
         up, _ = upsample_patches(net, patches.reshape(C * P, num_point, 3), up_ratio)

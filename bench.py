@@ -402,10 +402,20 @@ def main():
     backend = os.environ.get("TPU3_BENCH_BACKEND", "nccl")
     if os.environ.get("TPU3_BENCH_ONE_DEVICE"):
         local_rank = 0
+    # the device is bound BEFORE any allocation or communicator exists (RCCL binds its communicator to the current
+    # device; device_id makes the binding explicit and lets init create the communicator eagerly)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TPU3_BENCH_FORCE_DIST=1: initialise the process group and take every N > 1 code path (sharding, the all-gather on
+    # the side stream, the `comm` block, the barrier in fence()) at WHATEVER world size, 1 included -- so that RCCL has
+    # executed on a one-GPU box before the driver's 8-GPU node is the first to try (tests/test_rccl_world1.py)
+    force_dist = os.environ.get("TPU3_BENCH_FORCE_DIST", "0") not in ("0", "")
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if force_dist:
+            os.environ["TPU3_FORCE_COLLECTIVES"] = "1"      # read by pipeline.py at import (below)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -413,7 +423,7 @@ def main():
 
     ops, pipe, ups = pkg("network.operations"), pkg("pipeline"), pkg("network.upsampler")
     assert ops.BACKEND.name == "hip-gfx950"
-    patch_mode = world > 1 and args.shard == "patches"
+    patch_mode = multi and args.shard == "patches"
     N, npnt, r = args.num_shape_point, args.num_point, args.up_ratio
     C = 1 if patch_mode else args.clouds
     torch.manual_seed(0)
@@ -464,12 +474,13 @@ def main():
         out = pipe.upsample(net, clouds, npnt, r, 3, timing=timing, fps_stream=sides if split else side,
                             net_streams=nets, sub_batch=args.sub_batch, fps_offset=off, check_small=False,
                             optimistic_graph=True)                                                            # (C,3,N*r)
+        # (cloud-sharded ranks: every rank upsamples ITS clouds with the unsharded call above, then ONE all-gather)
         if split:
             # the step's launches ran on sides[off .. off + n_sub): join them on the first of them
             side = sides[off % len(sides)]
             for i in range(1, n_sub):
                 side.wait_stream(sides[(off + i) % len(sides)])
-        if world > 1:                                                       # reassemble: ONE all-gather
+        if multi:                                                           # reassemble: ONE all-gather
             if side is not None:
                 with torch.cuda.stream(side):
                     out = pipe._all_gather_cat(out)
@@ -479,7 +490,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -492,7 +503,7 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -504,7 +515,7 @@ def main():
 
     # all-gather bus bandwidth (N > 1): (P-1)/P * gathered bytes / time, 10 back-to-back gathers
     comm = None
-    if world > 1:
+    if multi:
         if patch_mode:
             P_ = pipe.num_outer_patches(N, npnt, 3)
             part = torch.empty((-(-P_ // world), npnt * r, 3), device=dev)
@@ -521,7 +532,8 @@ def main():
         total_bytes = part.numel() * 4 * world
         comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "allgather_bytes_total": total_bytes, "allgather_ms": dt * 1e3,
-                "allgather_bus_GBps": (world - 1) / world * total_bytes / dt / 1e9}
+                "allgather_bus_GBps": (world - 1) / world * total_bytes / dt / 1e9,
+                "forced_at_world_size_1": bool(force_dist and world == 1)}
 
     op_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
     fps_ms = None
@@ -591,8 +603,15 @@ def main():
                                    "up_ratio=%d, %d outer patches" % (N, world, npnt, r, P),
                        "clouds_per_gpu": C, "final_fps_overlap": sides is not None and not patch_mode,
                        "final_fps_launches_per_step": n_sub,
-                       "parallelism": ("patches sharded, 1 all-gather/step, final FPS replicated" if patch_mode else
-                                       "clouds sharded, 1 all-gather/step") if world > 1 else "single GPU"},
+                       "parallelism": (
+                           ("dp%d over outer patches: the %d outer patches of ONE cloud split across the ranks (strong "
+                            "scaling), one all-gather of the upsampled patches (%.1f MB) per step, then the final FPS "
+                            "REPLICATED on every rank -- the Amdahl term" % (world, P, P * npnt * r * 12 / 1e6))
+                           if patch_mode else
+                           ("dp%d over clouds: %d whole clouds per rank, per-GPU work fixed as N grows (weak scaling), "
+                            "zero communication until ONE all-gather of the finished clouds (%.1f MB of fp32 xyz) per "
+                            "step over RCCL / xGMI, issued on the final-FPS side stream"
+                            % (world, C, world * C * 3 * N * r * 4 / 1e6))) if multi else "single GPU"},
             "roofline": roof,
         }
         if comm is not None:
@@ -620,7 +639,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
