@@ -25,9 +25,7 @@
 // add issue pressure -- a 16-wave version of the single-sample kernel was issue-bound at 4400 cycles per
 // round) per batch element.  Group g belongs to wave g % 4; every table entry is written and read by the same
 // wave, hence no barrier between update and selection.
-#include "tpu3_dev.h"
-
-#include <hip/hip_fp16.h>
+#include "fps_bucket.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -38,60 +36,6 @@
 namespace {
 
 constexpr int FB_GS = 16;        // buckets per group = lanes per DPP row
-
-// Arguments of batch element 0; fb_elem() derives element i.  User arrays are dense (b, n, ...)
-// slabs, the per-element workspace arrays repeat every `per_elem` bytes, the sort arrays every
-// `sort_stride` words.
-struct FbArgs {
-    int n, m, nb, nbpad, npad, ng;      // n, m: slab strides = upper bounds of the live sizes
-    int ncell;                          // entries of the main kernel's LDS table: nbpad, or nbpad / 16 (three levels)
-    int bsz, lb;                        // points per bucket; log2 of the tie-rule block size
-    const int32_t *n_arr, *m_arr;       // live sizes per element, or null
-    const float *xyz;     // (n,3) original order
-    float *temp;          // (n)
-    int32_t *idx;         // (m)
-    float4 *sp;           // (npad) Morton order: x, y, z, running distance
-    uint32_t *skey;       // (npad) tie key of the original index (0xFFFFFFFF = padding)
-    uint32_t *ib;         // (9, nbpad) initial bucket table: max, key, x, y, z, box0, box1, box2, runner-up
-    float *bbox;          // (8)
-    size_t per_elem;
-    size_t sort_stride;
-    unsigned long long *prof;   // PROF builds only
-    // (r3) tile form (fl_main_kernel): a bucket = 16 consecutive slots of sp / skey, a tile = 64 buckets; one record
-    // per bucket and per tile
-    int fl, ntile;              // fl != 0: tile form; tiles of the slab (upper bound of the live count)
-    uint4 *rec;                 // (ntile * 64) bucket records: fp16 box (3 words) | runner-up distance bits
-    int32_t *bm0;               // (ntile * 64) initial bucket maxima (distance bits)
-    uint8_t *ba0;               // (ntile * 64) initial position (0..15) of the bucket's best point
-    float *tt;                  // (ntile, 8) tile records: box lo.xyz hi.xyz, max bits, runner-up bits
-};
-
-// element i of the batch: pointers advanced, n / m / nb / lb replaced by the element's live values
-__device__ __forceinline__ FbArgs fb_elem(const FbArgs &a0, int i)
-{
-    FbArgs a = a0;
-    a.xyz = a0.xyz + (size_t)i * a0.n * 3;
-    a.temp = a0.temp + (size_t)i * a0.n;
-    a.idx = a0.idx + (size_t)i * a0.m;
-    a.sp = (float4 *)((char *)a0.sp + (size_t)i * a0.per_elem);
-    a.skey = (uint32_t *)((char *)a0.skey + (size_t)i * a0.per_elem);
-    a.ib = (uint32_t *)((char *)a0.ib + (size_t)i * a0.per_elem);
-    a.bbox = (float *)((char *)a0.bbox + (size_t)i * a0.per_elem);
-    if (a0.fl) {
-        a.rec = (uint4 *)((char *)a0.rec + (size_t)i * a0.per_elem);
-        a.bm0 = (int32_t *)((char *)a0.bm0 + (size_t)i * a0.per_elem);
-        a.ba0 = (uint8_t *)((char *)a0.ba0 + (size_t)i * a0.per_elem);
-        a.tt = (float *)((char *)a0.tt + (size_t)i * a0.per_elem);
-    }
-    if (a0.n_arr) {
-        a.n = min(max(a0.n_arr[i], 0), a0.n);
-        a.nb = (a.n + a0.bsz - 1) / a0.bsz;
-        a.lb = tpu3_fps_log2_bs(a.n);
-    }
-    if (a0.m_arr)
-        a.m = min(max(a0.m_arr[i], 0), a0.m);
-    return a;
-}
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
 {
@@ -330,18 +274,6 @@ __global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a0)
         ib[7 * S + beta] = h[4] | (h[5] << 16);
         ib[8 * S + beta] = (uint32_t)runner;
     }
-}
-
-__device__ __forceinline__ float fb_half_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); }
-__device__ __forceinline__ float fb_half_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
-
-__device__ __forceinline__ float fb_dbox(float qx, float qy, float qz, float lx, float ly, float lz, float hx,
-                                         float hy, float hz)
-{
-    const float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
-    const float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
-    const float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
-    return tpu3_sqdist3(dx, dy, dz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1607,8 +1539,6 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
 //     an LDS counter, wave 0 ranks them and finds the longest clear prefix as in rl_main_kernel.
 // Exact for the same reason as the other bucketed kernels (box distance in the point distance's association is a
 // lower bound of every computed distance; stale bounds stay bounds).
-constexpr int FL_R = 16;                 // points per bucket
-constexpr int FL_TP = 64 * FL_R;         // points per tile
 constexpr int FL_CAP = 64;               // samples per round
 constexpr int FL_LIST = 512;             // candidates a round may list
 constexpr int FL_EW = 8;                 // words per candidate entry (5 used)
@@ -2489,8 +2419,14 @@ struct FbPlan {
     size_t per_elem;      // bytes of one batch element's arrays (sp, skey, ib, bbox)
     size_t sort_bytes;    // 4 key/value arrays x b
     size_t sort_temp;     // rocPRIM temporary storage
+    size_t mbox;          // mailboxes of the multi-workgroup tile form (fps_cluster.hip), all elements
+    int cluster;          // workgroups per element of that form (0: the single-workgroup kernels)
     size_t total;
 };
+
+// tpu3_debug_fps_cluster / TPU3_FPS_CLUSTER: -1 = the default policy of fb_plan, 0 = single-workgroup kernels only,
+// 2 / 4 / 8 / 16 = that many workgroups per element whenever the size allows it
+int g_cluster_force = getenv("TPU3_FPS_CLUSTER") ? atoi(getenv("TPU3_FPS_CLUSTER")) : -1;
 
 constexpr int FB_NB_MAX = 4096;     // buckets: 32 B of LDS each
 constexpr int FB_SORT_BITS = 31;    // 30 Morton bits + the dead-slot bit of ragged elements
@@ -2576,7 +2512,31 @@ bool fb_plan(int b, int n, FbPlan &p)
                                         (uint32_t *)nullptr, (size_t)n, 0, FB_SORT_BITS, (hipStream_t)0);
     }
     p.sort_temp = align256(tb);
-    p.total = p.sort_bytes + (size_t)b * p.per_elem + p.sort_temp;
+    // Several workgroups per element (fps_cluster.hip) when the launch is small: all b * G workgroups must be
+    // resident, and four such launches on four streams must still fit the 256 compute units together: b * G <= 64.
+    // G = the largest power of two within that budget, at most 8 -- or what the two-level form NEEDS beyond 256 tiles
+    // (config C5's 3744 tiles: 16).  TPU3_FPS_CLUSTER = 0 (off) / 2, 4, 8, 16 (forced): tuning hook, also
+    // tpu3_debug_fps_cluster().
+    p.cluster = 0;
+    if (p.fl) {
+        int gmin = 1;
+        while (gmin * 256 < p.ntile)
+            gmin *= 2;
+        int gg = g_cluster_force >= 0 ? g_cluster_force : 8;
+        if (g_cluster_force < 0) {
+            while (gg > 1 && (long)b * gg > 64)
+                gg /= 2;
+            if (p.ntile < 4 * gg)
+                gg = 1;                         // fewer than four tiles per member: not worth an exchange per round
+        }
+        if (gg > 1 && gg < gmin && (long)b * gmin <= 64)
+            gg = gmin;
+        if (gg >= 2 && gg >= gmin && gg <= 16 && (gg & (gg - 1)) == 0 &&
+            tpu3_fps_cluster_lds_bytes(p.ntile, gg) <= 160 * 1024)
+            p.cluster = gg;
+    }
+    p.mbox = p.fl ? align256((size_t)b * tpu3_fps_cluster_mailbox_bytes(16)) : 0;
+    p.total = p.sort_bytes + (size_t)b * p.per_elem + p.sort_temp + p.mbox;
     return true;
 }
 
@@ -2733,6 +2693,20 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         a0.prof = g_tile_stats;
         g_tile_stats = nullptr;
         hipLaunchKernelGGL(fl_init_kernel, dim3(p.ntile, b), dim3(64), 0, s, a0);
+        if (p.cluster) {
+            // several workgroups per element (fps_cluster.hip)
+            const hipEvent_t c0 = g_ev_start, c1 = g_ev_stop;
+            g_ev_start = g_ev_stop = nullptr;
+            unsigned long long *st = a0.prof;
+            a0.prof = nullptr;
+            if (c0) (void)hipEventRecord(c0, s);
+            const int rc = tpu3_fps_cluster_launch(s, b, p.cluster, &a0, sort_tmp + p.sort_temp, st);
+            if (c1) (void)hipEventRecord(c1, s);
+            if (rc)
+                return rc;
+            hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);
+            return tpu3_launch_status();
+        }
         const size_t lds = fl_lds_bytes(p.ntile, p.l3);
         void (*kern)(FbArgs) = p.l3 ? (a0.prof ? fl_main_kernel<true, true> : fl_main_kernel<false, true>)
                                     : (a0.prof ? fl_main_kernel<true, false> : fl_main_kernel<false, false>);
@@ -2788,6 +2762,35 @@ extern "C" int tpu3_debug_fps_level_stats(unsigned long long *stats)
 {
     g_level_stats = stats;
     return TPU3_OK;
+}
+
+// Tuning / test hook (not part of include/tpu3.h): workgroups per element of the tile-form FPS for the following calls
+// (-1: default policy, 0: single-workgroup kernels only, 2 / 4 / 8 / 16).  Returns the previous setting.
+extern "C" int tpu3_debug_fps_cluster(int g)
+{
+    const int old = g_cluster_force;
+    g_cluster_force = g;
+    return old;
+}
+
+// Which kernel family a call of this shape takes (the dispatch table of DESIGN section 4 as code; tests pin it):
+// 0 streaming / resident (fps.hip), 1 rb_main (rows in registers, one sample per round), 2 rl_main (lane per bucket),
+// 3 fm_main (64-point buckets), 4 fl_main two levels, 5 fl_main three levels, 6 the cluster form; *cluster = its G.
+extern "C" int tpu3_debug_fps_plan(int b, int n, int m, int *cluster)
+{
+    FbPlan p;
+    if (cluster) *cluster = 0;
+    if (!fb_plan(b, n, p))
+        return -1;
+    if (p.rb_rows && n > 1024 * 4 && m >= 256)
+        return 2;
+    if (p.rb_rows && p.rb_rows <= 7)
+        return 1;
+    if (p.fl) {
+        if (cluster) *cluster = p.cluster;
+        return p.cluster ? 6 : (p.l3 ? 5 : 4);
+    }
+    return 3;
 }
 
 extern "C" int tpu3_debug_fps_tile_stats(unsigned long long *stats)

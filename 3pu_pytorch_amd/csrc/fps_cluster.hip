@@ -1,0 +1,869 @@
+// fps_cluster.hip -- the tile-form farthest-point sampling (fps_bucket.hip, fl_main_kernel) on SEVERAL compute units
+// per point set (gfx950).
+//
+// Reference: sampling/sampling_cuda.cu:103-174 (one thread block per batch element; main.py:379-380 calls it with ONE
+// element of 239 616 points for 80 000 samples).  The single-workgroup tile form runs that call as ~2000 rounds of ~40
+// exact samples each on one compute unit; a round is tile prune -> bucket records -> the reached buckets' points ->
+// candidate list -> ranking -> clearance, two thirds of it the instruction throughput of that one unit (tools/
+// fps_tile_probe.py: 27 k of 40 k cycles in the update phases).  Here a CLUSTER of G = 2, 4, 8 or 16 workgroups shares
+// a set:
+//
+//   * tile t of the Morton-ordered slab belongs to member t mod G (a sample's ball covers CONSECUTIVE tiles: the
+//     interleaving spreads a round's visits evenly); the member keeps the maxima / arg-max positions of its tiles'
+//     buckets in ITS LDS (1/G of the table: up to 16 x 256 tiles = 4.19 M points on two levels -- config C5's 3.83 M
+//     point resample needs no third level) and is the only writer of its buckets' running distances and records;
+//   * per round every member applies the round's samples to its own tiles (phases 1 and 2 of the tile form), lists
+//     its own candidate buckets above ITS largest runner-up bound, and PUBLISHES the best <= 62 of them with its
+//     maximum and the threshold T_g its list is complete above: 8-byte {epoch, value} granules, one write-through
+//     (sc1) store each, no fence (MI355X guide, Guideline 16 form R2: the data is the flag);
+//   * every member then reads ALL G mailboxes (one wave per source, relaxed agent-scope polls until every granule
+//     carries the round's epoch) and derives the round's samples itself: T = max_g T_g, the candidates above T, the 64
+//     best by bisection, rank order, coordinates and tie keys from the immutable part of the slab, the longest clear
+//     prefix.  All members compute the same list from the same published words, so ONE exchange per round is the only
+//     inter-workgroup step -- no barrier, no leader, no broadcast;
+//   * equal maxima at the top (duplicated points) take the exact arg-max with the reference's tie rule through a
+//     second, rare exchange of (smallest tie key, slot) per member.
+//
+// Exactness is the tile form's: any threshold >= R* = max of all runner-up bounds is valid; T >= R*
+// because every T_g >= the member's own bound; the published lists are complete above T_g <= T; rank order is
+// (maximum descending, tie key ascending), independent of list order.  Bit-identical indices and final `temp`.
+//
+// Residency: the members of a cluster spin on each other, so all b * G workgroups of a launch must be resident.  The
+// dispatcher admits them in order and every other kernel on the device terminates, so a lone cluster launch of <= 256
+// workgroups always gets there; the host keeps b * G <= 64 so that four such launches on four streams still fit the 256
+// compute units together.  Every poll is bounded: a member that gives up raises the launch's fault word (`stats[4]`,
+// the last mailbox word) and all members leave; the host side reports it (tpu3_fps_cluster_faults).
+#include "fps_bucket.h"
+
+namespace {
+
+constexpr int FC_CAP = 64;              // samples per round
+constexpr int FC_LCAP = 62;             // candidates a member publishes per round: 4 header + 2 x 62 granules = 2 sweeps
+                                        // (31 on sixteen members: the cluster's list holds FC_LIST entries)
+constexpr int FC_LIST = 512;            // candidates a member may list per round
+constexpr int FC_WORK = 2048;           // work list entries (reached buckets of a round, one member)
+constexpr int FC_DENSE = 16;            // a tile with this many reached buckets is updated on the spot
+constexpr int FC_P2 = 3;                // phase-2 steps of a wave whose points are fetched together
+constexpr int FC_GMAX = 16;
+constexpr int FC_MB = 128;              // granules per mailbox
+constexpr unsigned FC_SPIN_MAX = 1u << 23;      // polls before a member gives up (~seconds)
+
+typedef unsigned long long u64;
+
+// granule traffic: relaxed agent-scope 8-byte accesses = global_{store,load}_dwordx2 sc1 (write-through / L1 bypass)
+__device__ __forceinline__ void fc_put(u64 *p, unsigned epoch, uint32_t v)
+{
+    __hip_atomic_store(p, ((u64)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 fc_get(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// faulted workgroups since the last reset (tpu3_fps_cluster_faults)
+__device__ u64 fc_fault_count;
+
+struct FcShared {
+    float pick[2][FC_CAP][4];           // the round's samples in rank order: x, y, z, distance
+    uint32_t pkey[2][FC_CAP];
+    int mrow[FC_CAP];                   // ranking: the selected maxima
+    uint32_t msel[FC_CAP];              //          their slots (point index in the Morton slab)
+    uint32_t kt[FC_CAP];                //          their tie keys (ties only)
+    uint32_t cand[FC_LIST * 2];         // this member's candidates: (maximum, slot)
+    uint32_t dl[FC_LIST * 2];           // what ALL members published, in arrival order (the pollers deposit while wave 0
+                                        // may still be reading the local list: two buffers)
+    uint32_t lsel[FC_LCAP * 2 + 4];     // the ones it publishes
+    int mcnt[FC_GMAX], mthr[FC_GMAX], mbest[FC_GMAX];
+    uint32_t tmask[512];                // prune: per local tile the samples of the round that may reach it (lo, hi)
+    u64 tmc[FC_GMAX];                   // tie exchange: (key << 32 | slot) per member
+    u64 tiekey;
+    int npick[2];
+    int ncand, nwork, jclear, ndense;
+    int lcount, lthr;
+    int gbest;
+    int fail;
+    u64 stat[8];
+};
+static_assert(offsetof(FcShared, mrow) % 16 == 0 && offsetof(FcShared, cand) % 16 == 0 && offsetof(FcShared, dl) % 16 == 0,
+              "vector reads of the lists");
+
+constexpr size_t fc_mbox_words(int g) { return (size_t)2 * g * FC_MB + (size_t)2 * g * 2 + 8; }
+
+constexpr size_t fc_lds_bytes(int ntile, int g)
+{
+    return ((((size_t)((ntile + g - 1) / g) * 64 * 5) + 15) & ~(size_t)15) + 512 * 4 + (size_t)FC_WORK * 12 +
+           sizeof(FcShared) + 64;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *mbox0, u64 *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = 1 << lg;
+    const int lcap = G <= 8 ? FC_LCAP : FC_LIST / G - 1;
+    const int cl = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
+    const FbArgs a = fb_elem(a0, cl);
+    if (a.n <= 0 || a.m <= 0)
+        return;                                             // (the whole cluster leaves)
+    const int ntile = (a.n + FL_TP - 1) / FL_TP;            // live tiles of this element
+    const int nltmax = (a0.ntile + G - 1) >> lg;            // LDS stride: local tiles of a member at most
+    const int nlt = (ntile - g + G - 1) >> lg;              // live local tiles of THIS member (0 for tiny sets)
+    int *bmax = (int *)smem;                                // [nltmax * 64] maxima of this member's buckets
+    uint8_t *barg = (uint8_t *)(bmax + nltmax * 64);        // [nltmax * 64] position of a bucket's best point
+    int *tmx = (int *)(smem + (((size_t)nltmax * 64 * 5 + 15) & ~(size_t)15));      // [256] tile maxima
+    int *trn = tmx + 256;                                   // [256] tile runner-up bounds
+    uint32_t *work = (uint32_t *)(trn + 256);               // [FC_WORK][3]
+    FcShared &sh = *(FcShared *)(work + FC_WORK * 3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = a.lb;
+    float4 *__restrict__ TP = a.sp;
+    const uint32_t *__restrict__ TK = a.skey;
+    u64 *mb = mbox0 + (size_t)cl * fc_mbox_words(G);        // this cluster's mailboxes: [parity][member][FC_MB]
+    u64 *tb = mb + (size_t)2 * G * FC_MB;                   // tie exchange: [parity][member][2]
+    u64 *faultw = tb + (size_t)2 * G * 2;
+
+    // local bucket index <-> global bucket id (tile t = lt * G + g)
+    auto gbucket = [&](int lbk) __attribute__((always_inline)) { return ((((lbk >> 6) << lg) | g) << 6) | (lbk & 63); };
+    auto lbucket = [&](int gb) __attribute__((always_inline)) { return (((gb >> 6) >> lg) << 6) | (gb & 63); };
+
+    for (int i = tid; i < nlt * 64; i += 1024) {
+        const int gb = gbucket(i);
+        bmax[i] = a.bm0[gb];
+        barg[i] = a.ba0[gb];
+    }
+    for (int i = tid; i < 256; i += 1024) {
+        const int t = (i << lg) | g;
+        tmx[i] = i < nlt ? __float_as_int(a.tt[t * 8 + 6]) : (int)0x80000000;
+        trn[i] = i < nlt ? __float_as_int(a.tt[t * 8 + 7]) : (int)0x80000000;
+    }
+    // A member's tiles are OWNED (visited, listed) by lane l < 16 of wave w: local tile l * 16 + w.
+    const int ltq = lane * 16 + wave;
+    const bool tvalid = lane < 16 && ltq < nlt;
+    // The prune step tests (tile, sample) pairs densely instead: the tiles in chunks of 64, a lane per tile, wave w
+    // on chunk w mod nch for the samples w / nch, w / nch + nwpc, ... (a member of a cluster owns 30 - 234 tiles:
+    // with a quad per tile 8 of a wave's 64 lanes had anything to test, and the test loop was 7 k cycles of a round)
+    const int nch = (nlt + 63) >> 6;
+    const int nwpc = nch > 0 ? 16 / nch : 0;                 // waves per chunk
+    const bool pwave = nch > 0 && wave < nch * nwpc;
+    const int ptile = pwave ? (wave % nch) * 64 + lane : 0;
+    const bool pvalid = pwave && ptile < nlt;
+    float pbx[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        pbx[c] = pvalid ? a.tt[(((ptile << lg) | g)) * 8 + c] : __builtin_inff();
+    for (int i = tid; i < 512; i += 1024)
+        sh.tmask[i] = 0u;
+    if (tid == 0) {
+        sh.ncand = 0;
+        sh.nwork = 0;
+        sh.ndense = 0;
+        sh.fail = 0;
+        sh.npick[0] = sh.npick[1] = 0;
+        if (g == 0)
+            a.idx[0] = 0;
+        sh.pick[1][0][0] = a.xyz[0]; sh.pick[1][0][1] = a.xyz[1]; sh.pick[1][0][2] = a.xyz[2];
+        sh.pick[1][0][3] = 0.f;
+    }
+    if (tid < 8)
+        sh.stat[tid] = 0;
+    __syncthreads();
+    if (a.m <= 1)
+        return;                                     // the reference's loop body never runs: temp untouched
+
+    // pair (i < l) number `lane` of the l-major enumeration (clearance test, first pass)
+    int pair_l = (int)((1.f + sqrtf(1.f + 8.f * (float)lane)) * 0.5f);
+    pair_l -= pair_l * (pair_l - 1) / 2 > lane ? 1 : 0;
+    pair_l += (pair_l + 1) * pair_l / 2 <= lane ? 1 : 0;
+    const int pair_i = lane - pair_l * (pair_l - 1) / 2;
+
+    // PROF: wave 0's cycles per phase -- apply phase 1 (+ barrier), phase 2 (+ barrier), candidate collection, local
+    // selection + publish, poll (+ barrier), merge / rank (+ barrier), clearance (+ barrier); listed / merged counts
+    u64 pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
+    auto mark = [&](int k) __attribute__((always_inline)) {
+        if (PROF) {
+            const u64 now = __builtin_amdgcn_s_memtime();
+            pc[k] += now - pt;
+            pt = now;
+        }
+    };
+
+    // ---- one bucket (the lane's): fold the samples of `sm0` into its 16 distances, re-derive its record ----------
+    auto update_bucket = [&](bool act, int gb, int lbk, unsigned long long sm0, int cur, int &best, int &run)
+        __attribute__((always_inline)) {
+        float4 *__restrict__ base = TP + (size_t)gb * FL_R;
+        int arg = 0;
+        best = (int)0x80000000; run = (int)0x80000000;
+#pragma unroll 1
+        for (int h = 0; h < FL_R; h += 8) {
+            float4 pt[8];
+            float nt[8];
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    pt[j] = base[h + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                nt[j] = act ? pt[j].w : 0.f;
+            for (unsigned long long sm = sm0; sm; sm &= sm - 1) {
+                const float4 p = *(const float4 *)sh.pick[cur][__builtin_ctzll(sm)];
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tbits = __float_as_int(nt[j]);
+                    asm("v_med3_i32 %0, %1, %2, %0" : "+v"(run) : "v"(best), "v"(tbits));
+                    arg = tbits > best ? h + j : arg;          // (first of equal maxima; ties are settled below)
+                    best = max(best, tbits);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (nt[j] != pt[j].w)
+                        ((float *)(base + h + j))[3] = nt[j];
+            }
+        }
+        // equal maxima inside a bucket (duplicated points): the smallest tie key wins
+        if (__ballot(act && run == best && best >= 0)) {
+            if (act && run == best && best >= 0) {
+                uint32_t bk = 0xFFFFFFFFu;
+                for (int j = 0; j < FL_R; ++j) {
+                    const uint32_t kj = TK[(size_t)gb * FL_R + j];
+                    const bool take = __float_as_int(base[j].w) == best && kj < bk;
+                    bk = take ? kj : bk;
+                    arg = take ? j : arg;
+                }
+            }
+        }
+        if (act) {
+            bmax[lbk] = best;
+            barg[lbk] = (uint8_t)arg;
+            ((uint32_t *)(a.rec + gb))[3] = (uint32_t)run;
+        }
+    };
+
+    // ---- fold the first nj samples of pick[cur] into every bucket of THIS member they reach -------------------
+    auto apply = [&](int nj, int cur) __attribute__((always_inline)) {
+        if (pwave) {
+            const float tmf = pvalid ? __int_as_float(tmx[ptile]) : -1.f;          // (a box distance is never < -1)
+            uint32_t mlo = 0, mhi = 0;
+            for (int i = wave / nch; i < nj; i += nwpc) {                           // (wave-uniform)
+                const float4 p = *(const float4 *)sh.pick[cur][i];
+                const bool hit = fb_dbox(p.x, p.y, p.z, pbx[0], pbx[1], pbx[2], pbx[3], pbx[4], pbx[5]) < tmf;
+                if (i < 32)
+                    mlo |= hit ? (1u << i) : 0u;
+                else
+                    mhi |= hit ? (1u << (i - 32)) : 0u;
+            }
+            if (mlo)
+                atomicOr(&sh.tmask[2 * ptile], mlo);
+            if (mhi)
+                atomicOr(&sh.tmask[2 * ptile + 1], mhi);
+        }
+        __syncthreads();
+        uint32_t mlo = 0, mhi = 0;
+        if (tvalid) {
+            mlo = sh.tmask[2 * ltq];
+            mhi = sh.tmask[2 * ltq + 1];
+            if (mlo | mhi)
+                *(uint2 *)(sh.tmask + 2 * ltq) = make_uint2(0u, 0u);
+        }
+        // one tile (local index lt): which of its 64 buckets do the samples of `smt` reach?
+        auto visit_tile = [&](int lt, unsigned long long smt) __attribute__((always_inline)) {
+            const int lbk = lt * 64 + lane;
+            const int gb = gbucket(lbk);
+            const uint4 rc = a.rec[gb];
+            const int bm = bmax[lbk];
+            const float lx = fb_half_lo(rc.x), ly = fb_half_hi(rc.x), lz = fb_half_lo(rc.y);
+            const float hx = fb_half_hi(rc.y), hy = fb_half_lo(rc.z), hz = fb_half_hi(rc.z);
+            unsigned long long mine = 0;            // the samples that reach THIS lane's bucket
+            for (unsigned long long sm = smt; sm; sm &= sm - 1) {
+                const int i = __builtin_ctzll(sm);
+                const float4 p = *(const float4 *)sh.pick[cur][i];
+                mine |= fb_dbox(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz) < __int_as_float(bm) ? (1ull << i) : 0ull;
+            }
+            const bool reached = mine != 0;
+            const unsigned long long rm = __ballot(reached);
+            if (!rm)
+                return;
+            const int nreach = __builtin_popcountll(rm);
+            int base = 0;
+            bool dense = nreach >= FC_DENSE;
+            if (!dense) {
+                if (lane == 0)
+                    base = atomicAdd(&sh.nwork, nreach);
+                base = __builtin_amdgcn_readfirstlane(base);
+                dense = base + nreach > FC_WORK;        // (list full: on the spot; the reserved slots are voided)
+            }
+            if (dense) {
+                if (nreach < FC_DENSE && reached) {
+                    const int pos = base + __builtin_popcountll(rm & ((1ull << lane) - 1ull));
+                    if (pos < FC_WORK)
+                        work[3 * pos] = 0xFFFFFFFFu;
+                }
+                int best, run;
+                update_bucket(reached, gb, lbk, smt, cur, best, run);
+                int tm = reached ? best : bm, tr = reached ? run : (int)rc.w;
+                tpu3_wave_max_i32_fast_x2(tm, tr);
+                if (lane == 0) {
+                    tmx[lt] = tm;
+                    trn[lt] = tr;
+                }
+                return;
+            }
+            // the tile's maxima over the buckets NOT reached; phase 2 adds the reached ones' (atomic max)
+            int um = reached ? (int)0x80000000 : bm, ur = reached ? (int)0x80000000 : (int)rc.w;
+            tpu3_wave_max_i32_fast_x2(um, ur);
+            if (lane == 0) {
+                tmx[lt] = um;
+                trn[lt] = ur;
+            }
+            if (reached) {
+                uint32_t *e = work + 3 * (base + __builtin_popcountll(rm & ((1ull << lane) - 1ull)));
+                e[0] = (uint32_t)gb; e[1] = (uint32_t)mine; e[2] = (uint32_t)(mine >> 32);
+            }
+        };
+        for (unsigned long long touched = __ballot((mlo | mhi) != 0); touched; touched &= touched - 1) {
+            const int L = __builtin_ctzll(touched);
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
+            visit_tile(L * 16 + wave, ((unsigned long long)shi << 32) | slo);
+        }
+        __syncthreads();
+        mark(0);
+        // phase 2: a DPP row of 16 lanes per listed bucket, a lane per point; four buckets per wave step, the steps
+        // dealt over the 16 waves
+        const int E = min(sh.nwork, FC_WORK);
+        const int row = lane >> 4, col = lane & 15;
+        for (int g0 = wave * 4; g0 < E; g0 += 64 * FC_P2) {
+            float4 ptv[FC_P2];
+            int bv[FC_P2];
+#pragma unroll
+            for (int k = 0; k < FC_P2; ++k) {
+                const int ee = g0 + 64 * k + row;
+                bv[k] = (int)work[3 * (ee < E ? ee : 0)];
+                ptv[k] = TP[(size_t)(bv[k] >= 0 ? bv[k] : 0) * FL_R + col];
+            }
+#pragma unroll
+            for (int k = 0; k < FC_P2; ++k) {
+                const int e0 = g0 + 64 * k;
+                if (e0 >= E)
+                    break;
+                const bool inl = e0 + row < E;
+                const uint32_t *e = work + 3 * (inl ? e0 + row : 0);
+                const bool act = inl && bv[k] >= 0;                 // (a voided slot: its tile was updated on the spot)
+                const int gb = act ? bv[k] : 0;
+                unsigned long long mine = act ? (((unsigned long long)e[2] << 32) | e[1]) : 0ull;
+                float4 *__restrict__ pp = TP + (size_t)gb * FL_R + col;
+                const float4 pt = ptv[k];
+                float nt = pt.w;
+                while (__ballot(mine != 0)) {           // every row walks ITS bucket's samples
+                    const bool go = mine != 0;
+                    const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
+                    mine &= mine - 1;
+                    const float d = fminf(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
+                    nt = go ? d : nt;
+                }
+                const int tbits = act ? __float_as_int(nt) : (int)0x80000000;
+                const int best = tpu3_row_max_i32_fast(tbits);
+                // the winner: the only lane at the maximum, or -- duplicated points -- the one with the smallest tie key
+                unsigned long long tie = __ballot(act && tbits == best);
+                const unsigned long long rowm = 0xFFFFull << (row * 16);
+                bool single = true;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    single &= __builtin_popcountll(tie & (0xFFFFull << (rr * 16))) <= 1;
+                if (!single) {
+                    const uint32_t kj = act && tbits == best ? TK[(size_t)gb * FL_R + col] : 0xFFFFFFFFu;
+                    const uint32_t km = tpu3_row_min_u32(kj);
+                    tie = __ballot(act && tbits == best && kj == km);
+                }
+                const bool winner = act && ((tie >> lane) & 1ull) != 0 && (tie & rowm & ((1ull << lane) - 1ull)) == 0;
+                const int run = tpu3_row_max_i32_fast(winner || !act ? (int)0x80000000 : tbits);
+                if (act && nt != pt.w)
+                    ((float *)pp)[3] = nt;
+                if (winner) {
+                    const int lbk = lbucket(gb);
+                    bmax[lbk] = best;
+                    barg[lbk] = (uint8_t)col;
+                    ((uint32_t *)(a.rec + gb))[3] = (uint32_t)run;
+                    atomicMax(&tmx[lbk >> 6], best);
+                    atomicMax(&trn[lbk >> 6], run);
+                }
+            }
+        }
+        __syncthreads();
+        mark(1);
+        if (tid == 0)
+            sh.nwork = 0;
+    };
+
+    // the buckets of this wave's tiles in `ul` (a ballot over the owner lanes): body(local bucket of this lane,
+    // its maximum, its best point's position) per tile
+    auto for_tiles = [&](unsigned long long ul, auto body) __attribute__((always_inline)) {
+        for (; ul; ul &= ul - 1) {
+            const int lbk = ((int)__builtin_ctzll(ul) * 16 + wave) * 64 + lane;
+            body(lbk, bmax[lbk], (int)barg[lbk]);
+        }
+    };
+
+    int J = 1, r = 1;
+    unsigned tepoch = 0;                            // tie exchanges so far
+    unsigned long long n_tie = 0, n_sweep = 0;
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        const unsigned epoch = (unsigned)round + 1u;
+        if (PROF) pt = __builtin_amdgcn_s_memtime();
+        apply(J, par ^ 1);
+        // ---- this member's candidates ------------------------------------------------------------------------
+        int lbest, lrstar;
+        {
+            int vm = (int)0x80000000, vr = (int)0x80000000;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vm = max(vm, tmx[i * 64 + lane]);
+                vr = max(vr, trn[i * 64 + lane]);
+            }
+            tpu3_wave_max_i32_fast_x2(vm, vr);
+            lbest = vm; lrstar = vr;
+        }
+        const int tmax = tvalid ? tmx[ltq] : (int)0x80000000;
+        // every bucket above `thr` (any threshold >= this member's largest runner-up bound is valid); when more
+        // than the list holds qualify the threshold is raised; when even the top value alone is shared by more
+        // buckets than the list holds (duplicated points) nothing is listed and T_g = the top value itself
+        int thr = lrstar, total = 0;
+        bool none = lbest <= lrstar;
+        while (!none) {
+            const unsigned long long tl = __ballot(tvalid && tmax > thr);
+            for_tiles(tl, [&](int lbk, int bm, int ba) __attribute__((always_inline)) {
+                const bool c = bm > thr;
+                const unsigned long long cm = __ballot(c);
+                if (!cm)
+                    return;
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&sh.ncand, (int)__builtin_popcountll(cm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                if (c && pos < FC_LIST) {
+                    sh.cand[pos * 2] = (uint32_t)bm;
+                    sh.cand[pos * 2 + 1] = ((uint32_t)gbucket(lbk) << 4) | (uint32_t)ba;
+                }
+            });
+            __syncthreads();
+            total = sh.ncand;
+            if (total <= FC_LIST)
+                break;
+            __syncthreads();
+            if (tid == 0)
+                sh.ncand = 0;
+            if (lbest - thr <= 1) {
+                none = true;
+                total = 0;
+            } else {
+                thr += (lbest - thr) >> 1;
+            }
+            __syncthreads();
+        }
+        if (none) {
+            thr = max(lrstar, lbest);
+            total = 0;
+        }
+        mark(2);
+        if (PROF) pc[7] += total;
+        // wave 0: the FC_LCAP best (bisection over the values it holds in registers), published with the header
+        if (wave == 0) {
+            int em[FC_LIST / 64];
+            uint32_t eb[FC_LIST / 64];
+#pragma unroll
+            for (int u = 0; u < FC_LIST / 64; ++u) {
+                const int i = u * 64 + lane;
+                em[u] = (int)0x80000000;
+                eb[u] = 0;
+                if (u * 64 < total) {
+                    em[u] = i < total ? (int)sh.cand[2 * i] : (int)0x80000000;
+                    eb[u] = sh.cand[2 * (i < total ? i : 0) + 1];
+                }
+            }
+            int thr2 = thr, nsel = total;
+            if (total > lcap) {
+                int lo = thr, hi = lbest, chi = 0;                // count(> lo) > lcap >= count(> hi) = chi
+                for (int it = 0; it < 32 && hi - lo > 1; ++it) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int u = 0; u < FC_LIST / 64; ++u)
+                        if (u * 64 < total)
+                            c += __builtin_popcountll(__ballot(em[u] > mid));
+                    if (c > lcap) {
+                        lo = mid;
+                    } else {
+                        hi = mid; chi = c;
+                        if (c >= lcap - lcap / 8)
+                            break;
+                    }
+                }
+                thr2 = hi; nsel = chi;
+            }
+            int base = 0;
+#pragma unroll
+            for (int u = 0; u < FC_LIST / 64; ++u) {
+                if (u * 64 >= total)
+                    break;
+                const bool sel = em[u] > thr2;
+                const unsigned long long smk = __ballot(sel);
+                if (sel) {
+                    const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
+                    sh.lsel[2 * pos] = (uint32_t)em[u];
+                    sh.lsel[2 * pos + 1] = eb[u];
+                }
+                base += __builtin_popcountll(smk);
+            }
+            // (the LDS list above is read back by other lanes of this wave only: program order within a wave)
+            u64 *box = mb + ((size_t)par * G + g) * FC_MB;
+            const int need = 4 + 2 * nsel;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int i = s * 64 + lane;
+                uint32_t v = 0;
+                if (i == 0) v = (uint32_t)lbest;
+                else if (i == 1) v = (uint32_t)thr2;
+                else if (i == 2) v = (uint32_t)nsel;
+                else if (i >= 4) v = sh.lsel[(i - 4) < 2 * nsel ? i - 4 : 0];
+                if (i < need)
+                    fc_put(box + i, epoch, v);
+            }
+            if (lane == 0)
+                sh.ncand = 0;
+        }
+        mark(3);
+        // ---- what every member published: one wave per source polls until each granule it needs carries the epoch
+        if (wave < G) {
+            const u64 *src = mb + ((size_t)par * G + wave) * FC_MB;
+            unsigned spins = 0;
+            u64 x0, x1;
+            int cnt = 0;
+            for (;;) {
+                x0 = fc_get(src + lane);
+                x1 = fc_get(src + 64 + lane);
+                const bool t0 = (unsigned)(x0 >> 32) == epoch, t1 = (unsigned)(x1 >> 32) == epoch;
+                const bool hdr = (__ballot(t0) & 7ull) == 7ull;
+                cnt = hdr ? __builtin_amdgcn_readlane((int)(uint32_t)x0, 2) : 0;
+                const int need = 4 + 2 * cnt;
+                if (hdr && !__ballot((lane < need && !t0) || (64 + lane < need && !t1)))
+                    break;
+                if (++spins > FC_SPIN_MAX || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    if (lane == 0)
+                        sh.fail = 1;
+                    cnt = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (wave == 0)
+                n_sweep += spins + 1;
+            if (lane == 0) {
+                sh.mbest[wave] = (int)(uint32_t)x0;
+                sh.mcnt[wave] = cnt;
+            }
+            if (lane == 1)
+                sh.mthr[wave] = (int)(uint32_t)x0;
+            // the entries go straight onto the cluster's list (any order: the ranking does not depend on it), unfiltered
+            // -- T0 is known only when all headers are in
+            int base = 0;
+            if (lane == 0 && cnt)
+                base = atomicAdd(&sh.ndense, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (lane >= 4 && lane < 4 + 2 * cnt)
+                sh.dl[2 * base + lane - 4] = (uint32_t)x0;
+            if (64 + lane < 4 + 2 * cnt)
+                sh.dl[2 * base + 60 + lane] = (uint32_t)x1;
+        }
+        __syncthreads();
+        mark(4);
+        if (sh.fail)
+            break;
+        // ---- the round's samples: every member derives the same list ----------------------------------------------
+        const int left = a.m - r;
+        uint32_t okey = 0;
+        if (wave == 0) {
+            int gb_ = lane < G ? sh.mbest[lane] : (int)0x80000000;
+            int t0_ = lane < G ? sh.mthr[lane] : (int)0x80000000;
+            tpu3_wave_max_i32_fast_x2(gb_, t0_);
+            const int gbest = gb_, T0 = t0_;
+            // the cluster's list (what the pollers deposited), filtered by T0: with the members' local bounds below the
+            // cluster's, two thirds of what they publish does not qualify
+            constexpr int NE = FC_LIST / 64;
+            const uint32_t *dl = sh.dl;
+            const int tot = sh.ndense;
+            int em[NE];
+            uint32_t eb[NE];
+            int total2 = 0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                em[u] = (int)0x80000000;
+                eb[u] = 0;
+                if (u * 64 < tot) {
+                    const int i = u * 64 + lane;
+                    const uint2 e = *(const uint2 *)(dl + 2 * (i < tot ? i : 0));
+                    em[u] = i < tot && (int)e.x > T0 ? (int)e.x : (int)0x80000000;
+                    eb[u] = e.y;
+                    total2 += __builtin_popcountll(__ballot(em[u] > T0));
+                }
+            }
+            int thr2 = T0, nsel = total2;
+            if (total2 > FC_CAP) {
+                int lo = T0, hi = gbest, chi = 0;                // count(> lo) > FC_CAP >= count(> hi) = chi
+                for (int it = 0; it < 32 && hi - lo > 1; ++it) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int u = 0; u < NE; ++u)
+                        if (u * 64 < tot)
+                            c += __builtin_popcountll(__ballot(em[u] > mid));
+                    if (c > FC_CAP) {
+                        lo = mid;
+                    } else {
+                        hi = mid; chi = c;
+                        if (c >= FC_CAP - FC_CAP / 16)
+                            break;
+                    }
+                }
+                thr2 = hi; nsel = chi;
+            }
+            // (nsel == 0: no bucket beats every runner-up bound, or more than FC_CAP share the top value -- duplicated
+            // points; the exact arg-max with the tie rule below settles it)
+            int base = 0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                if (u * 64 >= tot || nsel == 0)
+                    break;
+                const bool sel = em[u] > thr2;
+                const unsigned long long smk = __ballot(sel);
+                if (sel) {
+                    const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
+                    sh.mrow[pos] = em[u];
+                    sh.msel[pos] = eb[u];
+                }
+                base += __builtin_popcountll(smk);
+            }
+            const bool live = lane < nsel;
+            const int cM = live ? sh.mrow[lane] : (int)0x80000000;
+            const uint32_t cB = sh.msel[live ? lane : 0];
+            // ONE round trip for the coordinates and keys of the whole list (the IMMUTABLE words of the slab: any
+            // member may read them; the running distance of a foreign bucket is taken from its published maximum)
+            const float4 sp4 = TP[live ? cB : 0];
+            const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
+            if (!live)
+                sh.mrow[lane] = (int)0x80000000;
+            int rank = 0;
+            bool tie = false;
+            for (int c0 = 0; c0 < nsel; c0 += 16) {
+                int4 mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    mv[u] = *(const int4 *)(sh.mrow + c0 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m4[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        rank += m4[v] > cM ? 1 : 0;
+                        tie |= m4[v] == cM && c0 + 4 * u + v != lane;
+                    }
+                }
+            }
+            if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
+                sh.kt[lane] = cK;
+                rank = 0;
+                for (int c0 = 0; c0 < nsel; c0 += 8) {
+                    const int4 m0 = *(const int4 *)(sh.mrow + c0), m1 = *(const int4 *)(sh.mrow + c0 + 4);
+                    const uint4 k0 = *(const uint4 *)(sh.kt + c0), k1 = *(const uint4 *)(sh.kt + c0 + 4);
+                    const int m8[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                    const uint32_t k8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        rank += (m8[v] > cM || (m8[v] == cM && k8[v] < cK)) ? 1 : 0;
+                }
+            }
+            if (live) {
+                *(float4 *)sh.pick[par][rank] = make_float4(sp4.x, sp4.y, sp4.z, __int_as_float(cM));
+                sh.pkey[par][rank] = cK;
+            }
+            okey = sh.pkey[par][lane < nsel ? lane : 0];
+            if (lane == 0) {
+                const int jm = nsel < left ? nsel : left;
+                sh.npick[par] = jm;
+                sh.jclear = jm;
+                sh.gbest = gbest;
+                sh.ndense = 0;
+            }
+        }
+        __syncthreads();
+        mark(5);
+        int jmax = sh.npick[par];
+        if (jmax == 0) {
+            // one sample by the exact arg-max with the tie rule: the smallest tie key among ALL buckets at the top
+            // value -- every member finds its own, a second exchange finds the cluster's
+            ++n_tie;
+            const int gbest = sh.gbest;
+            const unsigned te = ++tepoch;
+            if (tid == 0)
+                sh.tiekey = ~0ull;
+            __syncthreads();
+            const unsigned long long t2 = __ballot(tvalid && tmax == gbest);
+            for_tiles(t2, [&](int lbk, int bm, int ba) __attribute__((always_inline)) {
+                if (bm == gbest) {
+                    const uint32_t w = ((uint32_t)gbucket(lbk) << 4) | (uint32_t)ba;
+                    atomicMin(&sh.tiekey, ((u64)TK[w] << 32) | w);
+                }
+            });
+            __syncthreads();
+            if (wave == 0 && lane < 2) {
+                const u64 k = sh.tiekey;
+                fc_put(tb + ((size_t)(te & 1) * G + g) * 2 + lane, te, lane == 0 ? (uint32_t)(k >> 32) : (uint32_t)k);
+            }
+            if (wave < G) {
+                const u64 *src = tb + ((size_t)(te & 1) * G + wave) * 2;
+                unsigned spins = 0;
+                u64 x = 0;
+                for (;;) {
+                    x = fc_get(src + (lane & 1));
+                    if ((__ballot((unsigned)(x >> 32) == te) & 3ull) == 3ull)
+                        break;
+                    if (++spins > FC_SPIN_MAX || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        if (lane == 0)
+                            sh.fail = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 0);
+                const uint32_t slotw = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 1);
+                if (lane == 0)
+                    sh.tmc[wave] = ((u64)key << 32) | slotw;
+            }
+            __syncthreads();
+            if (sh.fail)
+                break;
+            if (wave == 0) {
+                u64 best = ~0ull;
+                for (int w = 0; w < G; ++w)
+                    best = min(best, sh.tmc[w]);
+                const uint32_t w = (uint32_t)best;
+                if (lane == 0) {
+                    const float4 p = TP[w];
+                    *(float4 *)sh.pick[par][0] = make_float4(p.x, p.y, p.z, __int_as_float(gbest));
+                    sh.pkey[par][0] = (uint32_t)(best >> 32);
+                    sh.npick[par] = 1;
+                    sh.jclear = 1;
+                }
+                okey = (uint32_t)(best >> 32);
+            }
+            __syncthreads();
+            jmax = 1;
+        }
+        // longest prefix in which no member lies inside the update ball of an earlier member: the smallest l with
+        // d(sample i, sample l) < M_l for some i < l -- all pairs (i < l), 64 per pass in l-major order, the passes
+        // dealt over the waves
+        {
+            const int npair = jmax * (jmax - 1) / 2;
+            for (int t0 = wave * 64; t0 < npair; t0 += 1024) {
+                int pl = pair_l, pi = pair_i;
+                if (t0) {
+                    const int t = t0 + lane;
+                    pl = (int)((1.f + sqrtf(1.f + 8.f * (float)t)) * 0.5f);
+                    pl -= pl * (pl - 1) / 2 > t ? 1 : 0;
+                    pl += (pl + 1) * pl / 2 <= t ? 1 : 0;
+                    pi = t - pl * (pl - 1) / 2;
+                }
+                const bool ok = pl < jmax;
+                const float4 L4 = *(const float4 *)sh.pick[par][ok ? pl : 0];
+                const float4 I4 = *(const float4 *)sh.pick[par][ok ? pi : 0];
+                const float d = tpu3_sqdist3(L4.x - I4.x, L4.y - I4.y, L4.z - I4.z);
+                const unsigned long long hit = __ballot(ok && d < L4.w);
+                if (hit) {
+                    const int first = __builtin_amdgcn_readlane(pl, (int)__builtin_ctzll(hit));
+                    if (lane == 0)
+                        atomicMin(&sh.jclear, first);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        mark(6);
+        J = sh.jclear;
+        if (wave == 0 && g == 0 && lane < J)
+            a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
+        r += J;
+        if (r >= a.m) {
+            if (J > 1)
+                apply(J - 1, par);                  // every sample but the last one updates `temp`
+            if (stats && tid == 0 && g == 0 && cl == 0) {
+                stats[0] = (u64)round + 1; stats[1] = (u64)r - 1; stats[2] = n_tie; stats[3] = n_sweep;
+                if (PROF)
+                    for (int k = 0; k < 8; ++k)
+                        stats[8 + k] = pc[k];
+            }
+            return;
+        }
+    }
+    // a poll gave up (a member of this cluster never became resident, or died): tell the host
+    if (tid == 0) {
+        __hip_atomic_store(faultw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&fc_fault_count, 1ull);
+        if (stats)
+            atomicAdd(stats + 4, 1ull);
+    }
+}
+
+} // namespace
+
+size_t tpu3_fps_cluster_mailbox_bytes(int g)
+{
+    return fc_mbox_words(g) * sizeof(u64);
+}
+
+size_t tpu3_fps_cluster_lds_bytes(int ntile, int g)
+{
+    return fc_lds_bytes(ntile, g);
+}
+
+int tpu3_fps_cluster_launch(hipStream_t s, int b, int g, const void *fb_args, void *mbox, unsigned long long *stats)
+{
+    const FbArgs &a0 = *(const FbArgs *)fb_args;
+    int lg = 0;
+    while ((1 << lg) < g)
+        ++lg;
+    if ((1 << lg) != g || g < 2 || g > FC_GMAX || (a0.ntile + g - 1) / g > 256)
+        return TPU3_EINVAL;
+    const size_t lds = fc_lds_bytes(a0.ntile, g);
+    if (lds > 160 * 1024)
+        return TPU3_ELIMIT;
+    hipError_t e = hipMemsetAsync(mbox, 0, (size_t)b * tpu3_fps_cluster_mailbox_bytes(g), s);
+    if (e != hipSuccess)
+        return (int)e;
+    // (the per-phase cycle counters only when somebody asked for the statistics)
+    void (*kern)(FbArgs, int, u64 *, u64 *) = stats ? fc_main_kernel<true> : fc_main_kernel<false>;
+    e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+        return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)b * g), dim3(1024), lds, s, a0, lg, (u64 *)mbox, (u64 *)stats);
+    return tpu3_launch_status();
+}
+
+extern "C" long tpu3_fps_cluster_faults(int reset)
+{
+    u64 v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fc_fault_count), sizeof(v)) != hipSuccess)
+        return -1;
+    if (reset && v) {
+        const u64 z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fc_fault_count), &z, sizeof(z));
+    }
+    return (long)v;
+}

@@ -471,6 +471,23 @@ int tpu3_debug_knn_tiles_stats(unsigned *words);
 int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,
                                   int32_t *idx, void *workspace, size_t workspace_bytes,
                                   unsigned long long *prof);
+/* tpu3_debug_fps_cluster: workgroups per point set of the tile-form FPS for the calls that follow: -1 = the default
+ * policy (several compute units per set when the launch is small: b * G <= 64, G <= 8, 16 for sets beyond 262 144
+ * points), 0 = single-workgroup kernels only, 2 / 4 / 8 / 16 = forced wherever the size allows.  Returns the previous
+ * setting (also: environment TPU3_FPS_CLUSTER).  With the cluster form, tpu3_debug_fps_tile_stats receives rounds,
+ * samples, tie exchanges, wave 0's poll sweeps and the launch's fault count in stats[0..4].
+ * tpu3_debug_fps_plan: which FPS kernel family a (b, n, m) call takes -- 0 register-resident / streaming (n <= 25 600
+ * with few samples), 1 rows in registers with one sample per round, 2 a lane per bucket with several samples per
+ * round (per-level resampling), 3 64-point buckets in memory, 4 / 5 the tile form on two / three levels, 6 the tile
+ * form on *cluster workgroups per set; -1 beyond every plan.  The dispatch table of DESIGN section 4 as code. */
+int tpu3_debug_fps_cluster(int g);
+int tpu3_debug_fps_plan(int b, int n, int m, int *cluster);
+
+/* The multi-workgroup FPS spins on its partner workgroups with BOUNDED polls; a launch whose workgroups never all
+ * became resident gives up, leaves its outputs incomplete and counts a fault.  Returns the number of faulted
+ * workgroups since the last reset on the current device (synchronises the device: call at a synchronisation point,
+ * as pipeline.upsample and bench.py do).  0 in every correct run. */
+long tpu3_fps_cluster_faults(int reset);
 
 #ifdef __cplusplus
 }
