@@ -2512,23 +2512,22 @@ bool fb_plan(int b, int n, FbPlan &p)
                                         (uint32_t *)nullptr, (size_t)n, 0, FB_SORT_BITS, (hipStream_t)0);
     }
     p.sort_temp = align256(tb);
-    // Several workgroups per element (fps_cluster.hip) when the launch is small: all b * G workgroups must be
-    // resident, and four such launches on four streams must still fit the 256 compute units together: b * G <= 64.
-    // G = the largest power of two within that budget, at most 8 -- or what the two-level form NEEDS beyond 256 tiles
-    // (config C5's 3744 tiles: 16).  TPU3_FPS_CLUSTER = 0 (off) / 2, 4, 8, 16 (forced): tuning hook, also
-    // tpu3_debug_fps_cluster().
+    // Several workgroups per element (fps_cluster.hip) when the launch is small.  All b * G workgroups of such a launch
+    // must be resident, and four of them on four streams must still fit the 256 compute units together: b * G <= 64.
+    // Up to 4 elements: 16 members each (239 616 -> 80 000 alone: 33.4 ms on one workgroup, 17.2 on 8, 16.1 on 16);
+    // up to 8: 8 members; beyond that the single-workgroup kernels -- a 32-cloud launch is hidden under the network
+    // stages of the next batch either way, and spends fewer compute-unit-milliseconds on one unit per cloud (measured:
+    // 9.09 vs 9.05 M points/s).  Beyond 256 tiles the two-level form NEEDS 16 members (config C5's 3744 tiles).
+    // TPU3_FPS_CLUSTER = 0 (off) / 2, 4, 8, 16 (forced): tuning hook, also tpu3_debug_fps_cluster().
     p.cluster = 0;
     if (p.fl) {
         int gmin = 1;
         while (gmin * 256 < p.ntile)
             gmin *= 2;
-        int gg = g_cluster_force >= 0 ? g_cluster_force : 8;
-        if (g_cluster_force < 0) {
-            while (gg > 1 && (long)b * gg > 64)
-                gg /= 2;
-            if (p.ntile < 4 * gg)
-                gg = 1;                         // fewer than four tiles per member: not worth an exchange per round
-        }
+        int gg = g_cluster_force >= 0 ? g_cluster_force : (b <= 4 ? 16 : (b <= 8 ? 8 : 1));
+        if (g_cluster_force < 0)
+            while (gg > 1 && p.ntile < 4 * gg)
+                gg /= 2;                        // fewer than four tiles per member: not worth an exchange per round
         if (gg > 1 && gg < gmin && (long)b * gmin <= 64)
             gg = gmin;
         if (gg >= 2 && gg >= gmin && gg <= 16 && (gg & (gg - 1)) == 0 &&

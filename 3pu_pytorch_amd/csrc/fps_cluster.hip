@@ -35,6 +35,8 @@
 // the last mailbox word) and all members leave; the host side reports it (tpu3_fps_cluster_faults).
 #include "fps_bucket.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int FC_CAP = 64;              // samples per round
@@ -45,7 +47,8 @@ constexpr int FC_WORK = 2048;           // work list entries (reached buckets of
 constexpr int FC_DENSE = 16;            // a tile with this many reached buckets is updated on the spot
 constexpr int FC_P2 = 3;                // phase-2 steps of a wave whose points are fetched together
 constexpr int FC_GMAX = 16;
-constexpr int FC_MB = 128;              // granules per mailbox
+constexpr int FC_MB = 128;              // granules per mailbox: 4 header + 62 entries x 2 words
+constexpr int FC_EWMAX = 2;             // words of a candidate entry: maximum, slot
 constexpr unsigned FC_SPIN_MAX = 1u << 23;      // polls before a member gives up (~seconds)
 
 typedef unsigned long long u64;
@@ -69,12 +72,12 @@ struct FcShared {
     int mrow[FC_CAP];                   // ranking: the selected maxima
     uint32_t msel[FC_CAP];              //          their slots (point index in the Morton slab)
     uint32_t kt[FC_CAP];                //          their tie keys (ties only)
-    uint32_t cand[FC_LIST * 2];         // this member's candidates: (maximum, slot)
-    uint32_t dl[FC_LIST * 2];           // what ALL members published, in arrival order (the pollers deposit while wave 0
+    uint32_t cand[FC_LIST * FC_EWMAX];  // this member's candidates: (maximum, slot)
+    uint32_t dl[FC_LIST * FC_EWMAX];    // what ALL members published, in arrival order (the pollers deposit while wave 0
                                         // may still be reading the local list: two buffers)
-    uint32_t lsel[FC_LCAP * 2 + 4];     // the ones it publishes
+    uint32_t lsel[FC_CAP];              // the ones it publishes (positions in `cand`)
     int mcnt[FC_GMAX], mthr[FC_GMAX], mbest[FC_GMAX];
-    uint32_t tmask[512];                // prune: per local tile the samples of the round that may reach it (lo, hi)
+    float tbox[256 * 8];                // boxes of this member's tiles: lo.xyz, hi.xyz (+ 2 unused words)
     u64 tmc[FC_GMAX];                   // tie exchange: (key << 32 | slot) per member
     u64 tiekey;
     int npick[2];
@@ -89,6 +92,10 @@ static_assert(offsetof(FcShared, mrow) % 16 == 0 && offsetof(FcShared, cand) % 1
 
 constexpr size_t fc_mbox_words(int g) { return (size_t)2 * g * FC_MB + (size_t)2 * g * 2 + 8; }
 
+// (Measured and dropped: bucket records and the buckets' best points (x, y, z, tie key) in LDS with the candidates
+// published WITH their coordinates -- no memory trip in a round but the reached buckets' points.  Bit-identical, and
+// slower, 20.5 vs 17.2 ms for 239 616 -> 80 000 on eight members: six granules per candidate instead of two cost
+// 2.2 k cycles more to publish and 1.3 k more to poll, against 0.4 k saved in the ranking and 0.2 k in the visits.)
 constexpr size_t fc_lds_bytes(int ntile, int g)
 {
     return ((((size_t)((ntile + g - 1) / g) * 64 * 5) + 15) & ~(size_t)15) + 512 * 4 + (size_t)FC_WORK * 12 +
@@ -99,6 +106,8 @@ template <bool PROF>
 __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *mbox0, u64 *stats)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EW = 2;                                   // words per candidate entry
+    constexpr int NSW = (4 + FC_LCAP * EW + 63) / 64;       // 64-granule sweeps of a mailbox
     const int G = 1 << lg;
     const int lcap = G <= 8 ? FC_LCAP : FC_LIST / G - 1;
     const int cl = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
@@ -139,20 +148,14 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
     // A member's tiles are OWNED (visited, listed) by lane l < 16 of wave w: local tile l * 16 + w.
     const int ltq = lane * 16 + wave;
     const bool tvalid = lane < 16 && ltq < nlt;
-    // The prune step tests (tile, sample) pairs densely instead: the tiles in chunks of 64, a lane per tile, wave w
-    // on chunk w mod nch for the samples w / nch, w / nch + nwpc, ... (a member of a cluster owns 30 - 234 tiles:
-    // with a quad per tile 8 of a wave's 64 lanes had anything to test, and the test loop was 7 k cycles of a round)
-    const int nch = (nlt + 63) >> 6;
-    const int nwpc = nch > 0 ? 16 / nch : 0;                 // waves per chunk
-    const bool pwave = nch > 0 && wave < nch * nwpc;
-    const int ptile = pwave ? (wave % nch) * 64 + lane : 0;
-    const bool pvalid = pwave && ptile < nlt;
-    float pbx[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-        pbx[c] = pvalid ? a.tt[(((ptile << lg) | g)) * 8 + c] : __builtin_inff();
-    for (int i = tid; i < 512; i += 1024)
-        sh.tmask[i] = 0u;
+    // The prune step: wave w tests ITS tiles (w, w + 16, ...) against the round's samples, a lane per SAMPLE, the
+    // tile's box wave-uniform from LDS -- the ballot IS the tile's sample set, and the owner visits the tile at once:
+    // no hand-off, no barrier between prune and visits.  (A quad per tile as in the single-workgroup form left 8 of a
+    // wave's 64 lanes busy here, 7 k cycles of a round; tiles across the lanes with the samples dealt over the waves
+    // needed LDS atomics and a barrier to assemble the sets.)
+    float *tbox = sh.tbox;
+    for (int i = tid; i < nlt * 8; i += 1024)
+        tbox[i] = a.tt[(size_t)((((i >> 3) << lg) | g)) * 8 + (i & 7)];
     if (tid == 0) {
         sh.ncand = 0;
         sh.nwork = 0;
@@ -178,7 +181,14 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
 
     // PROF: wave 0's cycles per phase -- apply phase 1 (+ barrier), phase 2 (+ barrier), candidate collection, local
     // selection + publish, poll (+ barrier), merge / rank (+ barrier), clearance (+ barrier); listed / merged counts
-    u64 pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
+    u64 pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = 0, pm = 0;
+    auto mmark = [&](int k) __attribute__((always_inline)) {
+        if (PROF) {
+            const u64 now = __builtin_amdgcn_s_memtime();
+            pc[k] += now - pm;
+            pm = now;
+        }
+    };
     auto mark = [&](int k) __attribute__((always_inline)) {
         if (PROF) {
             const u64 now = __builtin_amdgcn_s_memtime();
@@ -248,30 +258,6 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
 
     // ---- fold the first nj samples of pick[cur] into every bucket of THIS member they reach -------------------
     auto apply = [&](int nj, int cur) __attribute__((always_inline)) {
-        if (pwave) {
-            const float tmf = pvalid ? __int_as_float(tmx[ptile]) : -1.f;          // (a box distance is never < -1)
-            uint32_t mlo = 0, mhi = 0;
-            for (int i = wave / nch; i < nj; i += nwpc) {                           // (wave-uniform)
-                const float4 p = *(const float4 *)sh.pick[cur][i];
-                const bool hit = fb_dbox(p.x, p.y, p.z, pbx[0], pbx[1], pbx[2], pbx[3], pbx[4], pbx[5]) < tmf;
-                if (i < 32)
-                    mlo |= hit ? (1u << i) : 0u;
-                else
-                    mhi |= hit ? (1u << (i - 32)) : 0u;
-            }
-            if (mlo)
-                atomicOr(&sh.tmask[2 * ptile], mlo);
-            if (mhi)
-                atomicOr(&sh.tmask[2 * ptile + 1], mhi);
-        }
-        __syncthreads();
-        uint32_t mlo = 0, mhi = 0;
-        if (tvalid) {
-            mlo = sh.tmask[2 * ltq];
-            mhi = sh.tmask[2 * ltq + 1];
-            if (mlo | mhi)
-                *(uint2 *)(sh.tmask + 2 * ltq) = make_uint2(0u, 0u);
-        }
         // one tile (local index lt): which of its 64 buckets do the samples of `smt` reach?
         auto visit_tile = [&](int lt, unsigned long long smt) __attribute__((always_inline)) {
             const int lbk = lt * 64 + lane;
@@ -327,11 +313,17 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 e[0] = (uint32_t)gb; e[1] = (uint32_t)mine; e[2] = (uint32_t)(mine >> 32);
             }
         };
-        for (unsigned long long touched = __ballot((mlo | mhi) != 0); touched; touched &= touched - 1) {
-            const int L = __builtin_ctzll(touched);
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, L);
-            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, L);
-            visit_tile(L * 16 + wave, ((unsigned long long)shi << 32) | slo);
+        {
+            const bool has = lane < nj;
+            const float4 ps = *(const float4 *)sh.pick[cur][has ? lane : 0];
+            for (int lt = wave; lt < nlt; lt += 16) {
+                const float4 b0 = *(const float4 *)(tbox + lt * 8), b1 = *(const float4 *)(tbox + lt * 8 + 4);
+                const float tmf = __int_as_float(tmx[lt]);
+                const unsigned long long m =
+                    __ballot(has && fb_dbox(ps.x, ps.y, ps.z, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y) < tmf);
+                if (m)
+                    visit_tile(lt, m);
+            }
         }
         __syncthreads();
         mark(0);
@@ -450,8 +442,9 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 base = __builtin_amdgcn_readfirstlane(base);
                 const int pos = base + __builtin_popcountll(cm & ((1ull << lane) - 1ull));
                 if (c && pos < FC_LIST) {
-                    sh.cand[pos * 2] = (uint32_t)bm;
-                    sh.cand[pos * 2 + 1] = ((uint32_t)gbucket(lbk) << 4) | (uint32_t)ba;
+                    uint32_t *e = sh.cand + pos * EW;
+                    e[0] = (uint32_t)bm;
+                    e[1] = ((uint32_t)gbucket(lbk) << 4) | (uint32_t)ba;
                 }
             });
             __syncthreads();
@@ -485,8 +478,8 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 em[u] = (int)0x80000000;
                 eb[u] = 0;
                 if (u * 64 < total) {
-                    em[u] = i < total ? (int)sh.cand[2 * i] : (int)0x80000000;
-                    eb[u] = sh.cand[2 * (i < total ? i : 0) + 1];
+                    em[u] = i < total ? (int)sh.cand[EW * i] : (int)0x80000000;
+                    eb[u] = (uint32_t)i;
                 }
             }
             int thr2 = thr, nsel = total;
@@ -518,22 +511,23 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 const unsigned long long smk = __ballot(sel);
                 if (sel) {
                     const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
-                    sh.lsel[2 * pos] = (uint32_t)em[u];
-                    sh.lsel[2 * pos + 1] = eb[u];
+                    sh.lsel[pos] = eb[u];
                 }
                 base += __builtin_popcountll(smk);
             }
             // (the LDS list above is read back by other lanes of this wave only: program order within a wave)
             u64 *box = mb + ((size_t)par * G + g) * FC_MB;
-            const int need = 4 + 2 * nsel;
+            const int need = 4 + EW * nsel;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NSW; ++s) {
                 const int i = s * 64 + lane;
+                if (s * 64 >= need)
+                    break;
                 uint32_t v = 0;
                 if (i == 0) v = (uint32_t)lbest;
                 else if (i == 1) v = (uint32_t)thr2;
                 else if (i == 2) v = (uint32_t)nsel;
-                else if (i >= 4) v = sh.lsel[(i - 4) < 2 * nsel ? i - 4 : 0];
+                else if (i >= 4 && i < need) v = sh.cand[EW * sh.lsel[(i - 4) / EW] + (i - 4) % EW];
                 if (i < need)
                     fc_put(box + i, epoch, v);
             }
@@ -545,16 +539,20 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         if (wave < G) {
             const u64 *src = mb + ((size_t)par * G + wave) * FC_MB;
             unsigned spins = 0;
-            u64 x0, x1;
+            u64 x[NSW];
             int cnt = 0;
             for (;;) {
-                x0 = fc_get(src + lane);
-                x1 = fc_get(src + 64 + lane);
-                const bool t0 = (unsigned)(x0 >> 32) == epoch, t1 = (unsigned)(x1 >> 32) == epoch;
-                const bool hdr = (__ballot(t0) & 7ull) == 7ull;
-                cnt = hdr ? __builtin_amdgcn_readlane((int)(uint32_t)x0, 2) : 0;
-                const int need = 4 + 2 * cnt;
-                if (hdr && !__ballot((lane < need && !t0) || (64 + lane < need && !t1)))
+#pragma unroll
+                for (int q = 0; q < NSW; ++q)
+                    x[q] = fc_get(src + q * 64 + lane);
+                const bool hdr = (__ballot((unsigned)(x[0] >> 32) == epoch) & 7ull) == 7ull;
+                cnt = hdr ? __builtin_amdgcn_readlane((int)(uint32_t)x[0], 2) : 0;
+                const int need = 4 + EW * cnt;
+                bool miss = false;
+#pragma unroll
+                for (int q = 0; q < NSW; ++q)
+                    miss |= q * 64 + lane < need && (unsigned)(x[q] >> 32) != epoch;
+                if (hdr && !__ballot(miss))
                     break;
                 if (++spins > FC_SPIN_MAX || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                     if (lane == 0)
@@ -567,21 +565,23 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             if (wave == 0)
                 n_sweep += spins + 1;
             if (lane == 0) {
-                sh.mbest[wave] = (int)(uint32_t)x0;
+                sh.mbest[wave] = (int)(uint32_t)x[0];
                 sh.mcnt[wave] = cnt;
             }
             if (lane == 1)
-                sh.mthr[wave] = (int)(uint32_t)x0;
+                sh.mthr[wave] = (int)(uint32_t)x[0];
             // the entries go straight onto the cluster's list (any order: the ranking does not depend on it), unfiltered
             // -- T0 is known only when all headers are in
             int base = 0;
             if (lane == 0 && cnt)
                 base = atomicAdd(&sh.ndense, cnt);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (lane >= 4 && lane < 4 + 2 * cnt)
-                sh.dl[2 * base + lane - 4] = (uint32_t)x0;
-            if (64 + lane < 4 + 2 * cnt)
-                sh.dl[2 * base + 60 + lane] = (uint32_t)x1;
+#pragma unroll
+            for (int q = 0; q < NSW; ++q) {
+                const int i = q * 64 + lane;
+                if (i >= 4 && i < 4 + EW * cnt)
+                    sh.dl[EW * base + i - 4] = (uint32_t)x[q];
+            }
         }
         __syncthreads();
         mark(4);
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         const int left = a.m - r;
         uint32_t okey = 0;
         if (wave == 0) {
+            if (PROF) pm = __builtin_amdgcn_s_memtime();
             int gb_ = lane < G ? sh.mbest[lane] : (int)0x80000000;
             int t0_ = lane < G ? sh.mthr[lane] : (int)0x80000000;
             tpu3_wave_max_i32_fast_x2(gb_, t0_);
@@ -609,12 +610,13 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 eb[u] = 0;
                 if (u * 64 < tot) {
                     const int i = u * 64 + lane;
-                    const uint2 e = *(const uint2 *)(dl + 2 * (i < tot ? i : 0));
-                    em[u] = i < tot && (int)e.x > T0 ? (int)e.x : (int)0x80000000;
-                    eb[u] = e.y;
+                    const int bm = (int)dl[EW * (i < tot ? i : 0)];
+                    em[u] = i < tot && bm > T0 ? bm : (int)0x80000000;
+                    eb[u] = (uint32_t)i;                            // (position on the list)
                     total2 += __builtin_popcountll(__ballot(em[u] > T0));
                 }
             }
+            mmark(8);
             int thr2 = T0, nsel = total2;
             if (total2 > FC_CAP) {
                 int lo = T0, hi = gbest, chi = 0;                // count(> lo) > FC_CAP >= count(> hi) = chi
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 }
                 thr2 = hi; nsel = chi;
             }
+            mmark(9);
             // (nsel == 0: no bucket beats every runner-up bound, or more than FC_CAP share the top value -- duplicated
             // points; the exact arg-max with the tie rule below settles it)
             int base = 0;
@@ -653,15 +656,17 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             }
             const bool live = lane < nsel;
             const int cM = live ? sh.mrow[lane] : (int)0x80000000;
-            const uint32_t cB = sh.msel[live ? lane : 0];
+            const uint32_t *ce = dl + EW * sh.msel[live ? lane : 0];
             // ONE round trip for the coordinates and keys of the whole list (the IMMUTABLE words of the slab: any
             // member may read them; the running distance of a foreign bucket is taken from its published maximum)
+            const uint32_t cB = ce[1];
             const float4 sp4 = TP[live ? cB : 0];
             const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
             if (!live)
                 sh.mrow[lane] = (int)0x80000000;
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); mmark(10); }
+            // rank = the number of larger maxima; equal maxima (rare) show up as two lanes landing on ONE rank
             int rank = 0;
-            bool tie = false;
             for (int c0 = 0; c0 < nsel; c0 += 16) {
                 int4 mv[4];
 #pragma unroll
@@ -669,15 +674,19 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     mv[u] = *(const int4 *)(sh.mrow + c0 + 4 * u);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int m4[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w};
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        rank += m4[v] > cM ? 1 : 0;
-                        tie |= m4[v] == cM && c0 + 4 * u + v != lane;
-                    }
+                    rank += mv[u].x > cM ? 1 : 0;
+                    rank += mv[u].y > cM ? 1 : 0;
+                    rank += mv[u].z > cM ? 1 : 0;
+                    rank += mv[u].w > cM ? 1 : 0;
                 }
             }
-            if (__ballot(live && tie)) {            // equal maxima among candidates: order by the tie key
+            // (volatile: another LANE's store to the same word is what is being looked for -- the compiler must not
+            // forward this lane's own store to its load)
+            volatile uint32_t *seat = sh.kt;
+            if (live)
+                seat[rank] = (uint32_t)lane;
+            const bool tie = live && seat[rank] != (uint32_t)lane;
+            if (__ballot(tie)) {                    // equal maxima among candidates: order by the tie key
                 sh.kt[lane] = cK;
                 rank = 0;
                 for (int c0 = 0; c0 < nsel; c0 += 8) {
@@ -690,6 +699,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                         rank += (m8[v] > cM || (m8[v] == cM && k8[v] < cK)) ? 1 : 0;
                 }
             }
+            mmark(11);
             if (live) {
                 *(float4 *)sh.pick[par][rank] = make_float4(sp4.x, sp4.y, sp4.z, __int_as_float(cM));
                 sh.pkey[par][rank] = cK;
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             if (stats && tid == 0 && g == 0 && cl == 0) {
                 stats[0] = (u64)round + 1; stats[1] = (u64)r - 1; stats[2] = n_tie; stats[3] = n_sweep;
                 if (PROF)
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         stats[8 + k] = pc[k];
             }
             return;

@@ -83,6 +83,13 @@ class HipBackend(object):
                 t.zero_()
         return hits
 
+    def fps_cluster_faults(self, reset=True):
+        """Workgroups of the multi-workgroup FPS (csrc/fps_cluster.hip) that gave up waiting for their partners since
+        the last reset, on the current device (synchronises it).  Always 0 unless a cluster launch could not become
+        resident (more than 256 cluster workgroups in flight at once); a non-zero count means some FPS result since
+        the last reset is incomplete."""
+        return int(L.lib().tpu3_fps_cluster_faults(1 if reset else 0))
+
     def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True, unique_cache=None):
         """query (B,M,C), points (Bp,N,C) f32 contiguous device tensors ->
         idx int64 (B,M,k), dist f32 (B,M,k) | None, grouped f32 (B,M,k,C) | None.

@@ -166,6 +166,12 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
             if timing is not None:
                 del timing[n_timing:]                   # the first pass's events are not this call's result
             out = run(False)
+    if check_small and hasattr(be, "fps_cluster_faults"):
+        # (rank-local: a faulted launch leaves THIS rank's result incomplete; no collective depends on it)
+        faults = be.fps_cluster_faults(reset=True)
+        if faults:
+            raise RuntimeError("%d workgroups of a multi-workgroup FPS launch gave up waiting for their partners (too "
+                               "many cluster launches in flight at once?): the sampled cloud is incomplete" % faults)
     if check_small and hasattr(net, "small_cloud_events"):
         bad = net.small_cloud_events
         if _any_rank(bad, clouds.device) if sharded else bad:

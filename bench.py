@@ -512,6 +512,7 @@ def main():
     assert int(net.small_cloud_events) == 0
     assert ops.BACKEND.graph_dup_events() == 0, "an optimistic kNN graph asked for the exact path: result not final"
     assert not ops.GENERIC_PATH_EVENTS, "generic (unfused) path taken in the measured run: %r" % dict(ops.GENERIC_PATH_EVENTS)
+    assert ops.BACKEND.fps_cluster_faults() == 0, "a multi-workgroup FPS launch gave up: result not final"
 
     # all-gather bus bandwidth (N > 1): (P-1)/P * gathered bytes / time, 10 back-to-back gathers
     comm = None

@@ -98,3 +98,32 @@ def test_cpu_tensors_are_rejected():
                                   torch.zeros(1, 2, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         ops.group_knn(2, torch.zeros(1, 3, 4), torch.zeros(1, 3, 8))
+
+
+def test_fps_dispatch_table():
+    """Which kernel a (b, n, m) call takes -- DESIGN section 4's table, as the dispatcher reports it.  A wrong size
+    threshold would silently select a slower kernel: the regimes are pinned here (no launch: runs without a GPU
+    through the same plan function the launcher uses)."""
+    lib = pkg("_lib").lib()
+    lib.tpu3_debug_fps_cluster(-1)
+    cl = ctypes.c_int(0)
+
+    def plan(b, n, m):
+        k = lib.tpu3_debug_fps_plan(b, n, m, ctypes.byref(cl))
+        return k, cl.value
+    # per-level resampling of the network (one set per outer patch): a lane per bucket, several samples per round
+    assert plan(1536, 6240, 1248)[0] == 2 and plan(1536, 12480, 2496)[0] == 2 and plan(1536, 24960, 4992)[0] == 2
+    # small sets with few samples: rows in registers, one sample per round
+    assert plan(48, 4096, 300)[0] == 1 and plan(4, 7000, 100)[0] == 1
+    # mid-size sets with few samples: 64-point buckets in memory
+    assert plan(2, 20000, 100)[0] == 3
+    # the metric's final FPS: one cloud (latency) on 16 members, a sub-batch of 8 on 8, the bench's 32-cloud launch on
+    # one workgroup per cloud (two-level tile form)
+    assert plan(1, 239616, 80000) == (6, 16) and plan(4, 239616, 80000) == (6, 16)
+    assert plan(8, 239616, 80000) == (6, 8) and plan(32, 239616, 80000) == (4, 0)
+    # config C5's 3.83 M -> 1.28 M: two levels need 16 members; a batch that cannot have them takes three levels
+    assert plan(1, 3833856, 1280000) == (6, 16) and plan(8, 3833856, 1280000) == (5, 0)
+    # just above the register-resident limit: too few tiles for 16 members
+    assert plan(1, 25601, 3000) == (6, 4) and plan(1, 70000, 3000) == (6, 16)
+    # beyond every plan
+    assert plan(1, 5000000, 1000)[0] in (-1, 3)

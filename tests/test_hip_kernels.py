@@ -179,6 +179,79 @@ def test_fps_bucketed_batched_segmented_sort_ragged(orc, dev, b, n, m):
     np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
 
 
+@pytest.fixture
+def fps_cluster():
+    """tpu3_debug_fps_cluster(g) for the duration of a test, the default policy restored afterwards."""
+    lib = pkg("_lib").lib()
+
+    def force(g):
+        lib.tpu3_debug_fps_cluster(g)
+    yield force
+    lib.tpu3_debug_fps_cluster(-1)
+    assert lib.tpu3_fps_cluster_faults(1) == 0
+
+
+@pytest.mark.parametrize("g,b,n,m,dups", [(2, 1, 30000, 3000, False), (4, 2, 70000, 1500, False),
+                                            (8, 1, 239616, 6000, False), (16, 1, 239616, 6000, False),
+                                            (8, 1, 40000, 4000, True), (16, 1, 26000, 26000, False),
+                                            (16, 1, 300000, 2000, False), (4, 3, 25601, 300, False)])
+def test_fps_cluster_form_bit_exact(orc, dev, fps_cluster, g, b, n, m, dups):
+    """The tile form on g workgroups per set (csrc/fps_cluster.hip; reference: sampling_cuda.cu:103-174 run by ONE
+    block): indices AND final temp equal the plain algorithm's for every cluster size, duplicated points (the tie
+    exchange), every point sampled, a set beyond 256 tiles (two levels on 16 members) and a batch."""
+    sampling, lib = pkg("sampling"), pkg("_lib").lib()
+    fps_cluster(g)
+    cl = ctypes.c_int(0)
+    assert lib.tpu3_debug_fps_plan(b, n, m, ctypes.byref(cl)) == 6 and cl.value == g
+    if dups:
+        rng = np.random.default_rng(n)
+        base = sphere(n, n // 4, 1)[0]
+        xyz = base[rng.integers(0, base.shape[0], size=n)][None]
+    else:
+        xyz = sphere(3000 + n, n, b)
+    ref_idx, ref_temp = orc.fps(xyz, m)
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.empty((b, m), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(b, n, m, _t(xyz, dev), temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+def test_fps_cluster_form_ragged_and_continued(orc, dev, fps_cluster):
+    """Ragged batch (live point AND sample counts per element, a tiny element whose members own no tile at all) and
+    continuation from a caller-supplied temp through the cluster form."""
+    ops, sampling = pkg("network.operations"), pkg("sampling")
+    fps_cluster(8)
+    n, m = 60000, 500
+    xyz = sphere(17, n, 4)
+    n_arr = np.array([60000, 41000, 3000, 59999], np.int32)
+    m_arr = np.array([500, 499, 120, 1], np.int32)
+    idx = ops.fps(_t(xyz, dev), m, _t(n_arr, dev), _t(m_arr, dev)).cpu().numpy()
+    for i in range(4):
+        ref_idx, _ = orc.fps(xyz[i:i + 1, :n_arr[i]], int(m_arr[i]))
+        np.testing.assert_array_equal(idx[i, :m_arr[i]], ref_idx[0])
+    one = sphere(78, 50000, 1)
+    i1, t1 = orc.fps(one, 200)
+    i2, t2 = orc.fps(one, 300, temp=t1)
+    temp = _t(t1, dev)
+    out = torch.empty((1, 300), dtype=torch.int32, device=dev)
+    sampling.furthest_sampling(1, 50000, 300, _t(one, dev), temp, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), i2)
+    np.testing.assert_array_equal(temp.cpu().numpy(), t2)
+
+
+def test_fps_cluster_equals_single_workgroup_on_all_80000_picks(dev, fps_cluster):
+    """The metric's final resampling, 239 616 -> 80 000 (main.py:379-380), in full: 16 members against one workgroup
+    (which tests/test_c2_parity.py pins against the reference's own merged cloud), every pick."""
+    ops = pkg("network.operations")
+    x = _t(sphere(5, 239616, 1), dev)
+    fps_cluster(0)
+    one = ops.fps(x, 80000)
+    fps_cluster(16)
+    many = ops.fps(x, 80000)
+    assert torch.equal(one, many)
+
+
 @pytest.mark.parametrize("n", [300, 700, 3000])
 def test_fps_tie_rule_with_duplicated_points(orc, dev, n):
     """Exact ties only arise from duplicated points (pc_utils.load pads clouds that way); the

@@ -26,7 +26,7 @@ def run(G, reps=3):
     lib.tpu3_debug_fps_cluster(G)
     cl = ctypes.c_int(0)
     kind = lib.tpu3_debug_fps_plan(B, n, m, ctypes.byref(cl))
-    stats = torch.zeros(16, dtype=torch.int64, device=dev)
+    stats = torch.zeros(32, dtype=torch.int64, device=dev)
     lib.tpu3_debug_fps_tile_stats(ctypes.c_void_p(stats.data_ptr()))
     idx = ops.fps(x, m)
     torch.cuda.synchronize()
@@ -54,4 +54,6 @@ for G in [int(v) for v in os.environ.get("GS", "2,4,8,16").split(",")]:
     R = max(1, st[0])
     print("        wave 0 cycles per round: phase 1 %.0f | phase 2 %.0f | collect %.0f | local select + publish %.0f | poll %.0f "
           "| merge + rank %.0f | clearance %.0f ; listed locally %.1f" % tuple(st[8 + k] / R for k in range(8)))
+    print("        merge split: headers + load + filter %.0f | bisection %.0f | compaction + fetch %.0f | ranking %.0f"
+          % tuple(st[16 + k] / R for k in range(4)))
 lib.tpu3_debug_fps_cluster(-1)
