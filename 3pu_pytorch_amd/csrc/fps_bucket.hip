@@ -305,9 +305,6 @@ __global__ __launch_bounds__(256) void fb_bucket_init_kernel(FbArgs a0)
 // may be accepted.  The re-scans of a round are listed first and then run several buckets at a time with
 // all their loads in flight.
 // ---------------------------------------------------------------------------------------------
-constexpr int FM_CAP = 32;          // candidates per round (FM_CAP / NW per wave): a 32-bit sample mask per bucket
-constexpr int FM_EW = 8;            // words per candidate entry (5 used)
-
 struct FmHeader {                   // one per wave and buffer
     int best;                       // best group entry of the wave (distance bits) ...
     uint32_t key;
@@ -317,610 +314,6 @@ struct FmHeader {                   // one per wave and buffer
     int drop;                       // best candidate NOT entered (INT_MIN if none)
 };
 
-struct FmShared {
-    FmHeader h[2][8];
-    int nwk[8];                     // entries on each wave's re-scan list this round (two-level form)
-    uint32_t stat[8];               // PROF: rounds, samples, capped rounds, tie rounds, ...
-};
-
-constexpr size_t fm_lds_bytes(int nbpad, int nw)
-{
-    // 9 words per bucket; 12 per group-table entry, of which the 6 box words are setup only and are
-    // re-used for the candidate lists (2 x FM_CAP x FM_EW words) and the waves' re-scan work lists
-    // (nw x 64 x 2 words); the shared block
-    return (size_t)nbpad * 36 + (size_t)nw * 64 * 12 * 4 + sizeof(FmShared) + 64;
-}
-
-// L3 (point sets beyond 4096 x 64 = 262 144 points, up to 4.19 M: config C5's 3.83 M): three levels.  The LDS
-// table then holds CELLS of 16 consecutive 64-point leaf buckets (1024 points); the leaves' own entries --
-// the nine-row array the bucket-init kernel wrote, 36 bytes per leaf -- stay in global memory (2 MB for
-// 3.83 M points: L2) and are updated in place.  A reached cell is not re-scanned as a whole: its 16 leaf
-// entries are fetched (one DPP row per cell), tested against the samples that reach the cell, the reached
-// LEAVES are re-scanned exactly as buckets are in the two-level form, and the cell's entry is rebuilt from its
-// leaves.  Three dependent trips to L2 per reached cell instead of streaming 16 KB through the VALU.
-template <int NW, int PPL, bool PROF = false, bool L3 = false>
-__global__ __launch_bounds__(NW * 64) void fm_main_kernel(FbArgs a0)
-{
-    static_assert(!L3 || PPL == 1, "leaf buckets are 64 points");
-    static_assert(NW == 4 || NW == 8, "candidate slots: FM_CAP / NW per wave");
-    constexpr int WCAP = FM_CAP / NW;      // candidates a wave may enter per round
-    constexpr int W = NW * 64;
-    constexpr int GT = W;                           // group-table entries (owner order), one per lane
-    static_assert(2 * FM_CAP * FM_EW + 2 * NW * 64 * 2 <= 6 * GT, "lists must fit the setup-only box area");
-    constexpr int CH = PPL <= 2 ? 4 : 2;            // buckets in flight per re-scan step (8: register arrays spill)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FbArgs a = fb_elem(a0, blockIdx.x);
-    const int nbpad = a.ncell, ng = a.ng, lb = a.lb;        // nbpad: entries of the LDS table (cells)
-    const int LS = a.nbpad;                                 // row stride of the leaf table a.ib (L3)
-    if (a.n <= 0 || a.m <= 0)
-        return;
-    // Group g = the 16 CONSECUTIVE Morton buckets [16 g, 16 g + 16) (a compact box); it belongs to wave g % NW,
-    // owner lane g / NW.  With several samples per round, scattered over the cloud, the waves' re-scan loads
-    // balance statistically, and a sample touches one or two groups in total instead of one per wave.
-    int *t_max = (int *)smem;
-    uint32_t *t_key = (uint32_t *)(t_max + nbpad);
-    float *t_x = (float *)(t_key + nbpad);
-    float *t_y = t_x + nbpad;
-    float *t_z = t_y + nbpad;
-    uint32_t *t_b0 = (uint32_t *)(t_z + nbpad);     // fp16 boxes: lo.x|lo.y, lo.z|hi.x, hi.y|hi.z
-    uint32_t *t_b1 = t_b0 + nbpad;
-    uint32_t *t_b2 = t_b1 + nbpad;
-    int *t_r = (int *)(t_b2 + nbpad);               // runner-up of the bucket
-    int *g_max = t_r + nbpad;
-    uint32_t *g_key = (uint32_t *)(g_max + GT);
-    float *g_x = (float *)(g_key + GT);
-    float *g_y = g_x + GT;
-    float *g_z = g_y + GT;
-    int *g_r = (int *)(g_z + GT);                   // runner-up bound of the group
-    float *g_box = (float *)(g_r + GT);             // 6 x GT, setup only ...
-    uint32_t *cand = (uint32_t *)g_box;             // ... then the candidate lists [2][FM_CAP][FM_EW]
-    uint32_t *work = cand + 2 * FM_CAP * FM_EW;     // ... and the re-scan work lists [NW][64][2] (+ leaf lists, L3)
-    FmShared &sh = *(FmShared *)(g_box + 6 * GT);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = lane >> 4, col = lane & 15;
-    float4 *__restrict__ sp = a.sp;
-    const uint32_t *__restrict__ skey = a.skey;
-    uint32_t *wl = work + wave * 128;
-    uint32_t *wl2 = work + NW * 128 + wave * 128;   // L3: the reached leaves of the cells being worked on
-
-    // group g <-> wave g % NW, owner lane g / NW
-    auto refresh_groups = [&](int slot, bool with_box) __attribute__((always_inline)) {
-        const bool valid = slot >= 0 && slot * NW + wave < ng;
-        const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
-        const int bits = valid ? t_max[beta] : (int)0x80000000;
-        const uint32_t key = valid ? t_key[beta] : 0xFFFFFFFFu;
-        const int rmax = tpu3_row_max_i32_fast(bits);
-        unsigned long long tie = __ballot(valid && bits == rmax);
-        const unsigned long long rows = __ballot(valid && col == 0);
-        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
-            const uint32_t k = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
-            tie = __ballot(valid && bits == rmax && key == k);
-        }
-        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
-        const bool winner = valid && ((tie >> lane) & 1ull) && (tie & below) == 0;
-        // runner-up bound of the group: the other children's maxima and the winning child's own runner-up
-        const int rr = tpu3_row_max_i32_fast(valid ? (winner ? t_r[beta] : bits) : (int)0x80000000);
-        if (winner) {
-            const int e = wave * 64 + slot;
-            g_max[e] = rmax; g_key[e] = key; g_r[e] = rr;
-            g_x[e] = t_x[beta]; g_y[e] = t_y[beta]; g_z[e] = t_z[beta];
-        }
-        if (with_box) {     // setup: group AABB = union of the children's (outward-rounded) boxes
-            const uint32_t w0 = valid ? t_b0[beta] : 0, w1 = valid ? t_b1[beta] : 0, w2 = valid ? t_b2[beta] : 0;
-            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
-                          fb_half_hi(w2)};
-            for (int c3 = 0; c3 < 6; ++c3) {
-                if (!valid)
-                    v[c3] = -__builtin_inff();
-                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
-                if (valid && col == 0)
-                    g_box[c3 * GT + wave * 64 + slot] = c3 < 3 ? -m : m;
-            }
-        }
-    };
-
-    // ---- setup ------------------------------------------------------------------------------------
-    // a cell's entry from its 16 leaves (L3): DPP row `row` handles cell `cell` (< 0: idle), lane `col` leaf
-    // 16 cell + col.  Best leaf by (distance, tie key); runner-up = the other leaves' bests and the winner's own
-    // runner-up; with_box: union of the leaves' fp16 boxes (exact: min / max of fp16 values).
-    auto cell_from_leaves = [&](int cell, bool with_box) __attribute__((always_inline)) {
-        const bool valid = cell >= 0;
-        const int leaf = valid ? cell * FB_GS + col : 0;
-        const int bits = valid ? (int)a.ib[0 * LS + leaf] : (int)0x80000000;
-        const uint32_t key = valid ? a.ib[1 * LS + leaf] : 0xFFFFFFFFu;
-        const int lr = valid ? (int)a.ib[8 * LS + leaf] : (int)0x80000000;
-        const int rmax = tpu3_row_max_i32_fast(bits);
-        unsigned long long tie = __ballot(valid && bits == rmax);
-        const unsigned long long rows = __ballot(valid && col == 0);
-        if (__builtin_popcountll(tie) != __builtin_popcountll(rows)) {     // duplicated points
-            const uint32_t k2 = tpu3_row_min_u32(valid && bits == rmax ? key : 0xFFFFFFFFu);
-            tie = __ballot(valid && bits == rmax && key == k2);
-        }
-        const unsigned long long below = ((1ull << col) - 1ull) << (row * 16);
-        const bool winner = valid && ((tie >> lane) & 1ull) && (tie & below) == 0;
-        const int rr = tpu3_row_max_i32_fast(valid ? (winner ? lr : bits) : (int)0x80000000);
-        if (winner) {
-            t_max[cell] = rmax; t_key[cell] = key; t_r[cell] = rr;
-            t_x[cell] = __uint_as_float(a.ib[2 * LS + leaf]);
-            t_y[cell] = __uint_as_float(a.ib[3 * LS + leaf]);
-            t_z[cell] = __uint_as_float(a.ib[4 * LS + leaf]);
-        }
-        if (with_box) {
-            const uint32_t w0 = valid ? a.ib[5 * LS + leaf] : 0, w1 = valid ? a.ib[6 * LS + leaf] : 0;
-            const uint32_t w2 = valid ? a.ib[7 * LS + leaf] : 0;
-            float v[6] = {-fb_half_lo(w0), -fb_half_hi(w0), -fb_half_lo(w1), fb_half_hi(w1), fb_half_lo(w2),
-                          fb_half_hi(w2)};
-            uint32_t h[6];
-#pragma unroll
-            for (int c3 = 0; c3 < 6; ++c3) {
-                if (!valid)
-                    v[c3] = -__builtin_inff();
-                const float m = tpu3_unmono(tpu3_row_max_u32(tpu3_mono(v[c3])));
-                h[c3] = __half_as_ushort(__float2half(c3 < 3 ? -m : m));
-            }
-            if (valid && col == 0) {
-                t_b0[cell] = h[0] | (h[1] << 16); t_b1[cell] = h[2] | (h[3] << 16); t_b2[cell] = h[4] | (h[5] << 16);
-            }
-        }
-    };
-    if constexpr (L3) {
-        for (int c0 = wave * 4; c0 < nbpad; c0 += NW * 4)
-            cell_from_leaves(c0 + row, true);
-    } else {
-        for (int i = tid; i < nbpad; i += W) {
-            const int ti = i;                               // table slot = bucket id
-            t_max[ti] = (int)a.ib[0 * nbpad + i];
-            t_key[ti] = a.ib[1 * nbpad + i];
-            t_x[ti] = __uint_as_float(a.ib[2 * nbpad + i]);
-            t_y[ti] = __uint_as_float(a.ib[3 * nbpad + i]);
-            t_z[ti] = __uint_as_float(a.ib[4 * nbpad + i]);
-            t_b0[ti] = a.ib[5 * nbpad + i];
-            t_b1[ti] = a.ib[6 * nbpad + i];
-            t_b2[ti] = a.ib[7 * nbpad + i];
-            t_r[ti] = (int)a.ib[8 * nbpad + i];
-        }
-    }
-    for (int i = tid; i < GT; i += W) {
-        g_max[i] = (int)0x80000000; g_key[i] = 0xFFFFFFFFu; g_r[i] = (int)0x80000000;
-        g_x[i] = g_y[i] = g_z[i] = 0.f;
-        for (int c3 = 0; c3 < 6; ++c3)
-            g_box[c3 * GT + i] = __builtin_inff();          // lo = hi = +inf: infinitely far away
-    }
-    if (tid < 8)
-        sh.stat[tid] = 0;
-    __syncthreads();
-    for (int s0 = 0; s0 < 64; s0 += 4)
-        if ((s0 * NW + wave) < ng)
-            refresh_groups(s0 + row, true);
-    __syncthreads();
-    float gbox[6];
-    for (int c3 = 0; c3 < 6; ++c3)
-        gbox[c3] = g_box[c3 * GT + tid];
-    int gmax = g_max[tid];
-    __syncthreads();                                // the box area becomes the candidate / work lists
-
-    if (tid == 0)
-        a.idx[0] = 0;
-    if (a.m <= 1)
-        return;                                     // the reference's loop body never runs: temp untouched
-
-    // current samples: lane i < J holds sample i (coordinates); start with point 0
-    float px = a.xyz[0], py = a.xyz[1], pz = a.xyz[2];
-    int J = 1;
-    int r = 1;                                      // samples emitted so far
-    int rstar = 0x7FFFFFFF;                         // bound on every group's runner-up (from the previous round)
-
-    auto rl = [](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto now = []() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
-
-    // ---- re-scan the first `nwork` buckets of the wave's work list, CH at a time with all their loads in
-    // flight together (a bucket's entry = table slot, set of samples that reach it) -------------------
-    // ---- re-scan the first `nwork` buckets of the wave's work list (entry = bucket, set of samples that
-    // reach it), CH at a time with all their loads in flight together.  (Fetching the next CH while the current
-    // ones are worked on was tried through a two-buffer struct: the compiler put it in scratch, 200 vs 103 ms.)
-    // `at(e)` = the two words of entry e; the wave takes entries first, first + 1, .. first + CH - 1, then `step` on
-    auto rescan_at = [&](auto at, int nwork, int first, int step) __attribute__((always_inline)) {
-        for (int w0 = first; w0 < nwork; w0 += step) {
-            FbBucket<PPL> bk[CH];
-            int tb[CH];
-            uint32_t pmv[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int e = w0 + u < nwork ? w0 + u : w0;         // a short tail repeats the first (idempotent)
-                const uint32_t *ent = at(e);
-                tb[u] = __builtin_amdgcn_readfirstlane((int)ent[0]);
-                pmv[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[1]);
-                fb_load<PPL>(bk[u], sp, skey, tb[u], lane);
-            }
-            FbCand c[CH];
-            float sc[CH];
-            int mx[CH], rx[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                c[u] = fm_apply<PPL>(bk[u], pmv[u], px, py, pz, sc[u]);
-                mx[u] = __float_as_int(c[u].t);
-            }
-            if constexpr (CH >= 4) {
-#pragma unroll
-                for (int u = 0; u < CH; u += 4)
-                    tpu3_wave_max_i32_fast_x4(mx[u], mx[u + 1], mx[u + 2], mx[u + 3]);
-            } else {
-                tpu3_wave_max_i32_fast_x2(mx[0], mx[1]);
-            }
-            bool win[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                unsigned long long t0 = __ballot(__float_as_int(c[u].t) == mx[u]);
-                if (__builtin_popcountll(t0) != 1) {      // duplicated points: smallest tie key
-                    const uint32_t k = tpu3_wave_min_u32(__float_as_int(c[u].t) == mx[u] ? c[u].key : 0xFFFFFFFFu);
-                    t0 = __ballot(__float_as_int(c[u].t) == mx[u] && c[u].key == k);
-                }
-                win[u] = lane == (int)__builtin_ctzll(t0);
-                rx[u] = __float_as_int(win[u] ? sc[u] : c[u].t);
-            }
-            if constexpr (CH >= 4) {
-#pragma unroll
-                for (int u = 0; u < CH; u += 4)
-                    tpu3_wave_max_i32_fast_x4(rx[u], rx[u + 1], rx[u + 2], rx[u + 3]);
-            } else {
-                tpu3_wave_max_i32_fast_x2(rx[0], rx[1]);
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (win[u] && (u == 0 || w0 + u < nwork)) {
-                    const int b = tb[u];
-                    if constexpr (L3) {                     // leaf entries live in global memory
-                        a.ib[0 * LS + b] = (uint32_t)mx[u]; a.ib[1 * LS + b] = c[u].key;
-                        a.ib[2 * LS + b] = __float_as_uint(c[u].x); a.ib[3 * LS + b] = __float_as_uint(c[u].y);
-                        a.ib[4 * LS + b] = __float_as_uint(c[u].z); a.ib[8 * LS + b] = (uint32_t)rx[u];
-                    } else {
-                        t_max[b] = mx[u]; t_key[b] = c[u].key; t_x[b] = c[u].x; t_y[b] = c[u].y; t_z[b] = c[u].z;
-                        t_r[b] = rx[u];
-                    }
-                }
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (u == 0 || w0 + u < nwork)
-                    fb_store<PPL>(bk[u], sp, tb[u], lane);     // stores last
-        }
-    };
-    auto rescan = [&](const uint32_t *list, int nwork) __attribute__((always_inline)) {
-        rescan_at([&](int e) __attribute__((always_inline)) { return list + 2 * e; }, nwork, 0, CH);
-    };
-
-    // ---- work off the first `nwork` entries of the wave's list (cell or bucket, set of samples reaching it) ----
-    // L3: entries = cells; `at(e)` as for rescan_at (evaluated per lane: the four rows look at four entries)
-    auto flush_cells = [&](auto at, int nwork, int first, int step) __attribute__((always_inline)) {
-        if constexpr (L3) {
-            for (int w0 = first; w0 < nwork; w0 += step) {
-                // four listed cells at a time, one per DPP row; lane `col` looks at leaf `col` of its row's cell
-                const int e = w0 + row;
-                const bool valid = e < nwork;
-                const uint32_t *ent = at(valid ? e : w0);
-                const int cell = valid ? (int)ent[0] : -1;
-                uint32_t rem = valid ? ent[1] : 0u;
-                const int leaf = valid ? cell * FB_GS + col : 0;
-                const uint32_t w0b = a.ib[5 * LS + leaf], w1b = a.ib[6 * LS + leaf], w2b = a.ib[7 * LS + leaf];
-                const float tm = __int_as_float((int)a.ib[0 * LS + leaf]);
-                const float lx = fb_half_lo(w0b), ly = fb_half_hi(w0b), lz = fb_half_lo(w1b);
-                const float hx = fb_half_hi(w1b), hy = fb_half_lo(w2b), hz = fb_half_hi(w2b);
-                uint32_t pm = 0;
-                while (__ballot(rem != 0)) {
-                    const int i = rem ? __builtin_ctz(rem) : 0;
-                    const float qx = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(px)));
-                    const float qy = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(py)));
-                    const float qz = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(pz)));
-                    pm |= (rem != 0 && fb_dbox(qx, qy, qz, lx, ly, lz, hx, hy, hz) < tm) ? (1u << i) : 0u;
-                    rem &= rem - 1;
-                }
-                const unsigned long long bt = __ballot(pm != 0);
-                if (pm != 0) {
-                    const int pos = __builtin_popcountll(bt & ((1ull << lane) - 1ull));
-                    wl2[2 * pos] = (uint32_t)leaf;
-                    wl2[2 * pos + 1] = pm;
-                }
-                rescan(wl2, __builtin_popcountll(bt));
-                // the leaves' new entries were written by lanes of this wave: make them visible to its other lanes
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                cell_from_leaves(cell, false);
-                if (PROF) pc[7] += __builtin_popcountll(bt);
-            }
-        }
-    };
-    auto flush = [&](int nwork) __attribute__((always_inline)) {
-        if constexpr (!L3)
-            rescan(wl, nwork);
-        else
-            flush_cells([&](int e) __attribute__((always_inline)) { return (const uint32_t *)(wl + 2 * e); }, nwork, 0, 4);
-    };
-
-    // ---- fold the first `nj` current samples into everything they reach -------------------------------
-    auto apply = [&](int nj) __attribute__((always_inline)) {
-        unsigned long long t0 = 0, t1 = 0;
-        if (PROF) t0 = now();
-        // 1. group prune: which samples reach this lane's group?
-        uint32_t gpm = 0;
-        for (int i = 0; i < nj; ++i)
-            gpm |= fb_dbox(rl(px, i), rl(py, i), rl(pz, i), gbox[0], gbox[1], gbox[2], gbox[3], gbox[4], gbox[5]) <
-                           __int_as_float(gmax) ? (1u << i) : 0u;
-        const unsigned long long gmask = __ballot(gpm != 0);
-        if (PROF) { t1 = now(); pc[0] += t1 - t0; t0 = t1; }
-        // 2. children tests, four touched groups (one per DPP row) at a time: every reached bucket goes on
-        //    the wave's work list together with the set of samples that reach it
-        int nwork = 0;
-        for (unsigned long long mask = gmask; mask;) {
-            int slot = -1;
-            uint32_t rem = 0;                       // the samples that reach this row's group
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                if (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)gpm, l);
-                    if (row == rr) {
-                        slot = l;
-                        rem = m;
-                    }
-                }
-            const bool valid = slot >= 0;
-            const int beta = valid ? (slot * NW + wave) * FB_GS + col : 0;
-            const uint32_t w0 = t_b0[beta], w1 = t_b1[beta], w2 = t_b2[beta];
-            const float lx = fb_half_lo(w0), ly = fb_half_hi(w0), lz = fb_half_lo(w1);
-            const float hx = fb_half_hi(w1), hy = fb_half_lo(w2), hz = fb_half_hi(w2);
-            const float tm = __int_as_float(t_max[beta]);
-            uint32_t pm = 0;
-            while (__ballot(rem != 0)) {            // every row walks ITS group's samples (usually one)
-                const int i = rem ? __builtin_ctz(rem) : 0;
-                const float qx = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(px)));
-                const float qy = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(py)));
-                const float qz = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, __float_as_int(pz)));
-                pm |= (rem != 0 && fb_dbox(qx, qy, qz, lx, ly, lz, hx, hy, hz) < tm) ? (1u << i) : 0u;
-                rem &= rem - 1;
-            }
-            const unsigned long long bt = __ballot(pm != 0);
-            const int cnt = __builtin_popcountll(bt);
-            if (nwork + cnt > 64) {                 // the list holds 64 entries: work it off first
-                flush(nwork);
-                nwork = 0;
-            }
-            if (PROF && !L3) pc[7] += cnt;
-            if (pm != 0) {
-                const int pos = nwork + __builtin_popcountll(bt & ((1ull << lane) - 1ull));
-                wl[2 * pos] = (uint32_t)beta;
-                wl[2 * pos + 1] = pm;
-            }
-            nwork += cnt;
-        }
-        if (PROF) { t1 = now(); pc[1] += t1 - t0; t0 = t1; }
-        // 3. the re-scans
-        {
-            // A sample's neighbourhood is one or two groups, i.e. one or two WAVES' lists: the round's re-scans are
-            // dealt out over all waves -- the lists stay where they are, every wave reads the others' lengths after a
-            // barrier and takes every NW-th chunk of CH entries of their concatenation; a second barrier before the
-            // owners rebuild their group entries from the bucket table.  (Two more barriers per round, but the slowest
-            // wave's re-scan time was twice the average.)
-            if (lane == 0)
-                sh.nwk[wave] = nwork;
-            __syncthreads();
-            int pre[NW + 1];
-            pre[0] = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-                pre[w + 1] = pre[w] + __builtin_amdgcn_readfirstlane(sh.nwk[w]);
-            auto at = [&](int e) __attribute__((always_inline)) {
-                int ws = 0, base = 0;
-#pragma unroll
-                for (int w = 1; w < NW; ++w) {
-                    const bool ge = e >= pre[w];
-                    ws = ge ? w : ws;
-                    base = ge ? pre[w] : base;
-                }
-                return (const uint32_t *)(work + ws * 128 + 2 * (e - base));
-            };
-            if constexpr (L3)
-                flush_cells(at, pre[NW], wave * 4, NW * 4);         // (three levels: the entries are cells)
-            else
-                rescan_at(at, pre[NW], wave * CH, NW * CH);
-            __syncthreads();
-            if (!gmask)
-                return;
-        }
-        if (PROF) { t1 = now(); pc[2] += t1 - t0; t0 = t1; }
-        // 4. rebuild the touched groups' entries
-        for (unsigned long long mask = gmask; mask;) {
-            int slot = -1;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                if (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    if (row == rr)
-                        slot = l;
-                }
-            refresh_groups(slot, false);
-        }
-        if (PROF) { t1 = now(); pc[3] += t1 - t0; }
-    };
-
-    for (int round = 0;; ++round) {
-        apply(J);
-        // ---- select the next samples ---------------------------------------------------------------
-        // (r3) With a FRESH bound.  Until round 2 the candidates were picked against the R* of the PREVIOUS round
-        // (the waves' runner-up maxima travelled through the same barrier as their candidates): valid -- bounds only
-        // fall -- but the groups sampled in a round are exactly those whose runner-up was about to become their
-        // maximum, so the stale bound sat just above the next candidates: 8.0 samples per round against 13-17 with
-        // the fresh one (simulation on the metric's merged cloud, tools/fps_cells_sim.py).  Now every wave reads
-        // ALL group entries after one barrier (8 per lane), derives R*, the candidate set and its order itself: no
-        // per-wave candidate quota, no second hand-off.
-        unsigned long long s0 = 0, s1 = 0;
-        if (PROF) s0 = now();
-        __syncthreads();                                                    // every wave's group entries are final
-        if (PROF) { s1 = now(); pc[5] += s1 - s0; s0 = s1; }
-        gmax = g_max[tid];                                                  // own group: the prune test of apply()
-        int gm[NW];
-        int rs = (int)0x80000000;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            gm[i] = g_max[i * 64 + lane];
-            rs = max(rs, g_r[i * 64 + lane]);
-        }
-        rstar = tpu3_wave_max_i32_fast(rs);
-        // candidates: groups whose best beats every group's runner-up bound, at most FM_CAP of them (a sample mask is
-        // 32 bits).  More than that qualify in a quarter of the rounds: the threshold is then raised -- any threshold
-        // >= R* is valid, the groups left out are all below the ones entered -- by a few bisection steps between R*
-        // and the largest maximum.
-        auto count_above = [&](int thr) __attribute__((always_inline)) {
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i)
-                c += __builtin_popcountll(__ballot(gm[i] > thr));
-            return c;
-        };
-        int thr = rstar;
-        int total = count_above(thr);
-        if (total > FM_CAP) {
-            int mx = gm[0];
-#pragma unroll
-            for (int i = 1; i < NW; ++i)
-                mx = max(mx, gm[i]);
-            int lo = thr, hi = tpu3_wave_max_i32_fast(mx), chi = 0;        // count(lo) > FM_CAP >= count(hi) = chi
-            for (int it = 0; it < 6 && hi - lo > 1; ++it) {
-                const int mid = lo + ((hi - lo) >> 1);
-                const int c = count_above(mid);
-                if (c > FM_CAP) {
-                    lo = mid;
-                } else {
-                    hi = mid; chi = c;
-                }
-            }
-            thr = hi; total = chi;
-            if (PROF && tid == 0) sh.stat[2] += 1;
-        }
-        uint32_t *cl = cand + wave * FM_CAP;                                // entry numbers of the candidates, entry order
-        {
-            int base = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const bool c = gm[i] > thr;
-                const unsigned long long cm = __ballot(c);
-                if (c)
-                    cl[base + __builtin_popcountll(cm & ((1ull << lane) - 1ull))] = (uint32_t)(i * 64 + lane);
-                base += __builtin_popcountll(cm);
-            }
-        }
-        if (PROF) { s1 = now(); pc[4] += s1 - s0; s0 = s1; }
-        const bool live = lane < total;
-        const unsigned long long lm = __ballot(live);
-        const int left = a.m - r;
-        uint32_t okey;                              // tie key of sample `lane` of this round (lanes < J)
-        bool multi = total >= 1;                    // (a single candidate is the unique global maximum)
-        int cM = (int)0x80000000;
-        uint32_t cK = 0xFFFFFFFFu;
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        int rank = 0;
-        if (multi) {
-            // every wave ranks the candidate list on its own (no further synchronisation)
-            if (live) {
-                const int e = (int)cl[lane];
-                cM = g_max[e]; cK = g_key[e];
-                cx = g_x[e]; cy = g_y[e]; cz = g_z[e];
-            }
-            bool tie = false;
-            for (unsigned long long mm = lm; mm;) {
-                const int i = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const int mi = __builtin_amdgcn_readlane(cM, i);
-                rank += mi > cM ? 1 : 0;
-                tie |= (mi == cM && i != lane);
-            }
-            // equal maxima among candidates (rare): order them by the reference's tie key
-            if (__ballot(live && tie)) {
-                rank = 0;
-                for (unsigned long long mm = lm; mm;) {
-                    const int i = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const int mi = __builtin_amdgcn_readlane(cM, i);
-                    const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)cK, i);
-                    rank += (mi > cM || (mi == cM && ki < cK)) ? 1 : 0;
-                }
-                if (PROF && tid == 0) sh.stat[3] += 1;
-            }
-        }
-        if (!multi) {
-            // no group beats R* (ties at the top: duplicated points): the plain arg-max over all groups with the
-            // reference's tie rule -- the lane's best entry first, then across the wave
-            int bm = gm[0], be = lane;
-            uint32_t bk = g_key[lane];
-#pragma unroll
-            for (int i = 1; i < NW; ++i) {
-                const uint32_t ki = g_key[i * 64 + lane];
-                if (gm[i] > bm || (gm[i] == bm && ki < bk)) {
-                    bm = gm[i]; bk = ki; be = i * 64 + lane;
-                }
-            }
-            int wl_;
-            (void)tpu3_wave_argmax(bm, bk, wl_);
-            const int we = __builtin_amdgcn_readlane(be, wl_);
-            px = g_x[we]; py = g_y[we]; pz = g_z[we];
-            okey = g_key[we];
-            J = 1;
-        } else {
-            // into rank order: lane `rank` receives this candidate (dead lanes keep to themselves, behind)
-            const int deadpos = total + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
-            const int dst = (live ? rank : deadpos) * 4;
-            auto perm = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(v))); };
-            px = perm(cx); py = perm(cy); pz = perm(cz);
-            okey = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cK);
-            const int sM = __builtin_amdgcn_ds_permute(dst, cM);
-            int jmax = total < left ? total : left;
-            // longest prefix in which no member's best point lies inside the update ball of an earlier member
-            // (then that point keeps its distance, and every other point of its cell can only fall)
-            for (int i = 0; i + 1 < jmax; ++i) {
-                const float d = tpu3_sqdist3(px - rl(px, i), py - rl(py, i), pz - rl(pz, i));
-                const unsigned long long hit = __ballot(lane > i && lane < jmax && d < __int_as_float(sM));
-                if (hit) {
-                    const int f = __builtin_ctzll(hit);
-                    jmax = f < jmax ? f : jmax;
-                }
-            }
-            J = jmax;
-        }
-        if (J > left)
-            J = left;
-        if (wave == 0 && lane < J)
-            a.idx[r + lane] = tpu3_fps_tiekey_to_index(okey, lb);
-        if (PROF && tid == 0) { sh.stat[0] += 1; sh.stat[1] += (uint32_t)J; sh.stat[4] += (uint32_t)total; }
-        if (PROF) { s1 = now(); pc[6] += s1 - s0; }
-        r += J;
-        if (r >= a.m) {
-            if (J > 1)
-                apply(J - 1);                           // every sample but the last one updates `temp`
-            break;
-        }
-    }
-    if (PROF && tid == 0 && a.prof)
-        for (int i = 0; i < 8; ++i)
-            a.prof[i] = sh.stat[i];
-    if (PROF && lane == 0 && a.prof)
-        for (int i = 0; i < 8; ++i)
-            a.prof[8 + wave * 8 + i] = pc[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// Point sets that fit the register file (n <= 25 600): the same exact pruning with the points held
-// in VGPRs.  One 16-wave workgroup per set; a ROW is 64 consecutive points of the Morton order (a
-// compact region, = one bucket of the init kernel) and row r belongs to wave r % 16, slot r / 16
-// (lane l holds point 64 r + l: x, y, z, running distance), so the handful of neighbouring rows a
-// sample touches are re-scanned by different waves in parallel.  Per round lane j of a wave tests row j's
-// AABB (kept in that lane's registers together with the row's current maximum); only touched rows
-// are re-scanned -- the row index is wave-uniform, so the register array is addressed by scalar
-// branches -- and publish (max, tie key, xyz of that point) to a row table in LDS.  The register-
-// resident kernel of fps.hip spends 25 points x 10 VALU ops per lane and round on the same sets
-// (2.0 us per round, all 16 waves busy); here a round touches ~2 rows of the whole set.
-// ---------------------------------------------------------------------------------------------
 template <int I, int N, typename F>
 __device__ __forceinline__ void rb_static_for(F &&f)
 {
@@ -2458,23 +1851,20 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.l3 = p.nb > FB_NB_MAX;
     if (p.l3 && p.nb > FB_NB_MAX * FB_GS)
         return false;
-    // waves per workgroup: 8 (two per SIMD: a round's re-scans spread over twice the waves: 103 -> 84 ms for
-    // 239 616 -> 80 000) when the LDS tables fit next to eight waves' work lists, else 4.  TPU3_FM_NW=4 (tuning hook).
-    static const int fm_nw = getenv("TPU3_FM_NW") ? atoi(getenv("TPU3_FM_NW")) : 8;
-    for (p.nw = fm_nw == 4 ? 4 : 8;; p.nw = 4) {
-        const int unit = FB_GS * p.nw * (p.l3 ? FB_GS : 1);                         // whole groups per wave
+    // (bucket-table geometry of the register-resident kernels' setup: 64-point buckets, groups of 16)
+    p.nw = 8;
+    {
+        const int unit = FB_GS * p.nw * (p.l3 ? FB_GS : 1);
         p.nbpad = (p.nb + unit - 1) / unit * unit;
         p.ncell = p.l3 ? p.nbpad / FB_GS : p.nbpad;
-        if (p.nw == 4 || fm_lds_bytes(p.ncell, p.nw) <= 160 * 1024)
-            break;
     }
     p.ng = p.ncell / FB_GS;
     p.npad = p.nb * bsz;
-    // 25 601 .. 262 144 points: the tile form; beyond (config C5), its three-level variant.  TPU3_FL=0 / TPU3_FL=1
-    // (tuning hooks): the 64-point-bucket kernel instead for all / for the three-level sizes.
-    static const int use_fl = getenv("TPU3_FL") ? atoi(getenv("TPU3_FL")) : 2;
+    // beyond the register-resident limit: the tile form (two levels up to 262 144 points, three up to 4 194 304)
     p.ntile = (n + FL_TP - 1) / FL_TP;
-    p.fl = use_fl && !p.rb_rows && (!p.l3 || (use_fl >= 2 && p.ntile <= FL_TMAX));
+    p.fl = !p.rb_rows;
+    if (p.fl && p.ntile > FL_TMAX)
+        return false;
     p.fl_rec = p.fl_bm = p.fl_ba = p.fl_tt = 0;
     if (p.fl) {
         p.npad = p.ntile * FL_TP;
@@ -2549,25 +1939,6 @@ unsigned long long *g_level_stats = nullptr;
 // rounds) of its first set, see tpu3_debug_fps_tile_stats
 unsigned long long *g_tile_stats = nullptr;
 
-template <int PPL, bool PROF>
-int fb_launch_main(hipStream_t s, int b, const FbArgs &a0, const FbPlan &p)
-{
-    if (p.ngpt != 1)
-        return TPU3_ELIMIT;
-    const size_t lds = fm_lds_bytes(p.ncell, p.nw);
-    auto kern = p.nw == 8 ? (p.l3 ? fm_main_kernel<8, PPL, PROF, true> : fm_main_kernel<8, PPL, PROF, false>)
-                          : (p.l3 ? fm_main_kernel<4, PPL, PROF, true> : fm_main_kernel<4, PPL, PROF, false>);
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess)
-        return (int)e;
-    const hipEvent_t e0 = g_ev_start, e1 = g_ev_stop;
-    g_ev_start = g_ev_stop = nullptr;
-    if (e0) (void)hipEventRecord(e0, s);
-    hipLaunchKernelGGL(kern, dim3(b), dim3(p.nw * 64), lds, s, a0);
-    if (e1) (void)hipEventRecord(e1, s);
-    return tpu3_launch_status();
-}
-
 int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32_t *m_arr, const float *xyz,
            float *temp, int32_t *idx, void *workspace, size_t workspace_bytes, unsigned long long *prof)
 {
@@ -2602,7 +1973,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
     a0.bbox = (float *)(slabs + 5 * p.ps + 9 * p.bs);
     a0.per_elem = p.per_elem;
     a0.sort_stride = p.ks / 4;
-    a0.fl = (p.fl && !prof) ? 1 : 0;
+    a0.fl = p.fl ? 1 : 0;
     a0.ntile = p.ntile;
     {
         char *f = slabs + 5 * p.ps + 9 * p.bs + align256(8 * sizeof(float));
@@ -2641,9 +2012,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
     }
     hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
-    // TPU3_RL=0 (tuning hook): without the lane-per-bucket kernel sets beyond 7 rows per wave take fm_main_kernel
-    static const int use_rl = getenv("TPU3_RL") ? atoi(getenv("TPU3_RL")) : 1;
-    if (p.rb_rows && !prof && p.ppl == 1 && use_rl && n > 1024 * 4 && m >= 256) {
+    if (p.rb_rows && n > 1024 * 4 && m >= 256) {
         // a lane per bucket of R Morton-consecutive points (rl_main_kernel)
         a0.prof = g_level_stats;
         g_level_stats = nullptr;
@@ -2671,7 +2040,10 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
 #undef RL_LAUNCH
         return tpu3_launch_status();
     }
-    if (p.rb_rows && p.rb_rows <= 7 && !prof && p.ppl == 1) {
+    if (p.rb_rows > 7)
+        return TPU3_ELIMIT;     // (up to 25 600 points with fewer than 256 samples: fps.hip keeps those on its
+                                // plain register-resident kernel and never asks for a bucket plan)
+    if (p.rb_rows) {
         // small sets, one sample per round: rows (= 64-point buckets) in VGPRs, no write-back pass
         hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
         const size_t lds1 = rb_lds_bytes(p.rb_rows);
@@ -2723,12 +2095,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);
         return tpu3_launch_status();
     }
-    hipLaunchKernelGGL(fb_bucket_init_kernel<1>, dim3((p.nbpad + 3) / 4, b), dim3(256), 0, s, a0);
-    const int r = prof ? fb_launch_main<1, true>(s, b, a0, p) : fb_launch_main<1, false>(s, b, a0, p);
-    if (r)
-        return r;
-    hipLaunchKernelGGL(fb_writeback_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, a0);
-    return tpu3_launch_status();
+    return TPU3_ELIMIT;         // (unreachable: every plan above returns)
 }
 
 } // namespace
@@ -2773,36 +2140,29 @@ extern "C" int tpu3_debug_fps_cluster(int g)
 }
 
 // Which kernel family a call of this shape takes (the dispatch table of DESIGN section 4 as code; tests pin it):
-// 0 streaming / resident (fps.hip), 1 rb_main (rows in registers, one sample per round), 2 rl_main (lane per bucket),
-// 3 fm_main (64-point buckets), 4 fl_main two levels, 5 fl_main three levels, 6 the cluster form; *cluster = its G.
+// 0 plain register-resident / streaming (fps.hip), 1 rb_main (rows in registers, one sample per round), 2 rl_main (lane
+// per bucket), 4 fl_main two levels, 5 fl_main three levels, 6 the cluster form (fps_cluster.hip); *cluster = its G.
 extern "C" int tpu3_debug_fps_plan(int b, int n, int m, int *cluster)
 {
     FbPlan p;
     if (cluster) *cluster = 0;
+    // (the front of tpu3_fps_ragged_f32, csrc/fps.hip: up to 25 600 points the bucketed kernels are taken from 4096
+    // points and 256 samples on; TPU3_FPS_BUCKET_MIN_N moves the first threshold)
+    static const int min_n = getenv("TPU3_FPS_BUCKET_MIN_N") ? atoi(getenv("TPU3_FPS_BUCKET_MIN_N")) : 4096;
+    if (n <= RB_MAX_N && !(n >= min_n && m >= 256))
+        return 0;
     if (!fb_plan(b, n, p))
         return -1;
-    if (p.rb_rows && n > 1024 * 4 && m >= 256)
+    if (p.rb_rows && n > 1024 * 4)
         return 2;
-    if (p.rb_rows && p.rb_rows <= 7)
-        return 1;
-    if (p.fl) {
-        if (cluster) *cluster = p.cluster;
-        return p.cluster ? 6 : (p.l3 ? 5 : 4);
-    }
-    return 3;
+    if (p.rb_rows)
+        return p.rb_rows <= 7 ? 1 : -1;
+    if (cluster) *cluster = p.cluster;
+    return p.cluster ? 6 : (p.l3 ? 5 : 4);
 }
 
 extern "C" int tpu3_debug_fps_tile_stats(unsigned long long *stats)
 {
     g_tile_stats = stats;
     return TPU3_OK;
-}
-
-// Development probe (not part of include/tpu3.h): the same kernel with per-phase cycle counters;
-// prof = NW x 8 u64: [prune+rescan+refresh, argmax, barrier wait, broadcast, -, buckets, group batches, -].
-extern "C" int tpu3_debug_fps_bucket_profile(void *stream, int n, int m, const float *xyz, float *temp,
-                                             int32_t *idx, void *workspace, size_t workspace_bytes,
-                                             unsigned long long *prof)
-{
-    return fb_run((hipStream_t)stream, 1, n, m, nullptr, nullptr, xyz, temp, idx, workspace, workspace_bytes, prof);
 }

@@ -449,8 +449,6 @@ int tpu3_scatter_add_rows_f32(tpu3_stream_t stream, int b, int n, long m, int c,
  * records `start` / `stop` (hipEvent_t created by the caller) on ITS stream immediately before / after
  * its main round-loop kernel, so that exactly that kernel can be timed on whatever stream it runs on.
  * One-shot, host-side state only.
- * tpu3_debug_fps_bucket_profile: one cloud through the same kernel with per-phase cycle counters;
- * prof (device) = waves x 8 u64.
  * tpu3_debug_fps_level_stats: the NEXT FPS call that takes the register-resident multi-sample kernel (per-level
  * resampling, 4096 < n <= 25 600) writes (rounds, samples) of its first set to stats[0..1] and, for the largest
  * sets, per-phase cycle counters of waves 0 and 1 to stats[2..13] and every wave's (update cycles, sample
@@ -468,18 +466,16 @@ int tpu3_debug_fps_tile_stats(unsigned long long *stats);
  * words: waves, tiles searched, tiles tested query by query, tiles per point set (summed over the waves).  One-shot;
  * host-side state only. */
 int tpu3_debug_knn_tiles_stats(unsigned *words);
-int tpu3_debug_fps_bucket_profile(tpu3_stream_t stream, int n, int m, const float *xyz, float *temp,
-                                  int32_t *idx, void *workspace, size_t workspace_bytes,
-                                  unsigned long long *prof);
 /* tpu3_debug_fps_cluster: workgroups per point set of the tile-form FPS for the calls that follow: -1 = the default
  * policy (several compute units per set when the launch is small: b * G <= 64, G <= 8, 16 for sets beyond 262 144
  * points), 0 = single-workgroup kernels only, 2 / 4 / 8 / 16 = forced wherever the size allows.  Returns the previous
  * setting (also: environment TPU3_FPS_CLUSTER).  With the cluster form, tpu3_debug_fps_tile_stats receives rounds,
  * samples, tie exchanges, wave 0's poll sweeps and the launch's fault count in stats[0..4].
- * tpu3_debug_fps_plan: which FPS kernel family a (b, n, m) call takes -- 0 register-resident / streaming (n <= 25 600
- * with few samples), 1 rows in registers with one sample per round, 2 a lane per bucket with several samples per
- * round (per-level resampling), 3 64-point buckets in memory, 4 / 5 the tile form on two / three levels, 6 the tile
- * form on *cluster workgroups per set; -1 beyond every plan.  The dispatch table of DESIGN section 4 as code. */
+ * tpu3_debug_fps_plan: which FPS kernel family a (b, n, m) call takes -- 0 plain register-resident / streaming (up to
+ * 25 600 points with fewer than 256 samples or fewer than 4096 points), 1 rows in registers with one sample per round
+ * (exactly 4096 points), 2 a lane per bucket with several samples per round (4097 .. 25 600 points: the per-level
+ * resampling), 4 / 5 the tile form on two / three levels, 6 the tile form on *cluster workgroups per set; -1 beyond
+ * every plan (more than 4 194 304 points).  The dispatch table of DESIGN section 4 as code. */
 int tpu3_debug_fps_cluster(int g);
 int tpu3_debug_fps_plan(int b, int n, int m, int *cluster);
 

@@ -113,10 +113,11 @@ def test_fps_dispatch_table():
         return k, cl.value
     # per-level resampling of the network (one set per outer patch): a lane per bucket, several samples per round
     assert plan(1536, 6240, 1248)[0] == 2 and plan(1536, 12480, 2496)[0] == 2 and plan(1536, 24960, 4992)[0] == 2
-    # small sets with few samples: rows in registers, one sample per round
-    assert plan(48, 4096, 300)[0] == 1 and plan(4, 7000, 100)[0] == 1
-    # mid-size sets with few samples: 64-point buckets in memory
-    assert plan(2, 20000, 100)[0] == 3
+    # up to 25 600 points with few samples (outer / inner patch seeds): the plain register-resident kernel
+    assert plan(32, 5000, 48)[0] == 0 and plan(4, 7000, 100)[0] == 0 and plan(2, 20000, 100)[0] == 0
+    assert plan(1536, 2496, 40)[0] == 0
+    # exactly 4096 points with many samples: rows in registers, one sample per round
+    assert plan(48, 4096, 300)[0] == 1
     # the metric's final FPS: one cloud (latency) on 16 members, a sub-batch of 8 on 8, the bench's 32-cloud launch on
     # one workgroup per cloud (two-level tile form)
     assert plan(1, 239616, 80000) == (6, 16) and plan(4, 239616, 80000) == (6, 16)
@@ -126,4 +127,4 @@ def test_fps_dispatch_table():
     # just above the register-resident limit: too few tiles for 16 members
     assert plan(1, 25601, 3000) == (6, 4) and plan(1, 70000, 3000) == (6, 16)
     # beyond every plan
-    assert plan(1, 5000000, 1000)[0] in (-1, 3)
+    assert plan(1, 5000000, 1000)[0] == -1
