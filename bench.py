@@ -16,11 +16,15 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL):
 The default (--gpus N, 32 clouds per GPU) is the throughput configuration of the 1-GPU line.
 
 One JSON line is printed by rank 0.  Besides the contract's keys it carries
-  roofline          dominant kernel (final FPS, fl_main_kernel): measured traffic / launch time against the
-                    HBM peak -- never above 1 -- plus us_per_sample next to a stated per-round floor; the streaming
-                    model of SURVEY 8d as `model_ratio` (the kernel skips >99 % of that model's bytes)
-  rooflines_other   every other hand-written kernel of a step, timed with events on its launch stream:
-                    MFMA kernels on EXECUTED matrix-core FLOPs, the kNN graph on the (2C+3) VALU model
+  roofline          the kernel that BOUNDS the step: the largest entry of `rooflines_other` by ms_per_step (round 4:
+                    dec_fused4_kernel, fp32 MFMA) with per-launch averages and the PMC traffic per launch
+  roofline_step     the whole step against the chip: executed MFMA FLOP and counter bytes / ms_per_step
+  rooflines_other   every hand-written kernel of a step, timed with events on its launch stream: MFMA kernels on
+                    EXECUTED matrix-core FLOPs, the kNN graph on the (2C+3) VALU model, HBM kernels on algorithmic
+                    bytes; the final FPS as a LATENCY entry (rounds, us_per_round, x_over_floor -- it runs hidden on
+                    a side stream and bounds nothing)
+  rooflines_train   config C3 (one optimisation step, B = 32, ratio 16, eager): the training kernels by time, the
+                    dominant one against its bound
   cpu_baseline      config C1 in full on the host cores (oracle/cpu_baseline.py), per-stage times
   parity            config C1 through the HIP path and through the oracle-driven CPU path on the same cloud:
                     chamfer_vs_oracle, set_close_1e-5  ("Chamfer vs ref" half of the metric)
@@ -51,7 +55,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TF = 157.3           # fp32 vector = fp32 MFMA dense peak
 F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA peak
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_traffic.json")
+PROFILE_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json")]
 
 
 def pkg(sub=None):
@@ -338,6 +342,81 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
     return ex
 
 
+def train_rooflines(ops, ups, dev, ratio=16, reps=3):
+    """Config C3 (BASELINE: one training step, batch 32 patches of 312 points, up_ratio 16, Chamfer fwd + bwd): an
+    EAGER step with events around the hand-written training kernels (a hipGraph replay cannot be bracketed per
+    kernel) -> each kernel's ms per step and the dominant one against its bound."""
+    import types
+    model_mod = pkg("model")
+    be = ops.BACKEND
+    g = torch.Generator().manual_seed(7)
+    inp = torch.randn(32, 312, 3, generator=g)
+    inp = (inp / inp.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous().to(dev)
+    lab = torch.randn(32, 312 * ratio, 3, generator=g)
+    lab = (lab / lab.norm(dim=2, keepdim=True)).transpose(2, 1).contiguous().to(dev)
+    torch.manual_seed(0)
+    tnet = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5).to(dev)
+    model = model_mod.Model(tnet, "train", types.SimpleNamespace(lr_init=1e-3, ckpt=None, graph_steps=False))
+    for _ in range(2):
+        model.set_input(inp, ratio, label_pc=lab)
+        model.optimize()
+    kt = KernelTimer(be)
+    shape0 = lambda t, *a, **kw: tuple(t.shape)
+    kt.wrap("dec_train_forward", lambda x, idx, off, w: tuple(x.shape))
+    kt.wrap("dec_train_backward", lambda x, idx, off, w, arg, gy: tuple(x.shape))
+    kt.wrap("dec_train_wgrad", lambda x, S, Z, G: (S.shape[0], G.shape[0]))
+    kt.wrap("knn_graph", lambda k, x, layout=None, optimistic=None: tuple(x.shape))
+    kt.wrap("linear_wgrad_bias", lambda x, dy, want_bias=True: (x.shape[0], x.shape[1], dy.shape[1]))
+    kt.wrap("linear_dgrad", lambda dy, w: (dy.shape[0], w.shape[0], w.shape[1]))
+    kt.wrap("interlevel_skip_train", lambda xyz, feat, *a, **kw: tuple(feat.shape))
+    kt.wrap("interlevel_skip_backward", lambda gg, *a, **kw: tuple(gg.shape))
+    walls = []
+    try:
+        for _ in range(reps):
+            kt.begin_rep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.set_input(inp, ratio, label_pc=lab)
+            model.optimize()
+            torch.cuda.synchronize()
+            walls.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        kt.restore()
+    names = {"dec_train_backward": "dec_train_bwd_kernel (DenseEdgeConv block backward: recompute, route to the arg-max edges, "
+                                   "three layers back, edge operands of the weight gradients)",
+             "dec_train_forward": "dec_train_fwd_kernel", "dec_train_wgrad": "linear_wgrad_all_kernel x2 + dec_wgrad_assemble_kernel "
+             "(the block's weight gradients from the edge tensors)", "knn_graph": "knn_graph kernels (feature graphs, exact form)",
+             "linear_wgrad_bias": "linear_wgrad_all_kernel (per-point layers: dW and db in one streaming pass)",
+             "linear_dgrad": "linear_dgrad_small_kernel", "interlevel_skip_train": "skip_dist + skip_apply (weights kept)",
+             "interlevel_skip_backward": "skip_bwd_kernel"}
+    rows = []
+    for nm, label in names.items():
+        ms, shp, spread = kt.total(nm)
+        if shp:
+            rows.append({"kernel": label, "launches_per_step": len(shp), "ms_per_step": ms, "ms_per_step_min_max": spread,
+                         "_name": nm, "_shapes": shp})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    dom = None
+    for r in rows:
+        shp = r.pop("_shapes")
+        nm = r.pop("_name")
+        if nm == "dec_train_backward":
+            # what the kernel must move: per edge 36 + 48 floats of weight-gradient operands written (G, Z), per point the
+            # 24-float row and gradient in, 24 + 36 floats out -- the edge tensors are 99 % of it (107 MB per block at B = 32)
+            byt = sum(p * n * (32 * 84 + 24 + 60 + 24 + 36) * 4.0 for p, n, _ in shp)
+            ach = byt / (r["ms_per_step"] * 1e-3) / 1e9
+            r.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_step": byt,
+                      "basis": "bytes the formulation writes and reads per launch (edge operands G, Z of the weight gradients: "
+                               "336 B per edge) / launch time (HIP events)"})
+        if dom is None:
+            dom = dict(r)
+    return {"config": "C3: B=32 patches x 312 pts, up_ratio=%d (%d levels), Chamfer fwd+bwd, clip, Adam; eager step with events "
+                      "around the hand-written training kernels" % (ratio, int(np.log2(ratio))),
+            "step_ms_eager_with_events": float(np.median(walls)), "kernels": rows, "dominant": dom,
+            "kernels_ms_sum": float(sum(r["ms_per_step"] for r in rows))}
+
+
 def parity_block(ops, pipe, ups, dev, cpu_out, N=5000, npnt=312):
     """Config C1 on the device against the oracle-driven CPU output of the same cloud and weights."""
     from oracle import cpu_baseline
@@ -548,47 +627,46 @@ def main():
 
     if rank == 0:
         traffic = None
-        try:
-            with open(PROFILE_TRAFFIC) as f:
-                traffic = json.load(f)
-        except (OSError, ValueError):
-            pass
+        for path in PROFILE_TRAFFIC:
+            try:
+                with open(path) as f:
+                    traffic = json.load(f)
+                traffic["_file"] = os.path.relpath(path, ROOT)
+                break
+            except (OSError, ValueError):
+                pass
         P = pipe.num_outer_patches(N, npnt, 3)
         n_merged = P * npnt * r
         m_out = N * r
         CL = min(args.sub_batch, -(-C // max(1, args.net_streams))) if split else C      # clouds per launch
-        # --- dominant kernel: the final FPS.  Its honest HBM figure is what the PMC counters saw cross the
-        # L2/fabric boundary (profiles/, FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the guide) over the
-        # launch time measured HERE with events on the kernel's own stream.  The streaming model of SURVEY 8d
-        # (20 B per point per round) is reported as model_ratio: the kernel prunes >99 % of that work, so the
-        # ratio may exceed 1 and is NOT a roofline fraction.
+        # --- the final FPS (main.py:379-380): a LATENCY entry.  It runs on a side stream under the next step's network
+        # stages and bounds nothing in this configuration; what describes it is the dependent chain per round.  Its HBM
+        # figure (PMC traffic / launch time) and SURVEY 8d's streaming model (20 B per point per round, of which the
+        # kernel skips > 99 %) are reported next to it, neither as a roofline fraction of the step.
         tr = None
         if traffic and traffic.get("clouds_per_launch") == CL and (N, npnt, r) == (5000, 312, 16):
             tr = traffic.get("traffic_bytes_per_launch")
         model_bytes = 20.0 * CL * n_merged * (m_out - 1)
-        roof = {"kernel": "fl_main_kernel (tile-form FPS, a lane per 16-point bucket): final FPS %d->%d, %d cloud(s) per launch"
-                          % (n_merged, m_out, CL),
-                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tr,
-                "achieved": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
-                "basis": "measured fabric traffic of one launch (PMC, profiles/r03_traffic.json) / launch time (HIP events "
-                         "on the kernel's stream)",
-                "traffic_provenance": (traffic or {}).get("provenance"),
-                "launch_ms": fps_ms, "operator_ms": op_ms,
-                "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
-                "us_per_round_floor": 2.5,
-                "previous_round": {"kernel": "fm_main_kernel", "launch_ms": 121.8, "traffic": 27.19e9, "frac": 0.028,
-                                   "note": "both factors of `achieved` fell: the launch takes 0.47x the time and moves "
-                                           "0.41x the bytes, so the HBM fraction of this latency-bound kernel went DOWN "
-                                           "while it got 2.1x faster; us_per_sample is the figure that tracks its speed"},
-                "floor_note": "a round (~38 samples of a cloud) is one dependent chain on ONE compute unit: tile prune -> "
-                              "bucket records of the reached tiles (L2 trip) -> the reached buckets' points (L2 trip) -> "
-                              "candidate list -> the ranked candidates' coordinates (L2 trip) -> clearance, with five "
-                              "workgroup barriers; three trips of ~0.5 us + ~1 us of instruction issue = 2.5 us per ROUND; "
-                              "us_per_sample = launch time / samples per cloud (the clouds of a launch run side by side)",
-                "model_bytes_per_launch": model_bytes,
-                "model_ratio": (model_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fps_ms else None,
-                "compulsory_bytes_per_launch": float(CL) * (12.0 * n_merged + 4.0 * m_out)}
-        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        kind = ctypes.c_int(0)
+        plan = tlib.tpu3_debug_fps_plan(CL, n_merged, m_out, ctypes.byref(kind))
+        fps_entry = {
+            "kernel": ("fc_main_kernel (tile-form FPS on %d workgroups per cloud)" % kind.value if plan == 6 else
+                       "fl_main_kernel (tile-form FPS, one workgroup per cloud)")
+            + ": final FPS %d->%d, %d cloud(s) per launch, on a side stream under the next step" % (n_merged, m_out, CL),
+            "bound": "latency", "launch_ms": fps_ms, "operator_ms": op_ms,
+            "us_per_sample": (fps_ms * 1e3 / (m_out - 1)) if fps_ms else None,
+            "hbm": {"traffic_bytes_per_launch": tr, "traffic_file": (traffic or {}).get("_file"),
+                    "traffic_provenance": (traffic or {}).get("provenance"),
+                    "achieved_GBps": (tr / (fps_ms * 1e-3) / 1e9) if (tr and fps_ms) else None,
+                    "frac_of_8TBps": (tr / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr and fps_ms) else None,
+                    "compulsory_bytes_per_launch": float(CL) * (12.0 * n_merged + 4.0 * m_out),
+                    "survey_streaming_model_bytes_per_launch": model_bytes},
+            "floor_model": "a round (~39 exact samples of a cloud) is ONE dependent chain: tile prune -> bucket records of "
+                           "the reached tiles (L2 trip) -> the reached buckets' points (L2 trip) -> candidate list -> the "
+                           "ranked candidates' coordinates (L2 trip) -> clearance, with five workgroup barriers: three "
+                           "trips of ~0.5 us + ~1 us of instruction issue = 2.5 us per round (a model of THIS algorithm on "
+                           "one compute unit, not a hardware bound)",
+            "us_per_round_floor": 2.5}
         total_points = total_clouds * N * r * args.steps
         line = {
             "metric": ("INVALID-DIAGNOSTIC " if args.diag_skip_final_fps else "")
@@ -613,7 +691,6 @@ def main():
                             "zero communication until ONE all-gather of the finished clouds (%.1f MB of fp32 xyz) per "
                             "step over RCCL / xGMI, issued on the final-FPS side stream"
                             % (world, C, world * C * 3 * N * r * 4 / 1e6))) if multi else "single GPU"},
-            "roofline": roof,
         }
         if comm is not None:
             line["comm"] = comm
@@ -622,9 +699,75 @@ def main():
             host = out.detach().cpu().contiguous().numpy()
             line["result_digest"] = [hashlib.sha256(host[i].tobytes()).hexdigest() for i in range(host.shape[0])]
         do_extras = not args.no_extras and world == 1 and not args.diag_skip_final_fps
+        others = []
+        if not args.no_extras and not args.diag_skip_final_fps and not patch_mode:
+            # (rank 0 only, untimed: the other ranks wait at the final barrier)
+            others = other_rooflines(ops, pipe, net, clouds, npnt, r, traffic)
+            # rounds / samples of one final-FPS set (development counters of the tile form; untimed)
+            try:
+                merged = pipe.upsample(net, clouds[:CL], npnt, r, 3, final_fps=False, check_small=False,
+                                       optimistic_graph=True).transpose(2, 1).contiguous()
+                st = torch.zeros(32, dtype=torch.int64, device=dev)
+                tlib.tpu3_debug_fps_tile_stats(ctypes.c_void_p(st.data_ptr()))
+                ops.fps(merged, m_out)
+                torch.cuda.synchronize()
+                rounds, samples = int(st[0]), int(st[1])
+                del merged
+                if rounds and fps_ms:
+                    fps_entry.update({"rounds": rounds, "samples_per_round": samples / rounds,
+                                      "us_per_round": fps_ms * 1e3 / rounds,
+                                      "x_over_floor": fps_ms * 1e3 / rounds / fps_entry["us_per_round_floor"]})
+            except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
+                fps_entry["rounds"] = "failed: %s" % (str(e).splitlines()[0][:120])
+        line["rooflines_other"] = others + [fps_entry]
+        # --- `roofline`: the kernel that bounds the step = the largest entry by ms_per_step that has a hardware bound
+        bounded = [o for o in others if o.get("frac") is not None]
+        if bounded:
+            top = max(bounded, key=lambda o: o["ms_per_step"])
+            import re
+            mlaunch = re.search(r"(\d+) launches/step", top["kernel"])
+            nl = int(mlaunch.group(1)) if mlaunch else None
+            work = top.get("executed_flop_per_step", top.get("model_flop_per_step", top.get("algorithmic_bytes_per_step")))
+            roof = {"kernel": top["kernel"], "bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"],
+                    "unit": top["unit"], "frac": top["frac"],
+                    "traffic": (top["traffic"] / nl) if (top.get("traffic") and nl) else None,
+                    "selected": "largest kernel of the step by ms_per_step among rooflines_other (median of 5 untimed "
+                                "single-stream steps, HIP events on the launch stream)",
+                    "basis": top["basis"], "launches_per_step": nl, "ms_per_step": top["ms_per_step"],
+                    "avg_launch_ms": (top["ms_per_step"] / nl) if nl else None,
+                    "algorithmic_work_per_launch": (work / nl) if (work and nl) else None,
+                    "traffic_bytes_per_step": top.get("traffic"), "traffic_file": (traffic or {}).get("_file"),
+                    "traffic_provenance": (traffic or {}).get("provenance")}
+            if "useful_frac" in top:
+                roof["useful_frac"] = top["useful_frac"]
+            line["roofline"] = roof
+            # --- the whole step against the chip
+            flop = sum(o.get("executed_flop_per_step", 0.0) for o in others)
+            byts = [o.get("traffic") for o in others if o.get("traffic")]
+            tsum = float(sum(byts)) + (tr or 0.0)
+            ms_step = elapsed / args.steps * 1e3
+            line["roofline_step"] = {
+                "ms_per_step": ms_step, "executed_mfma_flop_per_step": flop,
+                "mfma_TFLOPs": flop / (ms_step * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms_step * 1e-3) / 1e12 / FP32_PEAK_TF,
+                "counter_bytes_per_step": tsum if byts else None,
+                "hbm_GBps": (tsum / (ms_step * 1e-3) / 1e9) if byts else None,
+                "frac_of_hbm_peak": (tsum / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if byts else None,
+                "kernels_ms_sum_single_stream": float(sum(o["ms_per_step"] for o in others)),
+                "note": "executed matrix-core FLOP of the three MFMA kernels and the PMC traffic (FETCH_SIZE x 2 + "
+                        "WRITE_SIZE, %s) of every profiled kernel incl. one final-FPS launch, over the TIMED ms_per_step: the "
+                        "step is bound by VALU issue and dependent chains (kNN selection, FPS), not by either peak"
+                        % ((traffic or {}).get("_file"),)}
+        else:
+            # (profiling runs with --no_extras: no per-kernel events -- the latency entry stands in, explicitly unbounded)
+            line["roofline"] = {"kernel": fps_entry["kernel"], "bound": "latency", "achieved": None, "peak": None,
+                                "unit": None, "frac": None, "traffic": tr, "launch_ms": fps_ms,
+                                "note": "no per-kernel events in this run (--no_extras / sharded patches)"}
         if do_extras:
-            line["rooflines_other"] = other_rooflines(ops, pipe, net, clouds, npnt, r, traffic)
             line["extras"] = extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r)
+            try:
+                line["rooflines_train"] = train_rooflines(ops, ups, dev)
+            except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
+                line["rooflines_train"] = "failed: %s" % (str(e).splitlines()[0][:160])
             assert ops.BACKEND.graph_dup_events() == 0 and int(net.small_cloud_events) == 0, \
                 "an optimistic kNN graph / small-cloud event in the untimed extras: their numbers are not final"
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (bench contract)
