@@ -475,268 +475,18 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
     skip_apply_body<K, VEC, TAIL, T>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, a.dist, a.mins);
 }
 
-// ---------------------------------------------------------------------------------------------
-// (r4) A DPP ROW of 16 lanes per point, four points per wave step.
-//
-// A wave per point spends most of its instructions on what is per POINT rather than per channel: K wave-wide
-// reductions of the feature distances (7 instructions each for ONE point), the spatial distances, the weights' two
-// exponentials and two divisions, the 64-bit row addresses.  With a row of 16 lanes per point a lane holds
-// ceil(C / 64) float4 of each row (4 + a masked fifth for 264 channels), the same instructions serve FOUR points,
-// a reduction is 4 DPP steps inside the rows (all four points at once), and lane k of a row evaluates neighbour k's
-// spatial distance and weight, broadcast with row_newbcast.  Memory access stays coalesced: a load instruction reads
-// 16 lanes x 16 B = 256 contiguous bytes of each of four rows.  Same arithmetic per element as the wave-per-point
-// kernels; the feature-distance and weight sums are taken in another order (1e-7 relative: inside the 1e-5 bar
-// against the unfused formulation, tests/test_hip_network.py::test_interlevel_skip_*).
-// ---------------------------------------------------------------------------------------------
-constexpr int SKR_SLOTS = 5;            // float4 slots per lane: C <= 320
-
-template <int CTRL>
-__device__ __forceinline__ float skr_dpp_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-// sum / minimum over the 16 lanes of each row, result in every lane of the row
-__device__ __forceinline__ float skr_row_sum(float v)
-{
-    v += skr_dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
-    v += skr_dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
-    v += skr_dpp_f<0x141>(v);       // row_half_mirror
-    v += skr_dpp_f<0x140>(v);       // row_mirror
-    return v;
-}
-__device__ __forceinline__ float skr_row_min(float v)
-{
-    v = fminf(v, skr_dpp_f<0xB1>(v));
-    v = fminf(v, skr_dpp_f<0x4E>(v));
-    v = fminf(v, skr_dpp_f<0x141>(v));
-    v = fminf(v, skr_dpp_f<0x140>(v));
-    return v;
-}
-// lane KK of each row to all 16 lanes of the row (row_newbcast)
-template <int KK>
-__device__ __forceinline__ int skr_bcast_i(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x150 + KK, 0xF, 0xF, false);
-}
-template <int KK>
-__device__ __forceinline__ float skr_bcast_f(float v) { return __int_as_float(skr_bcast_i<KK>(__float_as_int(v))); }
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void skr_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        skr_for<I + 1, N>(f);
-    }
-}
-
-// the point group of a wave step: row r of the wave -> point i0 + r (clamped; `live` = it exists)
-template <int K, typename T>
-struct SkrCtx {
-    int b, pb, n, C4, i_lo, i_hi;
-    const float *XYZ, *PX;
-    T *F;
-    const T *PF;
-};
-
-template <int K, typename T>
-__device__ __forceinline__ SkrCtx<K, T> skr_ctx(const SkipArgs &a, T *feat_p, const T *prev_p)
-{
-    SkrCtx<K, T> c;
-    int slice;
-    skip_item(a, c.b, slice);
-    c.pb = a.pts_of ? a.pts_of[c.b] : c.b;
-    c.n = a.n;
-    c.C4 = a.c >> 2;
-    c.i_lo = slice * a.slice_len;
-    c.i_hi = min(a.n, c.i_lo + a.slice_len);
-    c.XYZ = a.xyz + (size_t)c.b * a.n * 3;
-    c.PX = a.prev_xyz + (size_t)c.pb * a.m * 3;
-    c.F = feat_p + (size_t)c.b * a.n * a.feat_stride;
-    c.PF = prev_p + (size_t)c.pb * a.m * a.c;
-    return c;
-}
-
-// the K neighbour rows of this lane's point, every lane of the row holding all K (lane k < K loads index k)
-template <int K>
-__device__ __forceinline__ void skr_neighbours(const SkipArgs &a, const void *idx_p, size_t io, int col, int (&nb)[K])
-{
-    const int kc = min(col, K - 1);
-    int mine = a.idx64 ? (int)((const long long *)idx_p)[io + kc] : ((const int *)idx_p)[io + kc];
-    mine = min(max(mine, 0), a.m - 1);
-    skr_for<0, K>([&](auto kk) __attribute__((always_inline)) { nb[decltype(kk)::value] = skr_bcast_i<decltype(kk)::value>(mine); });
-}
-
-template <int K, typename T>
-__global__ __launch_bounds__(SK_THREADS) void skip_dist_row_kernel(SkipArgs a)
-{
-    const SkrCtx<K, T> c = skr_ctx<K, T>(a, (T *)a.feat, (const T *)a.prev_feat);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, col = lane & 15;
-    float2 *DS = (float2 *)a.dist + (size_t)c.b * c.n * K;
-    float2 *MN = (float2 *)a.mins + (size_t)c.b * c.n;
-    // float4 slots of this lane: f = 16 j + col, live while f < C4 (the index is clamped, the value zeroed)
-    int fj[SKR_SLOTS];
-    bool fl[SKR_SLOTS];
-#pragma unroll
-    for (int j = 0; j < SKR_SLOTS; ++j) {
-        fl[j] = 16 * j + col < c.C4;
-        fj[j] = min(16 * j + col, c.C4 - 1);
-    }
-    const int nslot = (c.C4 + 15) >> 4;
-    constexpr int WAVES = SK_THREADS / 64;
-    for (int i0 = c.i_lo + 4 * wave; i0 < c.i_hi; i0 += 4 * WAVES) {
-        const bool live = i0 + row < c.i_hi;
-        const int i = live ? i0 + row : c.i_hi - 1;
-        int nb[K];
-        skr_neighbours<K>(a, a.idx, ((size_t)c.b * c.n + i) * K, col, nb);
-        // own row (streamed: non-temporal) and the small loads: lane k < K the neighbour's xyz, lane 8 the point's own
-        sk_f4 x[SKR_SLOTS];
-        const T *X4 = c.F + (size_t)i * a.feat_stride;
-#pragma unroll
-        for (int j = 0; j < SKR_SLOTS; ++j)
-            if (j < nslot)
-                x[j] = sk_ld4<true>(X4, fj[j]);
-        int mynb = nb[0];
-        skr_for<1, K>([&](auto kk) __attribute__((always_inline)) { mynb = col == decltype(kk)::value ? nb[decltype(kk)::value] : mynb; });
-        const float *pp = col < 8 ? c.PX + (size_t)mynb * 3 : c.XYZ + (size_t)i * 3;
-        const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
-        // feature distances, the rows of neighbour k + 1 in flight while neighbour k is consumed
-        sk_f4 r[2][SKR_SLOTS];
-#pragma unroll
-        for (int j = 0; j < SKR_SLOTS; ++j)
-            if (j < nslot)
-                r[0][j] = sk_ld4<false>(c.PF + (size_t)nb[0] * a.c, fj[j]);
-        float mine_f = 0.f, fmin_ = 0.f;
-        skr_for<0, K>([&](auto kk) __attribute__((always_inline)) {
-            constexpr int k = decltype(kk)::value;
-            if constexpr (k + 1 < K) {
-#pragma unroll
-                for (int j = 0; j < SKR_SLOTS; ++j)
-                    if (j < nslot)
-                        r[(k + 1) & 1][j] = sk_ld4<false>(c.PF + (size_t)nb[k + 1] * a.c, fj[j]);
-            }
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < SKR_SLOTS; ++j)
-                if (j < nslot) {
-                    float t = 0.f, d;
-                    d = x[j].x - r[k & 1][j].x; t = __builtin_fmaf(d, d, t);
-                    d = x[j].y - r[k & 1][j].y; t = __builtin_fmaf(d, d, t);
-                    d = x[j].z - r[k & 1][j].z; t = __builtin_fmaf(d, d, t);
-                    d = x[j].w - r[k & 1][j].w; t = __builtin_fmaf(d, d, t);
-                    s += fl[j] ? t : 0.f;
-                }
-            const float f = skr_row_sum(s);
-            fmin_ = k == 0 ? f : fminf(fmin_, f);
-            mine_f = col == k ? f : mine_f;
-        });
-        // spatial distance in lane k of the row: (dx^2 + dy^2) + dz^2, like torch.sum over 3 channels
-        const float qx = skr_bcast_f<8>(p0), qy = skr_bcast_f<8>(p1), qz = skr_bcast_f<8>(p2);
-        const float dx = qx - p0, dy = qy - p1, dz = qz - p2;
-        const float sp = (dx * dx + dy * dy) + dz * dz;
-        const float smin_ = skr_row_min(col < K ? sp : __builtin_inff());
-        if (live && col < K)
-            DS[(size_t)i * K + col] = make_float2(sp, mine_f);
-        if (live && col == 0)
-            MN[i] = make_float2(smin_, fmin_);
-    }
-}
-
-template <int K, typename T>
-__global__ __launch_bounds__(SK_THREADS) void skip_apply_row_kernel(SkipArgs a)
-{
-    const SkrCtx<K, T> c = skr_ctx<K, T>(a, (T *)a.feat, (const T *)a.prev_feat);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, col = lane & 15;
-    const float2 *DS = (const float2 *)a.dist + (size_t)c.b * c.n * K;
-    const float2 *MN = (const float2 *)a.mins + (size_t)c.b * c.n;
-    // h = mean over the patch's points of the distance to the closest of the K neighbours (every wave of every slice
-    // of a patch sums the same values in the same order: no barrier, no LDS)
-    float ms = 0.f, mf = 0.f;
-    for (int i = lane; i < c.n; i += 64) {
-        const float2 v = MN[i];
-        ms += v.x;
-        mf += v.y;
-    }
-    const float hs2 = sk_wave_sum(ms) / (float)c.n / 2, hf2 = sk_wave_sum(mf) / (float)c.n / 2;
-    int fj[SKR_SLOTS];
-    bool fl[SKR_SLOTS];
-#pragma unroll
-    for (int j = 0; j < SKR_SLOTS; ++j) {
-        fl[j] = 16 * j + col < c.C4;
-        fj[j] = min(16 * j + col, c.C4 - 1);
-    }
-    const int nslot = (c.C4 + 15) >> 4;
-    constexpr int WAVES = SK_THREADS / 64;
-    for (int i0 = c.i_lo + 4 * wave; i0 < c.i_hi; i0 += 4 * WAVES) {
-        const bool live = i0 + row < c.i_hi;
-        const int i = live ? i0 + row : c.i_hi - 1;
-        int nb[K];
-        skr_neighbours<K>(a, a.idx, ((size_t)c.b * c.n + i) * K, col, nb);
-        T *X4 = c.F + (size_t)i * a.feat_stride;
-        sk_f4 x[SKR_SLOTS], acc[SKR_SLOTS];
-#pragma unroll
-        for (int j = 0; j < SKR_SLOTS; ++j)
-            if (j < nslot)
-                x[j] = sk_ld4<true>(X4, fj[j]);
-        sk_f4 r[2][SKR_SLOTS];
-#pragma unroll
-        for (int j = 0; j < SKR_SLOTS; ++j)
-            if (j < nslot)
-                r[0][j] = sk_ld4<false>(c.PF + (size_t)nb[0] * a.c, fj[j]);
-        // weights (reference :340-342): w = ws * wf; w /= sum_k (w + 1e-5) -- lane k of the row evaluates neighbour k
-        const float2 ds = DS[(size_t)i * K + min(col, K - 1)];
-        const float mine = col < K ? expf(-ds.x / hs2) * expf(-ds.y / hf2) : 0.f;
-        const float tot = skr_row_sum(col < K ? mine + 1e-5f : 0.f);
-        const float mine_w = mine / tot;
-        if (a.wout && live && col < K)
-            a.wout[((size_t)c.b * c.n + i) * K + col] = mine_w;
-        skr_for<0, K>([&](auto kk) __attribute__((always_inline)) {
-            constexpr int k = decltype(kk)::value;
-            if constexpr (k + 1 < K) {
-#pragma unroll
-                for (int j = 0; j < SKR_SLOTS; ++j)
-                    if (j < nslot)
-                        r[(k + 1) & 1][j] = sk_ld4<false>(c.PF + (size_t)nb[k + 1] * a.c, fj[j]);
-            }
-            const float w = skr_bcast_f<k>(mine_w);
-#pragma unroll
-            for (int j = 0; j < SKR_SLOTS; ++j)
-                if (j < nslot) {
-                    if constexpr (k == 0) {
-                        acc[j].x = w * r[0][j].x; acc[j].y = w * r[0][j].y; acc[j].z = w * r[0][j].z; acc[j].w = w * r[0][j].w;
-                    } else {
-                        acc[j].x = __builtin_fmaf(w, r[k & 1][j].x, acc[j].x); acc[j].y = __builtin_fmaf(w, r[k & 1][j].y, acc[j].y);
-                        acc[j].z = __builtin_fmaf(w, r[k & 1][j].z, acc[j].z); acc[j].w = __builtin_fmaf(w, r[k & 1][j].w, acc[j].w);
-                    }
-                }
-        });
-#pragma unroll
-        for (int j = 0; j < SKR_SLOTS; ++j)
-            if (j < nslot) {
-                sk_f4 o;
-                o.x = __builtin_fmaf(a.scale, acc[j].x, x[j].x); o.y = __builtin_fmaf(a.scale, acc[j].y, x[j].y);
-                o.z = __builtin_fmaf(a.scale, acc[j].z, x[j].z); o.w = __builtin_fmaf(a.scale, acc[j].w, x[j].w);
-                if (live && fl[j])
-                    sk_st4(X4, 16 * j + col, o);
-            }
-    }
-}
+// (r4, measured and removed -- commit cc6a076 has the kernels): a DPP ROW of 16 lanes per point, four points per wave
+// step (a lane holds 4 + 1 float4 of each row; reductions are 4 DPP steps inside the rows for four points at once, lane
+// k of a row evaluates neighbour k's spatial distance and weight, row_newbcast hands them round; loads stay coalesced,
+// 256 contiguous bytes per point and instruction).  About half the wave instructions per point, within 1e-5 of the
+// unfused formulation -- and SLOWER: 1.62 ms per 3840-patch chunk with the next neighbour's row in flight (106 / 136
+// VGPRs, 4 / 3 waves per SIMD), 1.57 ms single-buffered (86 / 116 VGPRs), against 1.52 ms here.  These kernels are not
+// bound by their instruction count: what limits them is the vector-memory path (K + 1 rows of 1056 B per point and
+// kernel from L2 / HBM) and the waves available to hide it.
 
 template <int K>
 int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool half)
 {
-    // float4 rows of up to 320 channels: a DPP row per point (TPU3_SKIP_ROW=0: the wave-per-point kernels, tuning hook)
-    static const int use_row = getenv("TPU3_SKIP_ROW") ? atoi(getenv("TPU3_SKIP_ROW")) : 1;
-    if (use_row && vec && a.c <= 64 * SKR_SLOTS) {
-        if (half) {
-            hipLaunchKernelGGL((skip_dist_row_kernel<K, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-            hipLaunchKernelGGL((skip_apply_row_kernel<K, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-        } else {
-            hipLaunchKernelGGL((skip_dist_row_kernel<K, float>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-            hipLaunchKernelGGL((skip_apply_row_kernel<K, float>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
-        }
-        return tpu3_launch_status();
-    }
     if (half) {         // fp16 rows: the float4-per-lane forms only (the caller checked the alignment)
         if (a.c > 256) {
             hipLaunchKernelGGL((skip_dist_kernel<K, true, true, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
