@@ -81,13 +81,16 @@ struct FcShared {
     u64 tmc[FC_GMAX];                   // tie exchange: (key << 32 | slot) per member
     u64 tiekey;
     int npick[2];
-    int ncand, nwork, jclear, ndense;
+    int ncand, nwork, jclear, ndense, nseat;
+    alignas(16) int hist[256];          // merge: histogram of the candidates above T (monotone bins of the maxima)
+    int rankeq[FC_CAP];                 //        per seat: larger maxima (low half), equal ones (high half)
     int lcount, lthr;
     int gbest;
     int fail;
     u64 stat[8];
 };
-static_assert(offsetof(FcShared, mrow) % 16 == 0 && offsetof(FcShared, cand) % 16 == 0 && offsetof(FcShared, dl) % 16 == 0,
+static_assert(offsetof(FcShared, mrow) % 16 == 0 && offsetof(FcShared, cand) % 16 == 0 && offsetof(FcShared, dl) % 16 == 0 &&
+                  offsetof(FcShared, hist) % 16 == 0 && offsetof(FcShared, tbox) % 16 == 0,
               "vector reads of the lists");
 
 constexpr size_t fc_mbox_words(int g) { return (size_t)2 * g * FC_MB + (size_t)2 * g * 2 + 8; }
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         sh.ncand = 0;
         sh.nwork = 0;
         sh.ndense = 0;
+        sh.nseat = 0;
         sh.fail = 0;
         sh.npick[0] = sh.npick[1] = 0;
         if (g == 0)
@@ -169,6 +173,10 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
     }
     if (tid < 8)
         sh.stat[tid] = 0;
+    if (tid < 256)
+        sh.hist[tid] = 0;
+    if (tid < FC_CAP)
+        sh.rankeq[tid] = 0;
     __syncthreads();
     if (a.m <= 1)
         return;                                     // the reference's loop body never runs: temp untouched
@@ -468,22 +476,19 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         }
         mark(2);
         if (PROF) pc[7] += total;
-        // wave 0: the FC_LCAP best (bisection over the values it holds in registers), published with the header
+        // wave 0: the best `lcap` of the list (usually all of it: then the list is published as it stands), with the header
         if (wave == 0) {
-            int em[FC_LIST / 64];
-            uint32_t eb[FC_LIST / 64];
-#pragma unroll
-            for (int u = 0; u < FC_LIST / 64; ++u) {
-                const int i = u * 64 + lane;
-                em[u] = (int)0x80000000;
-                eb[u] = 0;
-                if (u * 64 < total) {
-                    em[u] = i < total ? (int)sh.cand[EW * i] : (int)0x80000000;
-                    eb[u] = (uint32_t)i;
-                }
-            }
             int thr2 = thr, nsel = total;
-            if (total > lcap) {
+            const bool cut = total > lcap;
+            if (cut) {
+                int em[FC_LIST / 64];
+#pragma unroll
+                for (int u = 0; u < FC_LIST / 64; ++u) {
+                    const int i = u * 64 + lane;
+                    em[u] = (int)0x80000000;
+                    if (u * 64 < total)
+                        em[u] = i < total ? (int)sh.cand[EW * i] : (int)0x80000000;
+                }
                 int lo = thr, hi = lbest, chi = 0;                // count(> lo) > lcap >= count(> hi) = chi
                 for (int it = 0; it < 32 && hi - lo > 1; ++it) {
                     const int mid = lo + ((hi - lo) >> 1);
@@ -501,19 +506,17 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     }
                 }
                 thr2 = hi; nsel = chi;
-            }
-            int base = 0;
+                int base = 0;
 #pragma unroll
-            for (int u = 0; u < FC_LIST / 64; ++u) {
-                if (u * 64 >= total)
-                    break;
-                const bool sel = em[u] > thr2;
-                const unsigned long long smk = __ballot(sel);
-                if (sel) {
-                    const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
-                    sh.lsel[pos] = eb[u];
+                for (int u = 0; u < FC_LIST / 64; ++u) {
+                    if (u * 64 >= total)
+                        break;
+                    const bool sel = em[u] > thr2;
+                    const unsigned long long smk = __ballot(sel);
+                    if (sel)
+                        sh.lsel[base + __builtin_popcountll(smk & ((1ull << lane) - 1ull))] = (uint32_t)(u * 64 + lane);
+                    base += __builtin_popcountll(smk);
                 }
-                base += __builtin_popcountll(smk);
             }
             // (the LDS list above is read back by other lanes of this wave only: program order within a wave)
             u64 *box = mb + ((size_t)par * G + g) * FC_MB;
@@ -527,7 +530,8 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 if (i == 0) v = (uint32_t)lbest;
                 else if (i == 1) v = (uint32_t)thr2;
                 else if (i == 2) v = (uint32_t)nsel;
-                else if (i >= 4 && i < need) v = sh.cand[EW * sh.lsel[(i - 4) / EW] + (i - 4) % EW];
+                else if (i >= 4 && i < need)
+                    v = cut ? sh.cand[EW * sh.lsel[(i - 4) / EW] + (i - 4) % EW] : sh.cand[i - 4];
                 if (i < need)
                     fc_put(box + i, epoch, v);
             }
@@ -587,105 +591,105 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         mark(4);
         if (sh.fail)
             break;
-        // ---- the round's samples: every member derives the same list ----------------------------------------------
+        // ---- the round's samples: every member derives the same list, ALL its waves at work --------------------------
+        // (In a first form wave 0 did this alone -- filter, bisection for the 64 best, compaction, ranking: 6.3 k of a
+        // round's ~19 k cycles while fifteen waves waited.)  A thread per listed candidate: T = max_g T_g and the
+        // cluster's maximum from the headers; a 256-bin histogram of the candidates above T (LDS atomics) whose suffix
+        // sums every wave scans itself gives the threshold bin that keeps <= 64 (a monotone binning of the maxima: the
+        // kept set is "everything above a threshold", as exactness needs; up to one bin's worth of candidates fewer
+        // than 64 may be kept); the kept ones take seats through an atomic counter; their ranks are counted as 16
+        // partial sums (wave w against seats 4 w .. 4 w + 3) while wave 0's fetch of their coordinates is in flight.
         const int left = a.m - r;
         uint32_t okey = 0;
-        if (wave == 0) {
-            if (PROF) pm = __builtin_amdgcn_s_memtime();
+        int gbest, T0;
+        {
             int gb_ = lane < G ? sh.mbest[lane] : (int)0x80000000;
             int t0_ = lane < G ? sh.mthr[lane] : (int)0x80000000;
             tpu3_wave_max_i32_fast_x2(gb_, t0_);
-            const int gbest = gb_, T0 = t0_;
-            // the cluster's list (what the pollers deposited), filtered by T0: with the members' local bounds below the
-            // cluster's, two thirds of what they publish does not qualify
-            constexpr int NE = FC_LIST / 64;
-            const uint32_t *dl = sh.dl;
-            const int tot = sh.ndense;
-            int em[NE];
-            uint32_t eb[NE];
-            int total2 = 0;
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                em[u] = (int)0x80000000;
-                eb[u] = 0;
-                if (u * 64 < tot) {
-                    const int i = u * 64 + lane;
-                    const int bm = (int)dl[EW * (i < tot ? i : 0)];
-                    em[u] = i < tot && bm > T0 ? bm : (int)0x80000000;
-                    eb[u] = (uint32_t)i;                            // (position on the list)
-                    total2 += __builtin_popcountll(__ballot(em[u] > T0));
-                }
+            gbest = gb_; T0 = t0_;
+        }
+        if (PROF) pm = __builtin_amdgcn_s_memtime();
+        const int tot = sh.ndense;                              // (<= FC_LIST <= 1024 threads)
+        const int my_bm = tid < tot ? (int)sh.dl[EW * tid] : (int)0x80000000;
+        const bool cand_ok = my_bm > T0;
+        int my_bin = -1;
+        if (cand_ok) {
+            const float scale = 256.f / ((float)(gbest - T0) + 1.f);
+            my_bin = min(255, (int)((float)(my_bm - T0) * scale));
+            atomicAdd(&sh.hist[my_bin], 1);
+        }
+        __syncthreads();
+        mmark(8);
+        int nsel, bstar;
+        {
+            // lane l holds bins 4 (63 - l) .. + 3, highest first: an inclusive PREFIX sum over the lanes is the number of
+            // candidates in bins >= 4 (63 - l)
+            const int4 h = *(const int4 *)(sh.hist + 4 * (63 - lane));
+            const int own = h.x + h.y + h.z + h.w;
+            int v = own;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);         // row_shr:1
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);         // row_shr:2
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);         // row_shr:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);         // row_shr:8
+            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);         // row_bcast:15 -> rows 1, 3
+            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);         // row_bcast:31 -> rows 2, 3
+            const unsigned long long over = __ballot(v > FC_CAP);
+            if (!over) {
+                bstar = 0;                                      // everything above T0 fits
+                nsel = __builtin_amdgcn_readlane(v, 63);
+            } else {
+                const int Lx = (int)__builtin_ctzll(over);      // the first lane whose bins overflow the round
+                int cum = __builtin_amdgcn_readlane(v - own, Lx);                   // candidates in the bins above its four
+                const int h3 = __builtin_amdgcn_readlane(h.w, Lx), h2 = __builtin_amdgcn_readlane(h.z, Lx);
+                const int h1 = __builtin_amdgcn_readlane(h.y, Lx);
+                const int top = 4 * (63 - Lx);
+                bstar = top + 4;
+                if (cum + h3 <= FC_CAP) { cum += h3; bstar = top + 3;
+                    if (cum + h2 <= FC_CAP) { cum += h2; bstar = top + 2;
+                        if (cum + h1 <= FC_CAP) { cum += h1; bstar = top + 1; } } }
+                nsel = cum;
             }
-            mmark(8);
-            int thr2 = T0, nsel = total2;
-            if (total2 > FC_CAP) {
-                int lo = T0, hi = gbest, chi = 0;                // count(> lo) > FC_CAP >= count(> hi) = chi
-                for (int it = 0; it < 32 && hi - lo > 1; ++it) {
-                    const int mid = lo + ((hi - lo) >> 1);
-                    int c = 0;
-#pragma unroll
-                    for (int u = 0; u < NE; ++u)
-                        if (u * 64 < tot)
-                            c += __builtin_popcountll(__ballot(em[u] > mid));
-                    if (c > FC_CAP) {
-                        lo = mid;
-                    } else {
-                        hi = mid; chi = c;
-                        if (c >= FC_CAP - FC_CAP / 16)
-                            break;
-                    }
-                }
-                thr2 = hi; nsel = chi;
-            }
-            mmark(9);
-            // (nsel == 0: no bucket beats every runner-up bound, or more than FC_CAP share the top value -- duplicated
-            // points; the exact arg-max with the tie rule below settles it)
-            int base = 0;
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                if (u * 64 >= tot || nsel == 0)
-                    break;
-                const bool sel = em[u] > thr2;
-                const unsigned long long smk = __ballot(sel);
-                if (sel) {
-                    const int pos = base + __builtin_popcountll(smk & ((1ull << lane) - 1ull));
-                    sh.mrow[pos] = em[u];
-                    sh.msel[pos] = eb[u];
-                }
-                base += __builtin_popcountll(smk);
-            }
-            const bool live = lane < nsel;
+        }
+        const bool kept = cand_ok && my_bin >= bstar;
+        if (kept) {
+            const int pos = atomicAdd(&sh.nseat, 1);
+            sh.mrow[pos] = my_bm;
+            sh.msel[pos] = (uint32_t)tid;                       // (position on the cluster's list)
+        }
+        if (tid >= nsel && tid < FC_CAP)
+            sh.mrow[tid] = (int)0x80000000;
+        __syncthreads();
+        mmark(9);
+        if (tid < 256)
+            sh.hist[tid] = 0;                                   // (every wave has scanned it)
+        // wave 0: ONE round trip for the coordinates and keys of the kept candidates (the IMMUTABLE words of the slab: any
+        // member may read them; the running distance of a foreign bucket is taken from its published maximum), in flight
+        // while the ranks are counted
+        const bool live = wave == 0 && lane < nsel;
+        float4 sp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t cK = 0xFFFFFFFFu;
+        if (live) {
+            const uint32_t cB = sh.dl[EW * sh.msel[lane] + 1];
+            sp4 = TP[cB];
+            cK = TK[cB];
+        }
+        {
+            // seat `lane` against seats 4 wave .. 4 wave + 3: larger maxima (low half) and equal ones (high half)
+            const int mine = sh.mrow[lane];
+            const int4 o = *(const int4 *)(sh.mrow + 4 * wave);
+            const int gt = (o.x > mine) + (o.y > mine) + (o.z > mine) + (o.w > mine);
+            const int eq = (o.x == mine) + (o.y == mine) + (o.z == mine) + (o.w == mine);
+            if (lane < nsel && (gt | eq))
+                atomicAdd(&sh.rankeq[lane], gt | (eq << 16));
+        }
+        __syncthreads();
+        mmark(10);
+        if (wave == 0) {
             const int cM = live ? sh.mrow[lane] : (int)0x80000000;
-            const uint32_t *ce = dl + EW * sh.msel[live ? lane : 0];
-            // ONE round trip for the coordinates and keys of the whole list (the IMMUTABLE words of the slab: any
-            // member may read them; the running distance of a foreign bucket is taken from its published maximum)
-            const uint32_t cB = ce[1];
-            const float4 sp4 = TP[live ? cB : 0];
-            const uint32_t cK = live ? TK[cB] : 0xFFFFFFFFu;
-            if (!live)
-                sh.mrow[lane] = (int)0x80000000;
-            if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); mmark(10); }
-            // rank = the number of larger maxima; equal maxima (rare) show up as two lanes landing on ONE rank
-            int rank = 0;
-            for (int c0 = 0; c0 < nsel; c0 += 16) {
-                int4 mv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    mv[u] = *(const int4 *)(sh.mrow + c0 + 4 * u);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    rank += mv[u].x > cM ? 1 : 0;
-                    rank += mv[u].y > cM ? 1 : 0;
-                    rank += mv[u].z > cM ? 1 : 0;
-                    rank += mv[u].w > cM ? 1 : 0;
-                }
-            }
-            // (volatile: another LANE's store to the same word is what is being looked for -- the compiler must not
-            // forward this lane's own store to its load)
-            volatile uint32_t *seat = sh.kt;
-            if (live)
-                seat[rank] = (uint32_t)lane;
-            const bool tie = live && seat[rank] != (uint32_t)lane;
+            const int re = live ? sh.rankeq[lane] : 0;
+            int rank = re & 0xFFFF;
+            const bool tie = live && (re >> 16) > 1;            // (its own seat counts once)
+            sh.rankeq[lane] = 0;
             if (__ballot(tie)) {                    // equal maxima among candidates: order by the tie key
                 sh.kt[lane] = cK;
                 rank = 0;
@@ -699,7 +703,6 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                         rank += (m8[v] > cM || (m8[v] == cM && k8[v] < cK)) ? 1 : 0;
                 }
             }
-            mmark(11);
             if (live) {
                 *(float4 *)sh.pick[par][rank] = make_float4(sp4.x, sp4.y, sp4.z, __int_as_float(cM));
                 sh.pkey[par][rank] = cK;
@@ -711,7 +714,9 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 sh.jclear = jm;
                 sh.gbest = gbest;
                 sh.ndense = 0;
+                sh.nseat = 0;
             }
+            mmark(11);
         }
         __syncthreads();
         mark(5);

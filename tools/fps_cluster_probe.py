@@ -54,6 +54,6 @@ for G in [int(v) for v in os.environ.get("GS", "2,4,8,16").split(",")]:
     R = max(1, st[0])
     print("        wave 0 cycles per round: phase 1 %.0f | phase 2 %.0f | collect %.0f | local select + publish %.0f | poll %.0f "
           "| merge + rank %.0f | clearance %.0f ; listed locally %.1f" % tuple(st[8 + k] / R for k in range(8)))
-    print("        merge split: headers + load + filter %.0f | bisection %.0f | compaction + fetch %.0f | ranking %.0f"
+    print("        merge split (wave 0): histogram + barrier %.0f | scan + seats + barrier %.0f | partial ranks + barrier %.0f | ties + picks %.0f"
           % tuple(st[16 + k] / R for k in range(4)))
 lib.tpu3_debug_fps_cluster(-1)
