@@ -1412,13 +1412,15 @@ extern "C" int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin,
 //   W_0 (12,48) = [S0^T x           | G0^T Z[:, 24:48]],  biases = column sums of S.
 namespace {
 
-__global__ __launch_bounds__(256) void dec_wgrad_assemble_kernel(int blocks_e, int blocks_p, const float *__restrict__ pe,
+__global__ __launch_bounds__(1024) void dec_wgrad_assemble_kernel(int blocks_e, int blocks_p, const float *__restrict__ pe,
                                                                  const float *__restrict__ pp, float *__restrict__ gw0,
                                                                  float *__restrict__ gw1, float *__restrict__ gw2,
                                                                  float *__restrict__ gb)
 {
     // partial layouts: edges (blocks_e, 64, 64) (36 x 49 used), points (blocks_p, 64, 32) (36 x 25 used)
-    __shared__ float part[4][64];
+    // (16 waves share the row ranges' blocks of an output: with 4, the up-to-1024 partial blocks were 256 dependent
+    // strided loads per thread on 26 compute units -- 22 us per call, 0.36 ms of a training step)
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     constexpr int N2 = 12 * 48, N1 = 12 * 36, N0 = 12 * 48, NB = 36;
@@ -1442,7 +1444,7 @@ __global__ __launch_bounds__(256) void dec_wgrad_assemble_kernel(int blocks_e, i
     const int blocks = edge ? blocks_e : blocks_p;
     const size_t step = edge ? 64 * 64 : 64 * 32;
     const float *p = (edge ? pe : pp) + (size_t)row * (edge ? 64 : 32) + col;
-    const int per = (blocks + 3) / 4, b0 = q * per, b1 = min(blocks, b0 + per);
+    const int per = (blocks + 15) / 16, b0 = q * per, b1 = min(blocks, b0 + per);
     float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -1454,8 +1456,13 @@ __global__ __launch_bounds__(256) void dec_wgrad_assemble_kernel(int blocks_e, i
     }
     part[q][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (q == 0 && live)
-        *dst = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (q == 0 && live) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            t[u] = (part[4 * u][lane] + part[4 * u + 1][lane]) + (part[4 * u + 2][lane] + part[4 * u + 3][lane]);
+        *dst = (t[0] + t[1]) + (t[2] + t[3]);
+    }
 }
 
 } // namespace
@@ -1482,7 +1489,7 @@ extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const
     if (r) return r;
     r = wgrad_all_launch<4, 1>(s, pp, ap);              // (25 columns: 2 tiles)
     if (r) return r;
-    hipLaunchKernelGGL(dec_wgrad_assemble_kernel, dim3((12 * 48 * 2 + 12 * 36 + 36 + 63) / 64), dim3(256), 0, s,
+    hipLaunchKernelGGL(dec_wgrad_assemble_kernel, dim3((12 * 48 * 2 + 12 * 36 + 36 + 63) / 64), dim3(1024), 0, s,
                        (int)pe.blocks, (int)pp.blocks, (const float *)we, (const float *)wp, gw0, gw1, gw2, gb);
     return tpu3_launch_status();
 }
