@@ -462,11 +462,11 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             __syncthreads();
             if (tid == 0)
                 sh.ncand = 0;
-            if (lbest - thr <= 1) {
+            if ((long)lbest - (long)thr <= 1) {
                 none = true;
                 total = 0;
             } else {
-                thr += (lbest - thr) >> 1;
+                thr = (int)(((long)thr + (long)lbest) >> 1);
             }
             __syncthreads();
         }
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                         em[u] = i < total ? (int)sh.cand[EW * i] : (int)0x80000000;
                 }
                 int lo = thr, hi = lbest, chi = 0;                // count(> lo) > lcap >= count(> hi) = chi
-                for (int it = 0; it < 32 && hi - lo > 1; ++it) {
-                    const int mid = lo + ((hi - lo) >> 1);
+                for (int it = 0; it < 34 && (long)hi - (long)lo > 1; ++it) {
+                    const int mid = (int)(((long)lo + (long)hi) >> 1);
                     int c = 0;
 #pragma unroll
                     for (int u = 0; u < FC_LIST / 64; ++u)
@@ -614,8 +614,12 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         const bool cand_ok = my_bm > T0;
         int my_bin = -1;
         if (cand_ok) {
-            const float scale = 256.f / ((float)(gbest - T0) + 1.f);
-            my_bin = min(255, (int)((float)(my_bm - T0) * scale));
+            // bin = floor(256 d / (R + 1)) with d = maximum - T0 <= R = cluster maximum - T0, as unsigned differences of
+            // the distance bits (they may exceed 2^31: T0 can be negative), both shifted down to 23 bits so that the float
+            // quotient is exact enough to be MONOTONE in d -- all the selection needs
+            const uint32_t d = (uint32_t)my_bm - (uint32_t)T0, R = (uint32_t)gbest - (uint32_t)T0;
+            const int sft = max(0, 9 - (int)__builtin_clz(R | 1u));
+            my_bin = min(255, (int)((float)(d >> sft) * 256.f / ((float)(R >> sft) + 1.f)));
             atomicAdd(&sh.hist[my_bin], 1);
         }
         __syncthreads();
