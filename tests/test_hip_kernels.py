@@ -240,6 +240,34 @@ def test_fps_cluster_form_ragged_and_continued(orc, dev, fps_cluster):
     np.testing.assert_array_equal(temp.cpu().numpy(), t2)
 
 
+def test_fps_cluster_launches_on_concurrent_streams(orc, dev, fps_cluster):
+    """Six cluster launches of 4 sets x 16 members (384 workgroups that spin on their partners, more than the 256
+    compute units hold) on six streams at once, next to streams of ordinary kernels: the members of a cluster are
+    dispatched in order, so every resident cluster completes and frees its units -- no launch may give up
+    (tpu3_fps_cluster_faults stays 0, checked by the fixture) and every result is the oracle's."""
+    ops = pkg("network.operations")
+    fps_cluster(16)
+    n, m, b = 60000, 1500, 4
+    xyz = [sphere(900 + i, n, b) for i in range(6)]
+    xs = [_t(x, dev) for x in xyz]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    filler = torch.rand((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    outs = [None] * 6
+    for rep in range(2):
+        for i in range(6):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = ops.fps(xs[i], m)
+        for st in streams[6:]:
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    filler = filler @ filler * 1e-4
+    torch.cuda.synchronize()
+    for i in range(6):
+        ref_idx, _ = orc.fps(xyz[i], m)
+        np.testing.assert_array_equal(outs[i].cpu().numpy(), ref_idx)
+
+
 def test_fps_cluster_equals_single_workgroup_on_all_80000_picks(dev, fps_cluster):
     """The metric's final resampling, 239 616 -> 80 000 (main.py:379-380), in full: 16 members against one workgroup
     (which tests/test_c2_parity.py pins against the reference's own merged cloud), every pick."""
