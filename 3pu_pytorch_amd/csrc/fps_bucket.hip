@@ -1904,7 +1904,7 @@ bool fb_plan(int b, int n, FbPlan &p)
     p.sort_temp = align256(tb);
     // Several workgroups per element (fps_cluster.hip) when the launch is small.  All b * G workgroups of such a launch
     // must be resident, and four of them on four streams must still fit the 256 compute units together: b * G <= 64.
-    // Up to 4 elements: 16 members each (239 616 -> 80 000 alone: 33.4 ms on one workgroup, 17.2 on 8, 16.1 on 16);
+    // Up to 4 elements: 16 members each (239 616 -> 80 000 alone: 33.4 ms on one workgroup, 15.5 on 8, 14.4 on 16, 15.0 on 32);
     // up to 8: 8 members; beyond that the single-workgroup kernels -- a 32-cloud launch is hidden under the network
     // stages of the next batch either way, and spends fewer compute-unit-milliseconds on one unit per cloud (measured:
     // 9.09 vs 9.05 M points/s).  Beyond 256 tiles the two-level form NEEDS 16 members (config C5's 3744 tiles).
@@ -1915,16 +1915,18 @@ bool fb_plan(int b, int n, FbPlan &p)
         while (gmin * 256 < p.ntile)
             gmin *= 2;
         int gg = g_cluster_force >= 0 ? g_cluster_force : (b <= 4 ? 16 : (b <= 8 ? 8 : 1));
+        if (g_cluster_force < 0 && b <= 2 && p.ntile >= 2048)
+            gg = 32;                            // (config C5's 3744 tiles: 287 ms on 16 members, 248 on 32, 250 on 64)
         if (g_cluster_force < 0)
             while (gg > 1 && p.ntile < 4 * gg)
                 gg /= 2;                        // fewer than four tiles per member: not worth an exchange per round
         if (gg > 1 && gg < gmin && (long)b * gmin <= 64)
             gg = gmin;
-        if (gg >= 2 && gg >= gmin && gg <= 16 && (gg & (gg - 1)) == 0 &&
+        if (gg >= 2 && gg >= gmin && gg <= 64 && (gg & (gg - 1)) == 0 &&
             tpu3_fps_cluster_lds_bytes(p.ntile, gg) <= 160 * 1024)
             p.cluster = gg;
     }
-    p.mbox = p.fl ? align256((size_t)b * tpu3_fps_cluster_mailbox_bytes(16)) : 0;
+    p.mbox = p.fl ? align256((size_t)b * tpu3_fps_cluster_mailbox_bytes(64)) : 0;
     p.total = p.sort_bytes + (size_t)b * p.per_elem + p.sort_temp + p.mbox;
     return true;
 }

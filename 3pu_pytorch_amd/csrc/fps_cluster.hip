@@ -46,7 +46,7 @@ constexpr int FC_LIST = 512;            // candidates a member may list per roun
 constexpr int FC_WORK = 2048;           // work list entries (reached buckets of a round, one member)
 constexpr int FC_DENSE = 16;            // a tile with this many reached buckets is updated on the spot
 constexpr int FC_P2 = 3;                // phase-2 steps of a wave whose points are fetched together
-constexpr int FC_GMAX = 16;
+constexpr int FC_GMAX = 64;             // members per cluster at most (a wave polls sources wave, wave + 16, ...)
 constexpr int FC_MB = 128;              // granules per mailbox: 4 header + 62 entries x 2 words
 constexpr int FC_EWMAX = 2;             // words of a candidate entry: maximum, slot
 constexpr unsigned FC_SPIN_MAX = 1u << 23;      // polls before a member gives up (~seconds)
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
     constexpr int EW = 2;                                   // words per candidate entry
     constexpr int NSW = (4 + FC_LCAP * EW + 63) / 64;       // 64-granule sweeps of a mailbox
     const int G = 1 << lg;
-    const int lcap = G <= 8 ? FC_LCAP : FC_LIST / G - 1;
+    const int lcap = G <= 8 ? FC_LCAP : FC_LIST / G - 1;    // (31 on 16 members, 15 on 32, 7 on 64)
     const int cl = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
     const FbArgs a = fb_elem(a0, cl);
     if (a.n <= 0 || a.m <= 0)
@@ -489,23 +489,44 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     if (u * 64 < total)
                         em[u] = i < total ? (int)sh.cand[EW * i] : (int)0x80000000;
                 }
-                int lo = thr, hi = lbest, chi = 0;                // count(> lo) > lcap >= count(> hi) = chi
-                for (int it = 0; it < 34 && (long)hi - (long)lo > 1; ++it) {
-                    const int mid = (int)(((long)lo + (long)hi) >> 1);
-                    int c = 0;
+                // the cut by a 64-bin histogram of the listed maxima (a monotone binning, as in the merge below): the bins
+                // from the top that hold <= lcap candidates are kept, and T_g = the largest maximum NOT kept -- the list
+                // is complete above it.  (A bisection over the values took ~10 steps of 2-8 ballots: 1.5 k cycles of
+                // every round of config C5, where ~70-100 buckets per member beat its bound.)
+                const uint32_t Rl = (uint32_t)lbest - (uint32_t)thr;
+                const int sftl = max(0, 9 - (int)__builtin_clz(Rl | 1u));
+                const float scl = 64.f / ((float)(Rl >> sftl) + 1.f);
+                int bn[FC_LIST / 64];
 #pragma unroll
-                    for (int u = 0; u < FC_LIST / 64; ++u)
-                        if (u * 64 < total)
-                            c += __builtin_popcountll(__ballot(em[u] > mid));
-                    if (c > lcap) {
-                        lo = mid;
-                    } else {
-                        hi = mid; chi = c;
-                        if (c >= lcap - lcap / 8)
-                            break;
+                for (int u = 0; u < FC_LIST / 64; ++u) {
+                    bn[u] = -1;
+                    if (u * 64 < total && em[u] > thr) {
+                        bn[u] = min(63, (int)((float)(((uint32_t)em[u] - (uint32_t)thr) >> sftl) * scl));
+                        atomicAdd(&sh.hist[bn[u]], 1);
                     }
                 }
-                thr2 = hi; nsel = chi;
+                int bcut;
+                {
+                    const int own = sh.hist[63 - lane];         // lane l: bin 63 - l; prefix over lanes = bins from the top
+                    sh.hist[63 - lane] = 0;                     // (the merge expects the histogram empty)
+                    int v = own;
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+                    const unsigned long long over = __ballot(v > lcap);      // (total > lcap: some lane overflows)
+                    const int Lx = over ? (int)__builtin_ctzll(over) : 64;
+                    bcut = 64 - Lx;                                          // keep bins >= bcut
+                    nsel = Lx > 0 ? __builtin_amdgcn_readlane(v, Lx > 0 ? Lx - 1 : 0) : 0;
+                }
+                int left_out = (int)0x80000000;                 // the largest listed maximum that is not kept
+#pragma unroll
+                for (int u = 0; u < FC_LIST / 64; ++u)
+                    if (u * 64 < total)
+                        left_out = max(left_out, bn[u] < bcut ? em[u] : (int)0x80000000);
+                thr2 = max(thr, tpu3_wave_max_i32_fast(left_out));
                 int base = 0;
 #pragma unroll
                 for (int u = 0; u < FC_LIST / 64; ++u) {
@@ -540,8 +561,8 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
         }
         mark(3);
         // ---- what every member published: one wave per source polls until each granule it needs carries the epoch
-        if (wave < G) {
-            const u64 *src = mb + ((size_t)par * G + wave) * FC_MB;
+        for (int sw = wave; sw < G; sw += 16) {
+            const u64 *src = mb + ((size_t)par * G + sw) * FC_MB;
             unsigned spins = 0;
             u64 x[NSW];
             int cnt = 0;
@@ -569,11 +590,11 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             if (wave == 0)
                 n_sweep += spins + 1;
             if (lane == 0) {
-                sh.mbest[wave] = (int)(uint32_t)x[0];
-                sh.mcnt[wave] = cnt;
+                sh.mbest[sw] = (int)(uint32_t)x[0];
+                sh.mcnt[sw] = cnt;
             }
             if (lane == 1)
-                sh.mthr[wave] = (int)(uint32_t)x[0];
+                sh.mthr[sw] = (int)(uint32_t)x[0];
             // the entries go straight onto the cluster's list (any order: the ranking does not depend on it), unfiltered
             // -- T0 is known only when all headers are in
             int base = 0;
@@ -746,8 +767,8 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 const u64 k = sh.tiekey;
                 fc_put(tb + ((size_t)(te & 1) * G + g) * 2 + lane, te, lane == 0 ? (uint32_t)(k >> 32) : (uint32_t)k);
             }
-            if (wave < G) {
-                const u64 *src = tb + ((size_t)(te & 1) * G + wave) * 2;
+            for (int sw = wave; sw < G; sw += 16) {
+                const u64 *src = tb + ((size_t)(te & 1) * G + sw) * 2;
                 unsigned spins = 0;
                 u64 x = 0;
                 for (;;) {
@@ -764,7 +785,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 0);
                 const uint32_t slotw = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 1);
                 if (lane == 0)
-                    sh.tmc[wave] = ((u64)key << 32) | slotw;
+                    sh.tmc[sw] = ((u64)key << 32) | slotw;
             }
             __syncthreads();
             if (sh.fail)

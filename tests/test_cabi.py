@@ -122,8 +122,10 @@ def test_fps_dispatch_table():
     # one workgroup per cloud (two-level tile form)
     assert plan(1, 239616, 80000) == (6, 16) and plan(4, 239616, 80000) == (6, 16)
     assert plan(8, 239616, 80000) == (6, 8) and plan(32, 239616, 80000) == (4, 0)
-    # config C5's 3.83 M -> 1.28 M: two levels need 16 members; a batch that cannot have them takes three levels
-    assert plan(1, 3833856, 1280000) == (6, 16) and plan(8, 3833856, 1280000) == (5, 0)
+    # config C5's 3.83 M -> 1.28 M: two levels need 16 members (one or two sets: 32); a batch that cannot have them
+    # takes three levels
+    assert plan(1, 3833856, 1280000) == (6, 32) and plan(4, 3833856, 1280000) == (6, 16)
+    assert plan(8, 3833856, 1280000) == (5, 0)
     # just above the register-resident limit: too few tiles for 16 members
     assert plan(1, 25601, 3000) == (6, 4) and plan(1, 70000, 3000) == (6, 16)
     # beyond every plan
