@@ -5,34 +5,39 @@
 // element of 239 616 points for 80 000 samples).  The single-workgroup tile form runs that call as ~2000 rounds of ~40
 // exact samples each on one compute unit; a round is tile prune -> bucket records -> the reached buckets' points ->
 // candidate list -> ranking -> clearance, two thirds of it the instruction throughput of that one unit (tools/
-// fps_tile_probe.py: 27 k of 40 k cycles in the update phases).  Here a CLUSTER of G = 2, 4, 8 or 16 workgroups shares
-// a set:
+// fps_tile_probe.py: 27 k of 40 k cycles in the update phases).  Here a CLUSTER of G = 2 ... 64 workgroups (a power of
+// two) shares a set:
 //
 //   * tile t of the Morton-ordered slab belongs to member t mod G (a sample's ball covers CONSECUTIVE tiles: the
 //     interleaving spreads a round's visits evenly); the member keeps the maxima / arg-max positions of its tiles'
-//     buckets in ITS LDS (1/G of the table: up to 16 x 256 tiles = 4.19 M points on two levels -- config C5's 3.83 M
-//     point resample needs no third level) and is the only writer of its buckets' running distances and records;
-//   * per round every member applies the round's samples to its own tiles (phases 1 and 2 of the tile form), lists
-//     its own candidate buckets above ITS largest runner-up bound, and PUBLISHES the best <= 62 of them with its
-//     maximum and the threshold T_g its list is complete above: 8-byte {epoch, value} granules, one write-through
-//     (sc1) store each, no fence (MI355X guide, Guideline 16 form R2: the data is the flag);
-//   * every member then reads ALL G mailboxes (one wave per source, relaxed agent-scope polls until every granule
-//     carries the round's epoch) and derives the round's samples itself: T = max_g T_g, the candidates above T, the 64
-//     best by bisection, rank order, coordinates and tie keys from the immutable part of the slab, the longest clear
-//     prefix.  All members compute the same list from the same published words, so ONE exchange per round is the only
-//     inter-workgroup step -- no barrier, no leader, no broadcast;
+//     buckets in ITS LDS (1/G of the table: from 16 members on, 256 tiles each = 4.19 M points on two levels -- config
+//     C5's 3.83 M point resample needs no third level) and is the only writer of its buckets' running distances and
+//     records;
+//   * per round every member applies the round's samples to its own tiles (prune: a wave per tile, a lane per
+//     sample; visits; bucket updates), lists its own candidate buckets above ITS largest runner-up bound, and
+//     PUBLISHES the best <= 62 of them (a histogram cut) with its maximum and the threshold T_g its list is complete
+//     above: 8-byte {epoch, value} granules, one write-through (sc1) store each, no fence (MI355X guide, Guideline 16
+//     form R2: the data is the flag);
+//   * every member then reads ALL G mailboxes (a wave per source, relaxed agent-scope polls until every granule
+//     carries the round's epoch) and derives the round's samples itself, on all its waves: T = max_g T_g, a thread per
+//     listed candidate, the 64 best above T by a histogram threshold, seats, ranks as 16 partial sums, coordinates
+//     and tie keys from the immutable part of the slab, the longest clear prefix.  All members compute the same list
+//     from the same published words, so ONE exchange per round is the only inter-workgroup step -- no barrier, no
+//     leader, no broadcast;
 //   * equal maxima at the top (duplicated points) take the exact arg-max with the reference's tie rule through a
 //     second, rare exchange of (smallest tie key, slot) per member.
 //
 // Exactness is the tile form's: any threshold >= R* = max of all runner-up bounds is valid; T >= R*
-// because every T_g >= the member's own bound; the published lists are complete above T_g <= T; rank order is
-// (maximum descending, tie key ascending), independent of list order.  Bit-identical indices and final `temp`.
+// because every T_g >= the member's own bound; the published lists are complete above T_g <= T; every cut keeps
+// "everything above a threshold" (the histograms bin the maxima monotonically); rank order is (maximum descending, tie
+// key ascending), independent of list order.  Bit-identical indices and final `temp`.
 //
 // Residency: the members of a cluster spin on each other, so all b * G workgroups of a launch must be resident.  The
-// dispatcher admits them in order and every other kernel on the device terminates, so a lone cluster launch of <= 256
-// workgroups always gets there; the host keeps b * G <= 64 so that four such launches on four streams still fit the 256
-// compute units together.  Every poll is bounded: a member that gives up raises the launch's fault word (`stats[4]`,
-// the last mailbox word) and all members leave; the host side reports it (tpu3_fps_cluster_faults).
+// dispatcher admits a launch's workgroups in order and every other kernel on the device terminates, so the clusters
+// already resident always complete and free their units (tests/test_hip_kernels.py runs 384 such workgroups on six
+// streams at once); the host keeps b * G <= 64 per launch.  Every poll is bounded: a member that gives up counts a
+// fault (tpu3_fps_cluster_faults, read by pipeline.upsample / bench.py at their synchronisation points; `stats[4]`)
+// and all members of its cluster leave.
 #include "fps_bucket.h"
 
 #include <cstdlib>
@@ -41,7 +46,7 @@ namespace {
 
 constexpr int FC_CAP = 64;              // samples per round
 constexpr int FC_LCAP = 62;             // candidates a member publishes per round: 4 header + 2 x 62 granules = 2 sweeps
-                                        // (31 on sixteen members: the cluster's list holds FC_LIST entries)
+                                        // (31 / 15 / 7 on 16 / 32 / 64 members: the cluster's list holds FC_LIST entries)
 constexpr int FC_LIST = 512;            // candidates a member may list per round
 constexpr int FC_WORK = 2048;           // work list entries (reached buckets of a round, one member)
 constexpr int FC_DENSE = 16;            // a tile with this many reached buckets is updated on the spot
