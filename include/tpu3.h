@@ -467,8 +467,9 @@ int tpu3_debug_fps_tile_stats(unsigned long long *stats);
  * host-side state only. */
 int tpu3_debug_knn_tiles_stats(unsigned *words);
 /* tpu3_debug_fps_cluster: workgroups per point set of the tile-form FPS for the calls that follow: -1 = the default
- * policy (several compute units per set when the launch is small: b * G <= 64, G <= 8, 16 for sets beyond 262 144
- * points), 0 = single-workgroup kernels only, 2 / 4 / 8 / 16 = forced wherever the size allows.  Returns the previous
+ * policy (several compute units per set when the launch is small: 16 workgroups per set for up to 4 sets, 8 for up
+ * to 8, 32 for one or two sets beyond 2 M points; b * G <= 64), 0 = single-workgroup kernels only, 2 / 4 / ... / 64 =
+ * forced wherever the size allows.  Returns the previous
  * setting (also: environment TPU3_FPS_CLUSTER).  With the cluster form, tpu3_debug_fps_tile_stats receives rounds,
  * samples, tie exchanges, wave 0's poll sweeps and the launch's fault count in stats[0..4].
  * tpu3_debug_fps_plan: which FPS kernel family a (b, n, m) call takes -- 0 plain register-resident / streaming (up to
