@@ -5,6 +5,8 @@ so the oracle is pinned three ways: (1) against fixtures the reference's own Pyt
 (tests/golden, see oracle/make_golden.py); (2) against independent brute-force numpy
 definitions; (3) by internal consistency properties (contracted vs un-contracted arithmetic give
 the same indices on generic data, tie rules, the b > 32 grid quirk)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -61,6 +63,43 @@ def test_fps_contraction_does_not_change_indices_on_generic_clouds(orc):
         a, _ = orc.fps(xyz, m, flags=orc.ORC_FMA)
         b, _ = orc.fps(xyz, m, flags=0)
         np.testing.assert_array_equal(a, b)
+
+
+def test_llvm_contracts_the_reference_expression_as_the_oracle_does(orc, tmp_path):
+    """The oracle's floating-point reading of sampling_cuda.cu:143 / nmdistance_cuda.cu:33 under nvcc's default
+    -fmad=true is fma(dz, dz, fma(dx, dx, dy*dy)).  nvcc's optimiser (NVVM) is LLVM; this image has no nvcc and no
+    NVPTX back end, but the contraction is done by LLVM's target-independent DAG combiner: compiling the reference's
+    own EXPRESSION with the LLVM in this image (-ffp-contract=fast, an FMA target) must give that association bit
+    for bit -- and not the un-contracted sum, nor the other two fused associations -- on values where they differ.
+    (Supporting evidence for the contract of DESIGN section 2, not a pin of nvcc itself.)"""
+    import ctypes
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang) or "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("needs the image's LLVM and an FMA host")
+    src = tmp_path / "expr.c"
+    # the expression exactly as the reference writes it (sampling_cuda.cu:143)
+    src.write_text("float sq(float x1, float y1, float z1, float x2, float y2, float z2)\n"
+                   "{ float d=(x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1); return d; }\n")
+    so = tmp_path / "expr.so"
+    subprocess.check_call([clang, "-O2", "-mfma", "-ffp-contract=fast", "-shared", "-fPIC", "-o", str(so), str(src)])
+    lib = ctypes.CDLL(str(so))
+    lib.sq.restype = ctypes.c_float
+    lib.sq.argtypes = [ctypes.c_float] * 6
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((4000, 6)).astype(np.float32)
+    got = np.array([lib.sq(*[float(v) for v in row]) for row in pts], np.float32)
+    dx, dy, dz = (pts[:, 3] - pts[:, 0]), (pts[:, 4] - pts[:, 1]), (pts[:, 5] - pts[:, 2])
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    oracle_form = fma(dz, dz, fma(dx, dx, dy * dy))
+    plain = (dx * dx + dy * dy) + dz * dz
+    other1 = fma(dz, dz, fma(dy, dy, dx * dx))
+    other2 = fma(dx, dx, fma(dy, dy, dz * dz))
+    np.testing.assert_array_equal(got, oracle_form)
+    assert (plain != oracle_form).any() and (other1 != oracle_form).any() and (other2 != oracle_form).any()
 
 
 def test_fps_grid32_quirk_only_when_asked(orc):
