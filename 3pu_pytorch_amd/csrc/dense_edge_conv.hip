@@ -73,6 +73,8 @@ struct DecArgs {
     int acc_stride, seed_off, store_off;
     float *xnext;                    // (P, n, 24): relu of the first 24 outputs = the next block's input rows
     int out_half;                    // `out` is a fp16 buffer (TPU3_STORE_F16; fp16-operand kernel only), stride in halves
+    int nosplit = 0;                 // tuning hook TPU3_DEC_SPLIT=0: left-over steps whole, as before round 4
+    int patches = 0;                 // lane-per-point kernel: a workgroup walks patches blockIdx.x, + gridDim.x, ...
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -549,6 +551,13 @@ __device__ __forceinline__ void dec4_mm24(const f32x4 *tab, int li, const f32x4 
         dec4_step<6>(tab, li, kq, x[kq][0], x[kq][1], x[kq][2], x[kq][3], acc);
 }
 
+// running maximum in LDS (ds_max_f32; no return value)
+__device__ __forceinline__ void dec4_lds_max(float *p, float v)
+{
+    __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP,
+                             false);
+}
+
 // The workgroup's operand tables, built in LDS from the raw weights: the 1620 weight and bias floats are first
 // copied into LDS with coalesced loads (ONE global round trip; `raw` may alias the z table, which is written later),
 // then re-arranged LDS -> LDS.  (Gathering the table entries straight from the weight matrices cost 20 us of
@@ -616,15 +625,12 @@ void dec_fused4_kernel(DecArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int li = lane & 3;
     const int n = a.n, k = a.k;
-    const float *X = a.x + (size_t)blockIdx.x * n * DEC_C;
-    float *O = a.out + (size_t)blockIdx.x * n * a.out_stride;
     f32x4 *tab = (f32x4 *)lds;
     float *bias = lds + DEC4_BIAS;
     float *zl = lds + DEC4_ZTAB;                 // z_p  = W0b x_p            (n x 12)
-    float *c2l = zl + (size_t)n * DEC_ZS;        // c2_p = W2c x_p + b2       (n x 12)
-    // (FOLD) A operands of the folded prep convolutions behind the two tables: float4 entries
+    // (FOLD) A operands of the folded prep convolutions behind the table: float4 entries
     // [chunk of 24 outputs][row group 6][kq 15][i 4] = fold_w[24 chunk + 4 rg + i][4 kq .. 4 kq + 3]
-    f32x4 *ftab = (f32x4 *)(c2l + (size_t)n * DEC_ZS + 4);
+    f32x4 *ftab = (f32x4 *)(zl + (size_t)n * DEC_ZS + 4);
 
     float wp[7];
     dec4_setup(a, lds, zl, wp);
@@ -635,60 +641,31 @@ void dec_fused4_kernel(DecArgs a)
         }
         // (visible after the barrier behind phase A)
     }
-
     const int nstep = (n + 63) >> 6;
-    // ---- phase A, per point (lane = point): the z table and the slot-independent part of the last layer into LDS,
-    // the x_i part of the output row straight from the registers.  The wave's steps are walked LAST FIRST, so the
-    // input rows of its first step are still in registers when phase B starts.
-    f32x4 x[6];
-    {
-        int st = wave;
-        while (st + nwave < nstep)
-            st += nwave;
-        for (; st >= 0; st -= nwave) {
-            int tofs = 0;                       // (opaque zero: keeps the A-operand reads inside the loop, see phase B)
-            asm volatile("" : "+v"(tofs));
-            const f32x4 *tabs = tab + tofs;
-            const int p = st * 64 + lane;
-            const f32x4 *xr = (const f32x4 *)(X + (size_t)min(p, n - 1) * DEC_C);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                x[q] = xr[q];
-            f32x4 z[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, c2[3];
-#pragma unroll
-            for (int rg = 0; rg < 3; ++rg)
-                c2[rg] = *(const f32x4 *)(bias + 24 + 4 * rg);
-            dec4_mm24(tabs + DEC4_T_Z, li, x, z);
-            dec4_mm24(tabs + DEC4_T_C2, li, x, c2);
-            if (p < n) {
-                f32x4 *zr = (f32x4 *)(zl + p * DEC_ZS), *cr = (f32x4 *)(c2l + p * DEC_ZS);
-                zr[0] = z[0]; zr[1] = z[1]; zr[2] = z[2];
-                cr[0] = c2[0]; cr[1] = c2[1]; cr[2] = c2[2];
-                f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);       // [36, 60): one 96-byte run
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    orow[9 + q] = x[q];
-            }
-        }
-    }
-    __syncthreads();
+    // (r4) steps left over by the round-robin deal (nstep mod 4 = 1 or 2) are split by neighbour slots over 4 or 2
+    // waves, see the end of phase B; their running maxima meet in `comb` [left-over step][36 channels][64 lanes]
+    const int rem = nstep % nwave;
+    const int split = (nwave == 4 && !a.nosplit && (k % (4 * U)) == 0) ? (rem == 1 ? 4 : rem == 2 ? 2 : 1) : 1;
+    float *comb = (float *)ftab + (size_t)a.fold_n * 60;
 
-    // ---- phase B: the wave's 64-point steps ---------------------------------------------------------------------
-    for (int st = wave; st < nstep; st += nwave) {
-        // (opaque zero: keeps the table reads of this step inside the loop -- hoisted, the loop-invariant A operands of
-        // the centre terms would occupy 144 registers)
-        int tofs = 0;
-        asm volatile("" : "+v"(tofs));
-        const f32x4 *tabs = tab + tofs;
-        const int p = st * 64 + lane;
-        const int pc = min(p, n - 1);
-        if (st != wave) {
+    // per-patch state (the workgroup walks patches blockIdx.x, blockIdx.x + gridDim.x, ...)
+    const float *X = nullptr;
+    float *O = nullptr;
+    size_t prow = 0;
+    int vw = 0;
+    f32x4 x[6];
+    const char *zb = (const char *)zl;
+    const int zmax = (n - 1) * (int)(DEC_ZS * sizeof(float));
+    const float ninf = -__builtin_inff();
+
+    // centre terms of a step: c0 = W0c x_i + b0, c1 = W1c x_i + b1 (x = the step's rows)
+    auto centre = [&](const f32x4 *tabs, int st, int pc, f32x4 (&c0)[3], f32x4 (&c1)[3]) __attribute__((always_inline)) {
+        {
             const f32x4 *xr = (const f32x4 *)(X + (size_t)pc * DEC_C);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 x[q] = xr[q];
         }
-        f32x4 c0[3], c1[3];
 #pragma unroll
         for (int rg = 0; rg < 3; ++rg) {
             c0[rg] = *(const f32x4 *)(bias + 4 * rg);
@@ -696,16 +673,17 @@ void dec_fused4_kernel(DecArgs a)
         }
         dec4_mm24(tabs + DEC4_T_C0, li, x, c0);
         dec4_mm24(tabs + DEC4_T_C1, li, x, c1);
-        // neighbour slots; index and z row of the following slots are requested before this iteration's MFMAs
-        const size_t ibase = ((size_t)blockIdx.x * n + pc) * a.idx_stride + a.idx_off;
-        const int zmax = (n - 1) * (int)(DEC_ZS * sizeof(float));
-        auto nbr = [&](int s) __attribute__((always_inline)) {     // byte offset of the neighbour's z row
-            const int j = IDX64 ? (int)((const long long *)a.idx)[ibase + s] : ((const int *)a.idx)[ibase + s];
+    };
+
+    // neighbour slots [s0, s1) of the lane's point folded into the running maxima; index and z row of the following
+    // slots are requested before an iteration's MFMAs
+    auto slots = [&](int pc, int s0, int s1, const f32x4 (&c0)[3], const f32x4 (&c1)[3], f32x4 (&m0)[3], f32x4 (&m1)[3],
+                     f32x4 (&m2)[3]) __attribute__((always_inline)) {
+        const size_t ibase = (prow + pc) * a.idx_stride + a.idx_off;
+        auto nbr = [&](int sl) __attribute__((always_inline)) {    // byte offset of the neighbour's z row
+            const int j = IDX64 ? (int)((const long long *)a.idx)[ibase + sl] : ((const int *)a.idx)[ibase + sl];
             return min(max(j * (int)(DEC_ZS * sizeof(float)), 0), zmax);
         };
-        const char *zb = (const char *)zl;
-        const float ninf = -__builtin_inff();
-        f32x4 m0[3], m1[3], m2[3];
 #pragma unroll
         for (int rg = 0; rg < 3; ++rg)
             m0[rg] = m1[rg] = m2[rg] = (f32x4){ninf, ninf, ninf, ninf};
@@ -713,12 +691,12 @@ void dec_fused4_kernel(DecArgs a)
         f32x4 zn[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f32x4 *zr = (const f32x4 *)(zb + nbr(min(u, k - 1)));
+            const f32x4 *zr = (const f32x4 *)(zb + nbr(min(s0 + u, s1 - 1)));
             zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
-            jn[u] = nbr(min(U + u, k - 1));
+            jn[u] = nbr(min(s0 + U + u, s1 - 1));
         }
 #pragma unroll 1
-        for (int s = 0; s < k; s += U) {
+        for (int sl = s0; sl < s1; sl += U) {
             f32x4 h0[U][3], h1[U][3], h2[U][3];
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -734,7 +712,7 @@ void dec_fused4_kernel(DecArgs a)
             for (int u = 0; u < U; ++u) {
                 const f32x4 *zr = (const f32x4 *)(zb + jn[u]);
                 zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
-                jn[u] = nbr(min(s + 2 * U + u, k - 1));
+                jn[u] = nbr(min(sl + 2 * U + u, s1 - 1));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -788,16 +766,30 @@ void dec_fused4_kernel(DecArgs a)
                     }
                 }
         }
-        // ---- write-out: [max h2 + c2 | max h1 | max h0] = floats [0, 36) of the lane's own row, nine back-to-back
-        // 16-byte stores (staging 16 rows at a time through LDS so that 15 consecutive lanes write one row was
-        // measured: no faster, and the tile costs the LDS of another workgroup per compute unit)
+    };
+
+    // what follows a point's maxima: c2_p = W2c x_p + b2 (the point's row again, six 16-byte loads) added to the last
+    // layer's, then (rows) the write-out [max h2 + c2 | max h1 | max h0] = floats [0, 36) of the lane's own row, nine
+    // back-to-back 16-byte stores (staging 16 rows at a time through LDS so that 15 consecutive lanes write one row was
+    // measured: no faster, and the tile costs the LDS of another workgroup per compute unit), then (FOLD) the chunks
+    // ch0, ch0 + chs, ... of the next prep convolutions
+    auto finish = [&](const f32x4 *tabs, int tofs, int p, int pc, f32x4 (&m0)[3], f32x4 (&m1)[3], f32x4 (&m2)[3], bool rows,
+                      int ch0, int chs) __attribute__((always_inline)) {
         {
-            const f32x4 *cr = (const f32x4 *)(c2l + min(p, n - 1) * DEC_ZS);
+            const f32x4 *xr2 = (const f32x4 *)(X + (size_t)pc * DEC_C);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                x[q] = xr2[q];
+            f32x4 c2[3];
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg)
-                m2[rg] = m2[rg] + cr[rg];
+                c2[rg] = *(const f32x4 *)(bias + 24 + 4 * rg);
+            dec4_mm24(tabs + DEC4_T_C2, li, x, c2);
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg)
+                m2[rg] = m2[rg] + c2[rg];
         }
-        if (p < n) {
+        if (rows && p < n) {
             f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg)
@@ -815,14 +807,10 @@ void dec_fused4_kernel(DecArgs a)
             // the level's feature buffer is then never re-read by a prep convolution (84 / 144 / 204 channels per
             // point and layer before).  Outputs in chunks of 24 (six accumulators); the first chunk completes the
             // NEXT block's input: ReLU, contiguous rows; the others are partial sums for the blocks after it.
-            const f32x4 *xr2 = (const f32x4 *)(X + (size_t)pc * DEC_C);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                x[q] = xr2[q];
-            float *arow = a.acc + ((size_t)blockIdx.x * n + pc) * a.acc_stride;
+            float *arow = a.acc + (prow + pc) * a.acc_stride;
 #pragma unroll 1
-            for (int ch = 0; ch < a.fold_n / 24; ++ch) {
-                asm volatile("" : "+v"(tofs));
+            for (int ch = ch0; ch < a.fold_n / 24; ch += chs) {
+                asm volatile("" : "+s"(tofs));
                 const f32x4 *ft = ftab + tofs + ch * (6 * 15 * 4);
                 f32x4 acc[6];
 #pragma unroll
@@ -847,7 +835,7 @@ void dec_fused4_kernel(DecArgs a)
                     step15(9 + q, x[q]);
                 if (p < n) {
                     if (ch == 0) {
-                        f32x4 *xn = (f32x4 *)(a.xnext + ((size_t)blockIdx.x * n + p) * DEC_C);
+                        f32x4 *xn = (f32x4 *)(a.xnext + (prow + p) * DEC_C);
 #pragma unroll
                         for (int rg = 0; rg < 6; ++rg) {
                             f32x4 v = acc[rg];
@@ -864,14 +852,125 @@ void dec_fused4_kernel(DecArgs a)
                 }
             }
         }
+    };
+
+    for (int patch_v = blockIdx.x; patch_v < a.patches; patch_v += gridDim.x) {
+        const int patch = __builtin_amdgcn_readfirstlane(patch_v);
+        X = a.x + (size_t)patch * n * DEC_C;
+        O = a.out + (size_t)patch * n * a.out_stride;
+        prow = (size_t)patch * n;
+        if (split > 1)
+            for (int e = tid; e < rem * 36 * 64; e += blockDim.x)
+                comb[e] = ninf;
+        // Which wave takes an extra step (no split: TPU3_DEC_SPLIT=0, or three left-over steps) rotates with the
+        // patch: wave w of every workgroup sits on SIMD w -- with the long wave always on SIMD 0 that SIMD alone would
+        // bound the compute unit.
+        vw = __builtin_amdgcn_readfirstlane((wave + patch) % nwave);
+        // ---- phase A, per point (lane = point): the z table into LDS, the x_i part of the output row straight from
+        // the registers.  (Keeping the first step's rows for phase B made all 24 registers live across the slot loop
+        // once the code around it grew: phase B reads its rows again.)  (r4: the slot-independent part of the last layer, c2_p = W2c x_p + b2, used
+        // to be a second n x 12 table here; it is re-derived by the point's own lane at the write-out instead: 72
+        // MFMAs per step, 15 KB less per workgroup.)
+        {
+            int st = vw;
+            while (st + nwave < nstep)
+                st += nwave;
+            for (; st >= 0; st -= nwave) {
+                int tofs = 0;                   // (opaque zero: keeps the A-operand reads inside the loop, see phase B)
+                asm volatile("" : "+s"(tofs));
+                const f32x4 *tabs = tab + tofs;
+                const int p = st * 64 + lane;
+                const f32x4 *xr = (const f32x4 *)(X + (size_t)min(p, n - 1) * DEC_C);
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    x[q] = xr[q];
+                f32x4 z[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                dec4_mm24(tabs + DEC4_T_Z, li, x, z);
+                if (p < n) {
+                    f32x4 *zr = (f32x4 *)(zl + p * DEC_ZS);
+                    zr[0] = z[0]; zr[1] = z[1]; zr[2] = z[2];
+                    f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);       // [36, 60): one 96-byte run
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        orow[9 + q] = x[q];
+                }
+            }
+        }
+        __syncthreads();
+
+        // whole steps, dealt round-robin
+        const int nwhole = split > 1 ? nstep - rem : nstep;
+        for (int st = vw; st < nwhole; st += nwave) {
+            // (opaque zero: keeps the table reads of this step inside the loop -- hoisted, the loop-invariant A operands of
+            // the centre terms would occupy 144 registers)
+            int tofs = 0;
+            asm volatile("" : "+s"(tofs));
+            const f32x4 *tabs = tab + tofs;
+            const int p = st * 64 + lane;
+            const int pc = min(p, n - 1);
+            f32x4 c0[3], c1[3], m0[3], m1[3], m2[3];
+            centre(tabs, st, pc, c0, c1);
+            slots(pc, 0, k, c0, c1, m0, m1, m2);
+            finish(tabs, tofs, p, pc, m0, m1, m2, true, 0, 1);
+        }
+        if (split > 1) {
+            // ---- (r4) the steps left over (a 312-point patch: the fifth of five on four waves), split by SLOTS: wave
+            // (j, q) folds slots [q k / split, (q + 1) k / split) of left-over step j, the waves' maxima meet in LDS
+            // (ds_max_f32 on a table that phase A set to -inf; max is order-independent, so the result is the unsplit
+            // step's bit for bit), and what follows the maxima is dealt out again: the rows to part split - 1, fold chunk ch
+            // to part ch mod split.  (One wave taking the whole step held the workgroup's place on the compute unit
+            // for two steps while three SIMDs waited -- the kernel took launches / 3 x the LONG wave's lifetime, measured
+            // with s_memtime marks: 0.575 -> 0.535 ms per 3840-patch launch, medians of 40; TPU3_DEC_SPLIT=0 restores it.)
+            int tofs = 0;
+            asm volatile("" : "+s"(tofs));
+            const f32x4 *tabs = tab + tofs;
+            const int j = vw / split, q = vw - j * split;
+            const int st = nwhole + j;
+            const int p = st * 64 + lane;
+            const int pc = min(p, n - 1);
+            float *cb = comb + j * (36 * 64) + lane;
+            const int ks = k / split;
+            {
+                f32x4 c0[3], c1[3], m0[3], m1[3], m2[3];
+                centre(tabs, st, pc, c0, c1);
+                slots(pc, q * ks, (q + 1) * ks, c0, c1, m0, m1, m2);
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dec4_lds_max(cb + (0 + 4 * rg + r) * 64, m2[rg][r]);
+                        dec4_lds_max(cb + (12 + 4 * rg + r) * 64, m1[rg][r]);
+                        dec4_lds_max(cb + (24 + 4 * rg + r) * 64, m0[rg][r]);
+                    }
+            }
+            __syncthreads();
+            const bool rows = q == split - 1;
+            if (rows || (FOLD && q < a.fold_n / 24)) {
+                f32x4 m0[3], m1[3], m2[3];
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        m2[rg][r] = cb[(0 + 4 * rg + r) * 64];
+                        m1[rg][r] = cb[(12 + 4 * rg + r) * 64];
+                        m0[rg][r] = cb[(24 + 4 * rg + r) * 64];
+                    }
+                finish(tabs, tofs, p, pc, m0, m1, m2, rows, q, split);
+            }
+        }
+        // (the z table and `comb` are rewritten for the next patch)
+        if (patch + (int)gridDim.x < a.patches)
+            __syncthreads();
     }
 }
 
 constexpr size_t dec4_lds_bytes(int n, int fold_n = 0)
 {
-    const size_t tables = 2 * (size_t)n * DEC_ZS + 4;          // z and c2 tables; the raw weights alias them during setup
+    const size_t tables = (size_t)n * DEC_ZS + 4;              // the z table; the raw weights alias it during setup
+    const int nstep = (n + 63) / 64, rem = nstep % 4;           // left-over steps split over the waves: their maxima
+    const size_t comb = nstep > 4 && (rem == 1 || rem == 2) ? (size_t)rem * 36 * 64 : 0;
     return ((size_t)DEC4_ZTAB + (tables > (size_t)DEC4_RAW_FLOATS ? tables : (size_t)DEC4_RAW_FLOATS) +
-            (size_t)fold_n * 60) * sizeof(float);
+            (size_t)fold_n * 60 + comb) * sizeof(float);
 }
 
 int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
@@ -881,21 +980,27 @@ int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
     // slots while three SIMDs wait.  With four, the wave that takes two steps runs alone on its SIMD as long as the
     // others, and the slots of the finished ones go to the next workgroup.  TPU3_DEC_NW / TPU3_DEC_U: tuning hooks.
     static const int nw_env = getenv("TPU3_DEC_NW") ? atoi(getenv("TPU3_DEC_NW")) : 4;
-    static const int u_env = getenv("TPU3_DEC_U") ? atoi(getenv("TPU3_DEC_U")) : 2;   // 294.9 vs 298.5 ms per bench step
     const int nw = min(min(DEC4_MAXW, max(1, nw_env)), (a.n + 63) / 64);
     const size_t lds = dec4_lds_bytes(a.n, a.fold_n);
-    const bool u2 = u_env == 2 && (a.k % 2) == 0;
+    // two neighbour slots per loop iteration (U = 1: 4 waves per SIMD but 36 instead of 18 running-maximum instructions
+    // per slot, 298.5 vs 294.9 ms per bench step in round 3, and it spills since the left-over steps are split)
     void (*kern)(DecArgs);
     if (a.fold_n)
-        kern = a.idx64 ? (u2 ? dec_fused4_kernel<true, 2, true> : dec_fused4_kernel<true, 1, true>)
-                       : (u2 ? dec_fused4_kernel<false, 2, true> : dec_fused4_kernel<false, 1, true>);
+        kern = a.idx64 ? dec_fused4_kernel<true, 2, true> : dec_fused4_kernel<false, 2, true>;
     else
-        kern = a.idx64 ? (u2 ? dec_fused4_kernel<true, 2, false> : dec_fused4_kernel<true, 1, false>)
-                       : (u2 ? dec_fused4_kernel<false, 2, false> : dec_fused4_kernel<false, 1, false>);
+        kern = a.idx64 ? dec_fused4_kernel<true, 2, false> : dec_fused4_kernel<false, 2, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
-    hipLaunchKernelGGL(kern, dim3(patches), dim3(nw * 64), lds, s, a);
+    static const int nosplit = getenv("TPU3_DEC_SPLIT") ? atoi(getenv("TPU3_DEC_SPLIT")) == 0 : 0;
+    // TPU3_DEC_PERSIST = workgroups per compute unit that walk the patches (0: one workgroup per patch)
+    static const int persist = getenv("TPU3_DEC_PERSIST") ? atoi(getenv("TPU3_DEC_PERSIST")) : 0;
+    static const int ncu = []() { int d = 0, v = 256; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    DecArgs a2 = a;
+    a2.nosplit = nosplit;
+    a2.patches = patches;
+    const int grid = persist > 0 ? min(patches, ncu * persist) : patches;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, a2);
     return tpu3_launch_status();
 }
 

@@ -14,7 +14,7 @@ idx = torch.randint(0, n, (B, n, k + 1), device=dev, dtype=torch.int32)
 out = torch.empty((B, n, 60), device=dev)
 ts = []
 with torch.no_grad():
-    for it in range(6):
+    for it in range(int(os.environ.get("ITERS", "6"))):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -23,4 +23,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
 flop = B * n * k * 3168.0
-print("dec ms: %s   (%.0f TFLOP/s of the block's 3168 FLOP per edge)" % (" ".join("%.3f" % t for t in ts), flop / min(ts) / 1e9))
+print("dec ms: %s   min %.3f median %.3f   (%.0f TFLOP/s of the block's 3168 FLOP per edge)"
+      % (" ".join("%.3f" % t for t in ts[:6]), min(ts), sorted(ts)[len(ts) // 2], flop / min(ts) / 1e9))
