@@ -6,7 +6,7 @@ importlib.import_module("3pu_pytorch_amd")
 ops = importlib.import_module("3pu_pytorch_amd.network.operations")
 dev = torch.device("cuda:0")
 B = int(os.environ.get("PATCHES", "3840"))
-n, C, k = 312, 24, 33
+n, C, k = int(os.environ.get("N", "312")), 24, 33
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand((B, n, C), device=dev, generator=g)
 owner = torch.repeat_interleave(torch.arange(B // 40, dtype=torch.int32, device=dev), 40)
@@ -20,4 +20,4 @@ for it in range(int(os.environ.get("ITERS", "6"))):
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
-print("knn_graph ms: %s" % " ".join("%.3f" % t for t in ts))
+print("knn_graph ms: %s   min %.3f median %.3f   %.2f ns per query" % (" ".join("%.3f" % t for t in ts[:6]), min(ts), sorted(ts)[len(ts) // 2], sorted(ts)[len(ts) // 2] * 1e6 / (B * n)))
