@@ -973,6 +973,9 @@ constexpr size_t dec4_lds_bytes(int n, int fold_n = 0)
             (size_t)fold_n * 60 + comb) * sizeof(float);
 }
 
+// left-over steps split over the waves (default) or dealt whole as before round 4: TPU3_DEC_SPLIT=0 / tpu3_debug_dec_split
+int g_dec_nosplit = getenv("TPU3_DEC_SPLIT") ? atoi(getenv("TPU3_DEC_SPLIT")) == 0 : 0;
+
 int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
 {
     // FOUR waves per workgroup, the 64-point steps dealt round-robin: with a wave per step a 312-point patch is
@@ -992,7 +995,7 @@ int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
-    static const int nosplit = getenv("TPU3_DEC_SPLIT") ? atoi(getenv("TPU3_DEC_SPLIT")) == 0 : 0;
+    const int nosplit = g_dec_nosplit;
     // TPU3_DEC_PERSIST = workgroups per compute unit that walk the patches (0: one workgroup per patch)
     static const int persist = getenv("TPU3_DEC_PERSIST") ? atoi(getenv("TPU3_DEC_PERSIST")) : 0;
     static const int ncu = []() { int d = 0, v = 256; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
@@ -1042,6 +1045,13 @@ int dec_launch(hipStream_t s, int patches, DecArgs &a)
 }
 
 } // namespace
+
+extern "C" int tpu3_debug_dec_split(int on)
+{
+    const int old = g_dec_nosplit ? 0 : 1;
+    g_dec_nosplit = on ? 0 : 1;
+    return old;
+}
 
 extern "C" int tpu3_dense_edge_conv_st_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
                                            const void *idx, int idx_elem_size, int idx_stride, int idx_off,

@@ -479,6 +479,11 @@ int tpu3_debug_knn_tiles_stats(unsigned *words);
  * every plan (more than 4 194 304 points).  The dispatch table of DESIGN section 4 as code. */
 int tpu3_debug_fps_cluster(int g);
 int tpu3_debug_fps_plan(int b, int n, int m, int *cluster);
+/* tpu3_debug_dec_split: the lane-per-point DenseEdgeConv kernel deals a patch's 64-point steps over four waves; steps
+ * left over (a 312-point patch: the fifth) are split by neighbour slots over the waves and combined by an LDS maximum
+ * (on = 1, the default) or taken whole by one wave (on = 0, the form before round 4; also TPU3_DEC_SPLIT=0).  Both
+ * give the same bits (tests/test_hip_network.py).  Returns the previous setting; host-side state only. */
+int tpu3_debug_dec_split(int on);
 
 /* The multi-workgroup FPS spins on its partner workgroups with BOUNDED polls; a launch whose workgroups never all
  * became resident gives up, leaves its outputs incomplete and counts a fault.  Returns the number of faulted

@@ -715,6 +715,44 @@ def test_dense_edge_conv_fused_matches_unfused(dev, P, N, k, monkeypatch):
         assert torch.equal(idx_f.long().sort(-1)[0], idx_k[:, :, 1:].sort(-1)[0])
 
 
+# 312: five steps on four waves, the fifth split four ways; 330 / 624: two left over, split two ways; 448: three left
+# over, dealt whole; k = 16 / 48: 4 / 12 slots per part
+@pytest.mark.parametrize("P,N,k", [(7, 312, 32), (3, 330, 32), (2, 624, 16), (2, 312, 48), (2, 448, 32)])
+@pytest.mark.parametrize("fold", [False, True])
+def test_dense_edge_conv_split_steps_give_the_same_bits(dev, P, N, k, fold):
+    """The left-over 64-point steps of a patch split by neighbour slots over the four waves (LDS maximum) against the
+    same kernel with one wave per step: bit-identical rows, with and without the folded prep convolutions."""
+    layers, ops = pkg("network.layers"), pkg("network.operations")
+    lib = pkg("_lib").lib()
+    blk = _dec_block(layers, dev, k, 7 * P + N)
+    g = torch.Generator(device=dev).manual_seed(N + k)
+    x = torch.randn(P, N, 24, device=dev, generator=g)
+    idx = torch.randint(0, N, (P, N, k + 1), device=dev, dtype=torch.int32, generator=g)
+    fw = torch.randn(72, 60, device=dev, generator=g) * 0.1
+    fb = torch.randn(72, device=dev, generator=g)
+
+    def run():
+        out = torch.zeros((P, N, 60), device=dev)
+        if not fold:
+            ops.BACKEND.dense_edge_conv(x, idx, 1, k, blk.mlps, out)
+            return (out,)
+        acc, xnext = torch.zeros((P, N, 48), device=dev), torch.zeros((P, N, 24), device=dev)
+        assert ops.BACKEND.dense_edge_conv_fold(x, idx, 1, k, blk.mlps, out, fw, fb, acc, 0, 0, xnext)
+        return out, acc, xnext
+
+    old = lib.tpu3_debug_dec_split(1)
+    try:
+        with torch.no_grad():
+            a = run()
+            lib.tpu3_debug_dec_split(0)
+            b = run()
+    finally:
+        lib.tpu3_debug_dec_split(old)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert float(a[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("P,N,k", [(4, 312, 32), (3, 1024, 32), (1, 3000, 16)])
 def test_dense_edge_conv_fp16_mfma_within_derived_bound(dev, P, N, k):
     """mlp_precision = "f16" (config C5: fp16 operands on the matrix cores, fp32 accumulate) on the same neighbour
