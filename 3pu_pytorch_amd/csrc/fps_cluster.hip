@@ -33,14 +33,16 @@
 // key ascending), independent of list order.  Bit-identical indices and final `temp`.
 //
 // Residency: the members of a cluster spin on each other, so all b * G workgroups of a launch must be resident.  The
-// dispatcher admits a launch's workgroups in order and every other kernel on the device terminates, so the clusters
-// already resident always complete and free their units (tests/test_hip_kernels.py runs 384 such workgroups on six
-// streams at once); the host keeps b * G <= 64 per launch.  Every poll is bounded: a member that gives up counts a
-// fault (tpu3_fps_cluster_faults, read by pipeline.upsample / bench.py at their synchronisation points; `stats[4]`)
-// and all members of its cluster leave.
+// host keeps b * G <= 64 per launch (a whole compute unit each) and, through a ring of events across streams, at most
+// (compute units / 64) = 4 cluster launches in flight per device (tpu3_fps_cluster_launch): everything else on the
+// device terminates, so every admitted launch gets its units (tests/test_hip_kernels.py runs 640 such workgroups on
+// ten streams at once).  Every poll is bounded all the same: a member that gives up counts a fault
+// (tpu3_fps_cluster_faults, read by pipeline.upsample / bench.py at their synchronisation points; `stats[4]`) and all
+// members of its cluster leave.
 #include "fps_bucket.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -897,8 +899,50 @@ int tpu3_fps_cluster_launch(hipStream_t s, int b, int g, const void *fb_args, vo
     e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return (int)e;
+    // The members of a set spin on each other, so every workgroup of a launch must become resident.  One launch alone
+    // always does: b g <= 64 workgroups of a whole compute unit each, and whatever else holds compute units drains.
+    // Launches on DIFFERENT streams could each hold part of the chip and wait for the rest (until the bounded spins
+    // give up and the fault counter says so): a ring of events keeps at most (compute units / 64) of them in flight
+    // per device -- launch i on any stream waits for launch i - 4.  (Not under stream capture: a captured launch is
+    // ordered by its graph.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)b * g), dim3(1024), lds, s, a0, lg, (u64 *)mbox, (u64 *)stats);
+        return tpu3_launch_status();
+    }
+    constexpr int MAXDEV = 16, RING = 8;
+    static std::mutex mu;
+    static hipEvent_t ring[MAXDEV][RING];
+    static unsigned long long issued[MAXDEV];
+    static int inflight[MAXDEV];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAXDEV)
+        dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!inflight[dev]) {
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        inflight[dev] = ncu / 64 < 1 ? 1 : (ncu / 64 > RING ? RING : ncu / 64);
+    }
+    const int slot = (int)(issued[dev] % (unsigned)inflight[dev]);
+    if (ring[dev][slot]) {
+        e = hipStreamWaitEvent(s, ring[dev][slot], 0);
+        if (e != hipSuccess)
+            return (int)e;
+    } else {
+        e = hipEventCreateWithFlags(&ring[dev][slot], hipEventDisableTiming);
+        if (e != hipSuccess)
+            return (int)e;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)b * g), dim3(1024), lds, s, a0, lg, (u64 *)mbox, (u64 *)stats);
-    return tpu3_launch_status();
+    const int rc = tpu3_launch_status();
+    if (rc)
+        return rc;
+    e = hipEventRecord(ring[dev][slot], s);
+    ++issued[dev];
+    return e == hipSuccess ? TPU3_OK : (int)e;
 }
 
 extern "C" long tpu3_fps_cluster_faults(int reset)

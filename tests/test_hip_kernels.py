@@ -241,29 +241,30 @@ def test_fps_cluster_form_ragged_and_continued(orc, dev, fps_cluster):
 
 
 def test_fps_cluster_launches_on_concurrent_streams(orc, dev, fps_cluster):
-    """Six cluster launches of 4 sets x 16 members (384 workgroups that spin on their partners, more than the 256
-    compute units hold) on six streams at once, next to streams of ordinary kernels: the members of a cluster are
-    dispatched in order, so every resident cluster completes and frees its units -- no launch may give up
+    """Ten cluster launches of 4 sets x 16 members (640 workgroups that spin on their partners; the 256 compute units
+    hold one each) on ten streams at once, next to streams of ordinary kernels, twice over.  Every workgroup of a
+    launch must become resident for the launch to finish: the library keeps at most (compute units / 64) cluster
+    launches in flight per device (an event ring across streams, csrc/fps_cluster.hip), so no launch may give up
     (tpu3_fps_cluster_faults stays 0, checked by the fixture) and every result is the oracle's."""
     ops = pkg("network.operations")
     fps_cluster(16)
-    n, m, b = 60000, 1500, 4
-    xyz = [sphere(900 + i, n, b) for i in range(6)]
+    n, m, b, L = 60000, 1500, 4, 10
+    xyz = [sphere(900 + i, n, b) for i in range(L)]
     xs = [_t(x, dev) for x in xyz]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(L + 2)]
     filler = torch.rand((4096, 4096), device=dev)
     torch.cuda.synchronize()
-    outs = [None] * 6
+    outs = [None] * L
     for rep in range(2):
-        for i in range(6):
+        for i in range(L):
             with torch.cuda.stream(streams[i]):
                 outs[i] = ops.fps(xs[i], m)
-        for st in streams[6:]:
+        for st in streams[L:]:
             with torch.cuda.stream(st):
                 for _ in range(6):
                     filler = filler @ filler * 1e-4
     torch.cuda.synchronize()
-    for i in range(6):
+    for i in range(L):
         ref_idx, _ = orc.fps(xyz[i], m)
         np.testing.assert_array_equal(outs[i].cpu().numpy(), ref_idx)
 
