@@ -65,28 +65,46 @@ struct DtLds {
 
 __device__ __forceinline__ void dt_load_weights(const DtArgs &a, DtLds &s)
 {
-    for (int e = threadIdx.x; e < 12 * 24; e += DT_THREADS) {
-        const int c = e / 24, d = e - c * 24;
-        s.eh[e] = a.w0[c * 48 + 24 + d];
-        s.h2w[e] = a.w2[c * 48 + d];
+    // every global load is requested before the first LDS store (r4): as ten load -> store iterations the image cost
+    // ten dependent round trips at the head of every workgroup
+    const int tid = threadIdx.x;
+    float r_eh[2], r_h2[2], r_h1 = 0.f, r_xw[4], r_xb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * DT_THREADS, c = e / 24, d = e - c * 24;
+        r_eh[i] = e < 12 * 24 ? a.w0[c * 48 + 24 + d] : 0.f;
+        r_h2[i] = e < 12 * 24 ? a.w2[c * 48 + d] : 0.f;
     }
-    for (int e = threadIdx.x; e < 12 * 12; e += DT_THREADS) {
-        const int c = e / 12, d = e - c * 12;
-        s.h1w[e] = a.w1[c * 36 + d];
+    if (tid < 12 * 12) {
+        const int c = tid / 12, d = tid - c * 12;
+        r_h1 = a.w1[c * 36 + d];
     }
-    for (int e = threadIdx.x; e < 36 * 24; e += DT_THREADS) {
-        const int r = e / 24, d = e - r * 24, c = r % 12;
-        float v;
-        if (r < 12)
-            v = a.w2[c * 48 + 24 + d];
-        else if (r < 24)
-            v = a.w1[c * 36 + 12 + d];
-        else
-            v = a.w0[c * 48 + d];
-        s.xw[r * 25 + d] = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * DT_THREADS, r = e / 24, d = e - r * 24, c = r % 12;
+        const float *src = r < 12 ? a.w2 + c * 48 + 24 + d : (r < 24 ? a.w1 + c * 36 + 12 + d : a.w0 + c * 48 + d);
+        r_xw[i] = e < 36 * 24 ? *src : 0.f;
     }
-    for (int e = threadIdx.x; e < 36; e += DT_THREADS)
-        s.xb[e] = e < 12 ? a.b2[e] : (e < 24 ? a.b1[e - 12] : a.b0[e - 24]);
+    if (tid < 36)
+        r_xb = tid < 12 ? a.b2[tid] : (tid < 24 ? a.b1[tid - 12] : a.b0[tid - 24]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * DT_THREADS;
+        if (e < 12 * 24) {
+            s.eh[e] = r_eh[i];
+            s.h2w[e] = r_h2[i];
+        }
+    }
+    if (tid < 12 * 12)
+        s.h1w[tid] = r_h1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * DT_THREADS, r = e / 24, d = e - r * 24;
+        if (e < 36 * 24)
+            s.xw[r * 25 + d] = r_xw[i];
+    }
+    if (tid < 36)
+        s.xb[tid] = r_xb;
     __syncthreads();
 }
 
@@ -379,10 +397,18 @@ int dt_check(long p, int n, int k, int idx_stride, int idx_off)
     return TPU3_OK;
 }
 
-unsigned dt_grid(long points)
+// One workgroup per compute-unit slot, walking its passes (r4).  The backward kernel holds 256 registers per lane --
+// ONE workgroup per compute unit -- and a training batch is ~1250 passes of 8 points: launched as 1248 workgroups of one
+// pass each (the cap used to be 2048) it ran five rounds of (weights into LDS, ~10 dependent load -> LDS-store round
+// trips; then one pass) with nothing to hide either behind: 112 us per launch.  `per_cu` = workgroups a compute unit
+// holds (backward 1, forward 2 at 188 registers); TPU3_DT_GRID overrides the cap (tuning hook).
+unsigned dt_grid(long points, int per_cu)
 {
+    static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    static const long cap_env = getenv("TPU3_DT_GRID") ? atol(getenv("TPU3_DT_GRID")) : 0;
     long blocks = (points + DT_THREADS / 32 - 1) / (DT_THREADS / 32);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const long cap = cap_env > 0 ? cap_env : (long)cus * per_cu;
+    if (blocks > cap) blocks = cap;
     return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
@@ -399,7 +425,7 @@ extern "C" int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k
     if (((uintptr_t)x & 15) != 0) return TPU3_ELIMIT;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, y, arg, nullptr, nullptr, nullptr, nullptr,
              nullptr};
-    hipLaunchKernelGGL(dec_train_fwd_kernel, dim3(dt_grid(a.points)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_train_fwd_kernel, dim3(dt_grid(a.points, 2)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }
 
@@ -415,6 +441,6 @@ extern "C" int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k
     if ((((uintptr_t)x | (uintptr_t)G | (uintptr_t)Z | (uintptr_t)S) & 15) != 0) return TPU3_ELIMIT;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, nullptr, const_cast<uint8_t *>(arg), gy, gx,
              G, Z, S};
-    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(dt_grid(a.points)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(dt_grid(a.points, 1)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }
