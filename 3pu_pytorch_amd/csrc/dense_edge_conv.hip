@@ -978,10 +978,10 @@ int g_dec_nosplit = getenv("TPU3_DEC_SPLIT") ? atoi(getenv("TPU3_DEC_SPLIT")) ==
 
 int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
 {
-    // FOUR waves per workgroup, the 64-point steps dealt round-robin: with a wave per step a 312-point patch is
-    // 5 waves on 4 SIMDs -- two of them share a SIMD, run at half speed and hold the workgroup's LDS and register
-    // slots while three SIMDs wait.  With four, the wave that takes two steps runs alone on its SIMD as long as the
-    // others, and the slots of the finished ones go to the next workgroup.  TPU3_DEC_NW / TPU3_DEC_U: tuning hooks.
+    // FOUR waves per workgroup, the whole 64-point steps dealt round-robin and the left-over ones split by neighbour
+    // slots (see the kernel): with a wave per step a 312-point patch is 5 waves on 4 SIMDs -- two of them share a SIMD,
+    // run at half speed and hold the workgroup's LDS and register slots while three SIMDs wait (0.70 vs 0.535 ms per
+    // 3840-patch launch).  TPU3_DEC_NW: tuning hook.
     static const int nw_env = getenv("TPU3_DEC_NW") ? atoi(getenv("TPU3_DEC_NW")) : 4;
     const int nw = min(min(DEC4_MAXW, max(1, nw_env)), (a.n + 63) / 64);
     const size_t lds = dec4_lds_bytes(a.n, a.fold_n);
