@@ -18,8 +18,8 @@
 // forward:  y (P,N,60) and arg (P,N,36) u8 = the edge slot that attains each maximum (lowest slot on ties).
 // backward: the forward chain is recomputed per edge, the incoming gradient of channel c goes to the edge
 //           arg[c], and with g_2, g_1 = relu'(a_1) (.. + W_2h1^T g_2), g_0 = relu'(a_0) (.. + W_2h0^T g_2 + W_1h^T g_1)
-//   G (edges, 36) = [g_2 | g_1 | g_0],  Z (edges, 48) = [h_1 | h_0 | d_j]      -> weight gradients of the edge
-//                                                                                  parts (tpu3_linear_wgrad_f32)
+//   G (36 per edge) = [g_2 | g_1 | g_0],  Z (48 per edge) = [h_1 | h_0 | d_j]  -> weight gradients of the edge parts
+//                                      (tpu3_dec_train_wgrad_f32); both as float4 PLANES over the edges (r4, see the stores)
 //   S (points, 36) = sum over the point's edges of G                            -> weight gradients of the x_i parts
 //                                                                                  (S^T X) and all bias gradients
 //   gx (points, 24) += gy_x + [W_2x; W_1x; W_0a - W_0b]^T S   (own point)   and   gx[j] += W_0b^T g_0   (neighbour),
@@ -42,7 +42,8 @@ struct DtArgs {
     uint8_t *arg;                   // (P,N,36)
     const float *gy;                // bwd: (P,N,60)
     float *gx;                      // (P,N,24), accumulated
-    float *G, *Z, *S;               // (P*N*32, 36), (P*N*32, 48), (P*N, 36)
+    float *G, *Z, *S;               // 9 / 12 float4 planes over the P*N*32 edges; (P*N, 36)
+    long plane;                     // float4 entries between planes (tpu3_dec_train_plane_stride)
 };
 
 // LDS image of the weights:
@@ -61,6 +62,8 @@ struct DtLds {
     float stage[DT_THREADS / 32][40];
     float nb[DT_THREADS / 32][DT_K][25];    // backward: the 32 neighbour shares of a half wave, [edge][channel] (padded)
     int nbrow[DT_THREADS / 32][DT_K];       //           and their rows
+    float sgy[DT_THREADS / 32][64];         //           the point's incoming gradient row (60) ...
+    int sarg[DT_THREADS / 32][40];          //           ... and its 36 arg-max slots, requested with the pass's first loads
 };
 
 __device__ __forceinline__ void dt_load_weights(const DtArgs &a, DtLds &s)
@@ -143,38 +146,105 @@ __device__ __forceinline__ void dt_point_terms(const DtLds &s, float *st, const 
         st[32 + hl] = t1;
 }
 
-// forward chain of one edge: a0, a1 (pre-activations), h2
-__device__ __forceinline__ void dt_edge_forward(const DtLds &s, const float *st, const float (&dj)[DT_C],
+// ---- (r4) the edge chains on v_mfma_f32_4x4x1 ---------------------------------------------------------------------
+// A lane owns an edge, and every product of the block is "12 or 24 outputs = W x (the lane's own vector)" with the same W
+// in every lane -- the layout of dec_fused4_kernel (csrc/dense_edge_conv.hip): one v_mfma_f32_4x4x1 with B = component k
+// of the lane's vector and A = W[4 rg .. 4 rg + 3][k] adds input k to outputs 4 rg .. 4 rg + 3 of 64 edges; the
+// instruction's A-broadcast control (cbsz = 4, abid = b) takes A from block b (lanes 4 b .. 4 b + 3) for all blocks, so
+// ONE register carries 16 (row group, k) operands and the six matrices of forward and backward live in 26 registers.
+// As scalar fmaf chains with the weights as wave-uniform LDS reads the backward kernel issued ~380 LDS reads per pass,
+// each waited for by the ONE wave per SIMD its 256 + 138 registers allowed: 20 us per pass.  The sums run in the same
+// order as before (ascending k, seeded with the same value): same bits.
+typedef float dt_f4 __attribute__((ext_vector_type(4)));
+
+// operand register v of a matrix with K inputs: lane 4 b + i holds entry (row 4 rg + i, column k) of operand
+// q = 16 v + b = rg K + k; `rs` / `cs` = strides of the matrix's rows / columns in `w` (cs = 1: as stored, rs = 1:
+// transposed)
+template <int NREG>
+__device__ __forceinline__ void dt_load_operands(float (&op)[NREG], const float *w, int K, int count, int rs, int cs)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int v = 0; v < NREG; ++v) {
+        const int q = 16 * v + (lane >> 2), i = lane & 3;
+        const int rg = q / K, k = q - rg * K;
+        op[v] = q < count ? w[(4 * rg + i) * rs + k * cs] : 0.f;
+    }
+}
+
+template <int Q, int NREG>
+__device__ __forceinline__ dt_f4 dt_mfma(const float (&op)[NREG], float b, dt_f4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(op[Q / 16], b, c, 4, Q % 16, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void dt_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dt_static_for<I + 1, N>(f);
+    }
+}
+
+// out[4 rg + i] += sum_k W[4 rg + i][k] in[k] for RG row groups, K inputs (ascending k: one fma chain per output)
+template <int RG, int K, int NREG>
+__device__ __forceinline__ void dt_matvec(const float (&op)[NREG], const float (&in)[K], float (&out)[4 * RG])
+{
+    dt_f4 acc[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+        acc[rg] = (dt_f4){out[4 * rg], out[4 * rg + 1], out[4 * rg + 2], out[4 * rg + 3]};
+    dt_static_for<0, K>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        dt_static_for<0, RG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int rg = decltype(rc)::value;
+            acc[rg] = dt_mfma<rg * K + k>(op, in[k], acc[rg]);
+        });
+    });
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+        out[4 * rg] = acc[rg][0]; out[4 * rg + 1] = acc[rg][1]; out[4 * rg + 2] = acc[rg][2]; out[4 * rg + 3] = acc[rg][3];
+    }
+}
+
+struct DtFwdOps {
+    float w0b[5], w1h[3], w2h[5];       // 3 x 24, 3 x 12, 3 x 24 operands
+};
+
+__device__ __forceinline__ void dt_load_fwd_ops(const DtArgs &a, DtFwdOps &o, bool with_h2)
+{
+    dt_load_operands(o.w0b, a.w0 + 24, 24, 72, 48, 1);
+    dt_load_operands(o.w1h, a.w1, 12, 36, 36, 1);
+    if (with_h2)
+        dt_load_operands(o.w2h, a.w2, 24, 72, 48, 1);
+}
+
+// forward chain of one edge: a0, a1 (pre-activations) and (H2) h2
+template <bool H2>
+__device__ __forceinline__ void dt_edge_forward(const DtFwdOps &o, const float *st, const float (&dj)[DT_C],
                                                 float (&a0)[DT_G], float (&a1)[DT_G], float (&h2)[DT_G])
 {
 #pragma unroll
     for (int c = 0; c < DT_G; ++c) {
-        float acc = st[24 + c];
-#pragma unroll
-        for (int d = 0; d < DT_C; ++d)
-            acc = __builtin_fmaf(s.eh[c * 24 + d], dj[d], acc);
-        a0[c] = acc;
-        __builtin_amdgcn_sched_barrier(0);              // (a row of weight reads in flight at a time: registers)
+        a0[c] = st[24 + c];
+        a1[c] = st[12 + c];
     }
+    dt_matvec<3, 24>(o.w0b, dj, a0);
+    float r0[DT_G];
 #pragma unroll
-    for (int c = 0; c < DT_G; ++c) {
-        float acc = st[12 + c];
+    for (int c = 0; c < DT_G; ++c)
+        r0[c] = fmaxf(a0[c], 0.f);
+    dt_matvec<3, 12>(o.w1h, r0, a1);
+    if constexpr (H2) {
+        float r10[24];
 #pragma unroll
-        for (int d = 0; d < DT_G; ++d)
-            acc = __builtin_fmaf(s.h1w[c * 12 + d], fmaxf(a0[d], 0.f), acc);
-        a1[c] = acc;
-    }
-#pragma unroll
-    for (int c = 0; c < DT_G; ++c) {
-        float acc = st[c];
-#pragma unroll
-        for (int d = 0; d < DT_G; ++d)
-            acc = __builtin_fmaf(s.h2w[c * 24 + d], fmaxf(a1[d], 0.f), acc);
-#pragma unroll
-        for (int d = 0; d < DT_G; ++d)
-            acc = __builtin_fmaf(s.h2w[c * 24 + 12 + d], fmaxf(a0[d], 0.f), acc);
-        h2[c] = acc;
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < DT_G; ++c) {
+            h2[c] = st[c];
+            r10[c] = fmaxf(a1[c], 0.f);
+            r10[12 + c] = r0[c];
+        }
+        dt_matvec<3, 24>(o.w2h, r10, h2);
     }
 }
 
@@ -198,6 +268,8 @@ __device__ __forceinline__ void dt_load_edge(const DtArgs &a, long pt, int hl, f
 __global__ __launch_bounds__(DT_THREADS) void dec_train_fwd_kernel(DtArgs a)
 {
     __shared__ DtLds s;
+    DtFwdOps ops;
+    dt_load_fwd_ops(a, ops, true);
     dt_load_weights(a, s);
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
     float *st = s.stage[half];
@@ -215,7 +287,7 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_fwd_kernel(DtArgs a)
         __builtin_amdgcn_wave_barrier();                            //  across waves: a half never spans two)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float a0[DT_G], a1[DT_G], h2[DT_G];
-        dt_edge_forward(s, st, dj, a0, a1, h2);
+        dt_edge_forward<true>(ops, st, dj, a0, a1, h2);
         // maxima over the 32 edges and the slot that attains each (lowest on ties)
         float m[36];
         uint32_t slot[36];
@@ -247,6 +319,14 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_fwd_kernel(DtArgs a)
 __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
 {
     __shared__ DtLds s;
+    DtFwdOps ops;
+    dt_load_fwd_ops(a, ops, false);
+    // transposed operands of the backward products: t = W_2h^T g_2 (24 outputs = 6 row groups, 12 inputs),
+    // u = W_1h^T g_1 (12, 12), vb = W_0b^T g_0 (24, 12)
+    float t2[5], t1[3], t0[5];
+    dt_load_operands(t2, a.w2, 12, 72, 1, 48);
+    dt_load_operands(t1, a.w1, 12, 36, 1, 36);
+    dt_load_operands(t0, a.w0 + 24, 12, 72, 1, 48);
     dt_load_weights(a, s);
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
     float *st = s.stage[half];
@@ -258,32 +338,42 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         const long pt = live ? pt0 : a.points - 1;
         float xi[DT_C], dj[DT_C];
         long jrow;
+        // the point's incoming gradient and arg-max record: requested together with the rows (behind the Z / G stores
+        // their loads waited for every store before them: 45 % of the kernel), handed to the half wave through LDS
+        const float gy_a = a.gy[pt * 60 + hl], gy_b = hl < 28 ? a.gy[pt * 60 + 32 + hl] : 0.f;
+        const int ar_a = a.arg[pt * 36 + hl], ar_b = hl < 4 ? a.arg[pt * 36 + 32 + hl] : 0;
         dt_load_edge(a, pt, hl, xi, dj, jrow);
+        s.sgy[half][hl] = gy_a;
+        s.sgy[half][32 + hl] = gy_b;
+        s.sarg[half][hl] = ar_a;
+        if (hl < 4)
+            s.sarg[half][32 + hl] = ar_b;
         dt_point_terms(s, st, xi, hl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float a0[DT_G], a1[DT_G], h2[DT_G];
-        dt_edge_forward(s, st, dj, a0, a1, h2);
+        dt_edge_forward<false>(ops, st, dj, a0, a1, h2);
         const long edge = pt * DT_K + hl;
-        if (live) {                                                 // Z = [h1 | h0 | d_j]
-            float4 *zo = (float4 *)(a.Z + edge * 48);
+        if (live) {                                                 // Z = [h1 | h0 | d_j], float4 planes over the edges
+            float4 *zo = (float4 *)a.Z + edge;
+            const size_t ps = (size_t)a.plane;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                zo[q] = make_float4(fmaxf(a1[4 * q], 0.f), fmaxf(a1[4 * q + 1], 0.f), fmaxf(a1[4 * q + 2], 0.f),
-                                    fmaxf(a1[4 * q + 3], 0.f));
+                zo[q * ps] = make_float4(fmaxf(a1[4 * q], 0.f), fmaxf(a1[4 * q + 1], 0.f), fmaxf(a1[4 * q + 2], 0.f),
+                                         fmaxf(a1[4 * q + 3], 0.f));
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                zo[3 + q] = make_float4(fmaxf(a0[4 * q], 0.f), fmaxf(a0[4 * q + 1], 0.f), fmaxf(a0[4 * q + 2], 0.f),
-                                        fmaxf(a0[4 * q + 3], 0.f));
+                zo[(3 + q) * ps] = make_float4(fmaxf(a0[4 * q], 0.f), fmaxf(a0[4 * q + 1], 0.f), fmaxf(a0[4 * q + 2], 0.f),
+                                               fmaxf(a0[4 * q + 3], 0.f));
 #pragma unroll
             for (int q = 0; q < 6; ++q)
-                zo[6 + q] = make_float4(dj[4 * q], dj[4 * q + 1], dj[4 * q + 2], dj[4 * q + 3]);
+                zo[(6 + q) * ps] = make_float4(dj[4 * q], dj[4 * q + 1], dj[4 * q + 2], dj[4 * q + 3]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // incoming gradient of channel c goes to the edge that attained the maximum
-        const float *gyp = a.gy + pt * 60;
-        const uint8_t *ap = a.arg + pt * 36;
+        const float *gyp = s.sgy[half];
+        const int *ap = s.sarg[half];
         float g2[DT_G], g1[DT_G], g0[DT_G];
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
@@ -292,13 +382,7 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
 #pragma unroll
         for (int d = 0; d < 24; ++d)
             t[d] = 0.f;
-#pragma unroll
-        for (int c = 0; c < DT_G; ++c) {
-#pragma unroll
-            for (int d = 0; d < 24; ++d)
-                t[d] = __builtin_fmaf(s.h2w[c * 24 + d], g2[c], t[d]);
-            __builtin_amdgcn_sched_barrier(0);          // (six weight reads in flight, not all 72: registers)
-        }
+        dt_matvec<6, 12>(t2, g2, t);
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
             g1[c] = a1[c] > 0.f ? ((int)ap[12 + c] == hl ? gyp[12 + c] : 0.f) + t[c] : 0.f;
@@ -307,28 +391,22 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
 #pragma unroll
         for (int d = 0; d < DT_G; ++d)
             u[d] = 0.f;
-#pragma unroll
-        for (int c = 0; c < DT_G; ++c) {
-#pragma unroll
-            for (int d = 0; d < DT_G; ++d)
-                u[d] = __builtin_fmaf(s.h1w[c * 12 + d], g1[c], u[d]);
-            if (c % 2 == 1)
-                __builtin_amdgcn_sched_barrier(0);
-        }
+        dt_matvec<3, 12>(t1, g1, u);
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
             g0[c] = a0[c] > 0.f ? ((int)ap[24 + c] == hl ? gyp[24 + c] : 0.f) + t[12 + c] + u[c] : 0.f;
         if (live) {
-            float4 *go = (float4 *)(a.G + edge * 36);
+            float4 *go = (float4 *)a.G + edge;
+            const size_t ps = (size_t)a.plane;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                go[q] = make_float4(g2[4 * q], g2[4 * q + 1], g2[4 * q + 2], g2[4 * q + 3]);
+                go[q * ps] = make_float4(g2[4 * q], g2[4 * q + 1], g2[4 * q + 2], g2[4 * q + 3]);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                go[3 + q] = make_float4(g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]);
+                go[(3 + q) * ps] = make_float4(g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                go[6 + q] = make_float4(g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]);
+                go[(6 + q) * ps] = make_float4(g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // neighbour's share: W_0b^T g_0
@@ -337,13 +415,7 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
 #pragma unroll
             for (int d = 0; d < DT_C; ++d)
                 vb[d] = 0.f;
-#pragma unroll
-            for (int c = 0; c < DT_G; ++c) {
-#pragma unroll
-                for (int d = 0; d < DT_C; ++d)
-                    vb[d] = __builtin_fmaf(s.eh[c * 24 + d], g0[c], vb[d]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            dt_matvec<6, 12>(t0, g0, vb);
             // scatter with a lane per CHANNEL: 24 lanes add one neighbour's 96 contiguous bytes per instruction (a
             // lane per edge would issue 64 separate 4-byte atomics per instruction: 0.46 ms per launch, 24x the
             // L2 transactions)
@@ -357,6 +429,7 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (live && hl < DT_C) {
+#pragma unroll
             for (int e = 0; e < DT_K; ++e)
                 atomicAdd(a.gx + (long)s.nbrow[half][e] * DT_C + hl, s.nb[half][e][hl]);
         }
@@ -402,6 +475,18 @@ int dt_check(long p, int n, int k, int idx_stride, int idx_off)
 // pass each (the cap used to be 2048) it ran five rounds of (weights into LDS, ~10 dependent load -> LDS-store round
 // trips; then one pass) with nothing to hide either behind: 112 us per launch.  `per_cu` = workgroups a compute unit
 // holds (backward 1, forward 2 at 188 registers); TPU3_DT_GRID overrides the cap (tuning hook).
+} // namespace
+
+// float4 entries between consecutive planes of G / Z: the edge count rounded up to 64 plus 17 -- with the bare count
+// (a multiple of 2^13 for the training batch) the same edge of all 21 planes fell into the same memory channel
+extern "C" long tpu3_dec_train_plane_stride(long points)
+{
+    const long e = points * DT_K;
+    return (e + 63) / 64 * 64 + 17;
+}
+
+namespace {
+
 unsigned dt_grid(long points, int per_cu)
 {
     static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
@@ -424,7 +509,7 @@ extern "C" int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !y || !arg) return TPU3_EINVAL;
     if (((uintptr_t)x & 15) != 0) return TPU3_ELIMIT;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, y, arg, nullptr, nullptr, nullptr, nullptr,
-             nullptr};
+             nullptr, 0};
     hipLaunchKernelGGL(dec_train_fwd_kernel, dim3(dt_grid(a.points, 2)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }
@@ -440,7 +525,7 @@ extern "C" int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !arg || !gy || !gx || !G || !Z || !S) return TPU3_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)G | (uintptr_t)Z | (uintptr_t)S) & 15) != 0) return TPU3_ELIMIT;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, nullptr, const_cast<uint8_t *>(arg), gy, gx,
-             G, Z, S};
-    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(dt_grid(a.points, 1)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
+             G, Z, S, tpu3_dec_train_plane_stride(p * n)};
+    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(dt_grid(a.points, 2)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }

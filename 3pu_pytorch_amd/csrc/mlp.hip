@@ -1043,12 +1043,16 @@ struct WgradAllArgs {
     float *partial;                      // (blocks, OG * 16, ct * 16)
     long rows_per_block;
     int ct;                              // 16-column tiles of cin + 1 columns
+    long plane = 0;                      // FLAT == 2: float4 entries between the planes of x and of dy
 };
 
 // FLAT (CTW == 1 only): x and dy are dense row-major with 4 | cin, 4 | cout -- a tile's 64 rows are one contiguous
 // block of each, fetched as float4 (6 loads per lane for the 48 -> 36 edge tensors of a DenseEdgeConv block instead of
 // 32 dword loads of which a quarter of the lanes idle: 62 -> 40 us for its 107 MB)
-template <int OG, int CTW, bool FLAT = false>
+// FLAT == 2 (r4): x and dy are stored as float4 PLANES -- plane q = columns 4 q .. 4 q + 3 of all m rows, (m, 4) dense --
+// the layout in which the DenseEdgeConv training backward writes its edge tensors (a lane per edge: 64 lanes x 16 B of a
+// plane are one contiguous KB per store instruction; row-major they were 64 pieces of 64 different lines)
+template <int OG, int CTW, int FLAT = 0>
 __global__ __launch_bounds__(256) void linear_wgrad_all_kernel(WgradAllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -1071,7 +1075,40 @@ __global__ __launch_bounds__(256) void linear_wgrad_all_kernel(WgradAllArgs a)
         // a store per element was 56 us per tile of the 265 -> 128 layer)
         constexpr int YL = (OG * 16 + 63) / 64;
         constexpr int RB = CTW == 1 ? 16 : CTW == 2 ? 8 : 4;        // rows per batch: ~30 loads per lane in flight
-        if constexpr (FLAT) {
+        if constexpr (FLAT == 2) {
+            const int left = (int)(r_hi - r0 < 64 ? r_hi - r0 : 64);
+            const int nxq = a.cin / 4, nyq = a.cout / 4;
+            const float4 *X4 = (const float4 *)a.x + r0, *Y4 = (const float4 *)a.dy + r0;
+            float4 xq[4], yq[OG];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
+                xq[u] = (q < nxq && r < left) ? X4[(size_t)q * a.plane + r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < OG; ++u) {
+                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
+                yq[u] = (q < nyq && r < left) ? Y4[(size_t)q * a.plane + r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
+                if (q < nxq) {
+                    float *d = xs + r * xw + 4 * q;
+                    d[0] = xq[u].x; d[1] = xq[u].y; d[2] = xq[u].z; d[3] = xq[u].w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OG; ++u) {
+                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
+                if (q < nyq) {
+                    float *d = dys + r * yw + 4 * q;
+                    d[0] = yq[u].x; d[1] = yq[u].y; d[2] = yq[u].z; d[3] = yq[u].w;
+                }
+            }
+            if (tid < 64)
+                xs[tid * xw + a.cin] = tid < left ? 1.f : 0.f;
+        } else if constexpr (FLAT == 1) {
             const long left = (r_hi - r0 < 64 ? r_hi - r0 : 64);
             const int nx = (int)left * a.cin / 4, ny = (int)left * a.cout / 4;
             const float4 *X4 = (const float4 *)(a.x + r0 * a.cin), *Y4 = (const float4 *)(a.dy + r0 * a.cout);
@@ -1227,14 +1264,20 @@ WgradAllPlan wgrad_all_plan(long m, int cin, int cout)
 }
 
 template <int OG, int CTW>
-int wgrad_all_launch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a)
+int wgrad_all_launch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a, bool planes = false)
 {
     auto kern = linear_wgrad_all_kernel<OG, CTW>;
     if constexpr (CTW == 1) {
+        if (planes) {
+            if (a.cin % 4 || a.cout % 4 || a.cin > 60 || a.cout > 16 * OG || ((((uintptr_t)a.x | (uintptr_t)a.dy) & 15) != 0))
+                return TPU3_EINVAL;
+            kern = linear_wgrad_all_kernel<OG, 1, 2>;
+        } else {
         const bool flat = a.xs == a.cin && a.dys == a.cout && a.cin % 4 == 0 && a.cout % 4 == 0 && a.cin <= 60 &&
                           (((uintptr_t)a.x | (uintptr_t)a.dy) & 15) == 0;
         if (flat)
-            kern = linear_wgrad_all_kernel<OG, 1, true>;
+            kern = linear_wgrad_all_kernel<OG, 1, 1>;
+        }
     }
     if (p.lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
@@ -1473,6 +1516,8 @@ extern "C" size_t tpu3_dec_train_wgrad_workspace_bytes(long points)
     return wgrad_all_plan(points * 32, 48, 36).bytes + wgrad_all_plan(points, 24, 36).bytes;
 }
 
+extern "C" long tpu3_dec_train_plane_stride(long points);
+
 extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S,
                                         const float *Z, const float *G, float *gw0, float *gw1, float *gw2, float *gb,
                                         void *workspace, size_t workspace_bytes)
@@ -1483,9 +1528,10 @@ extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const
     if (!workspace || workspace_bytes < pe.bytes + pp.bytes) return TPU3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float *we = (float *)workspace, *wp = (float *)((char *)workspace + pe.bytes);
-    WgradAllArgs ae{points * 32, 48, 36, 48, 36, Z, G, we, pe.rpb, pe.ct};
+    WgradAllArgs ae{points * 32, 48, 36, 48, 36, Z, G, we, pe.rpb, pe.ct, tpu3_dec_train_plane_stride(points)};
     WgradAllArgs ap{points, 24, 36, 24, 36, x, S, wp, pp.rpb, pp.ct};
-    int r = wgrad_all_launch<4, 1>(s, pe, ae);          // (49 columns: 4 tiles, one per wave; 36 outputs: 4 groups)
+    int r = wgrad_all_launch<4, 1>(s, pe, ae, true);    // (49 columns: 4 tiles, one per wave; 36 outputs: 4 groups; Z and G
+                                                        //  arrive as float4 planes, see tpu3_dec_train_bwd_f32)
     if (r) return r;
     r = wgrad_all_launch<4, 1>(s, pp, ap);              // (25 columns: 2 tiles)
     if (r) return r;

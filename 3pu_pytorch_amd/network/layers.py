@@ -161,20 +161,10 @@ class _FusedDECTrain(torch.autograd.Function):
         weights = ctx.saved_tensors[3:]
         be = operations.BACKEND
         gx, G, Z, S = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
-        if hasattr(be, "dec_train_wgrad"):
-            gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, Z, G)
-            return (gx, None, None, gw0.view(ctx.shapes[0]), gb[24:36], gw1.view(ctx.shapes[1]), gb[12:24],
-                    gw2.view(ctx.shapes[2]), gb[0:12])
-        # (backends without the fused entry: the same sums piece by piece)
-        g2h = be.linear_wgrad(Z[:, 0:24], G[:, 0:12])               # W_2[:, 0:24]  (inputs [h1, h0])
-        g1h = be.linear_wgrad(Z[:, 12:24], G[:, 12:24])             # W_1[:, 0:12]  (input h0)
-        g0b = be.linear_wgrad(Z[:, 24:48], G[:, 24:36])             # W_0[:, 24:48] (input x_j - x_i)
-        gxw = S.t().matmul(x.view(-1, x.size(-1)))                  # (36, 24): rows W_2x, W_1x, W_0a
-        gb = S.sum(dim=0)
-        gw0 = torch.cat([gxw[24:36], g0b], dim=1).view(ctx.shapes[0])
-        gw1 = torch.cat([g1h, gxw[12:24]], dim=1).view(ctx.shapes[1])
-        gw2 = torch.cat([g2h, gxw[0:12]], dim=1).view(ctx.shapes[2])
-        return gx, None, None, gw0, gb[24:36], gw1, gb[12:24], gw2, gb[0:12]
+        # (G and Z are float4 planes over the edges, the layout tpu3_dec_train_wgrad_f32 reads -- include/tpu3.h)
+        gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, Z, G)
+        return (gx, None, None, gw0.view(ctx.shapes[0]), gb[24:36], gw1.view(ctx.shapes[1]), gb[12:24],
+                gw2.view(ctx.shapes[2]), gb[0:12])
 
 
 def linear_1x1(conv, x):

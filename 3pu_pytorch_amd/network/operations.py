@@ -455,12 +455,14 @@ class HipBackend(object):
         return y, arg
 
     def dec_train_backward(self, x, idx, idx_off, weights, arg, gy):
-        """-> gx (P,N,24), G (P*N*32, 36), Z (P*N*32, 48), S (P*N, 36); see tpu3_dec_train_bwd_f32."""
+        """-> gx (P,N,24), G (9 float4 planes over the P*N*32 edges), Z (12 planes), S (P*N, 36); see
+        tpu3_dec_train_bwd_f32.  G and Z are for dec_train_wgrad only."""
         P, N, _ = x.shape
         dev = x.device
         gx = torch.zeros((P, N, 24), dtype=torch.float32, device=dev)
-        G = torch.empty((P * N * 32, 36), dtype=torch.float32, device=dev)
-        Z = torch.empty((P * N * 32, 48), dtype=torch.float32, device=dev)
+        stride = int(L.lib().tpu3_dec_train_plane_stride(P * N))
+        G = torch.empty((9, stride, 4), dtype=torch.float32, device=dev)
+        Z = torch.empty((12, stride, 4), dtype=torch.float32, device=dev)
         S = torch.empty((P * N, 36), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.check(L.lib().tpu3_dec_train_bwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
