@@ -1585,6 +1585,24 @@ namespace {
 // The self graph's first (usually only) pass: one pass with the index in the key's low bits (n up to 2^13: >= 10
 // mantissa bits stay), the two-pass kernel beyond that and for n == k.  Either raises uws[2] when rows may be
 // duplicated.
+// Threads per workgroup of the self graph: the patch's queries in one workgroup (312 points: five waves share one
+// staged tile) when the launch fills the chip; ONE WAVE per workgroup (r4) when all waves of the launch find a SIMD
+// of their own -- a training batch (32 patches) or one cloud's 48 outer patches used to be 32 / 48 workgroups whose
+// five waves shared four SIMDs of one compute unit while most of the chip idled (82 -> 63 us per call).
+// TPU3_KG_THREADS: tuning hook.
+int kg_graph_threads(int b, int n)
+{
+    static const int forced = getenv("TPU3_KG_THREADS") ? atoi(getenv("TPU3_KG_THREADS")) : 0;
+    static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    if (forced > 0)
+        return forced;
+    int threads = ((n + 63) / 64) * 64;
+    if (threads > 512) threads = 256;
+    if ((long)b * ((n + 63) / 64) <= 8L * cus)      // (384 patches: 0.124 vs 0.142 ms; 768: 0.207 vs 0.173)
+        threads = 64;
+    return threads;
+}
+
 int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a)
 {
     const int c = a.c, k = a.k;
@@ -1629,8 +1647,7 @@ extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c
     hipError_t e = hipMemsetAsync(uws, 0, (size_t)TPU3_KNN_UWS_WORDS(groups) * sizeof(uint32_t), s);
     if (e != hipSuccess) return (int)e;
     KnnArgs a{n, n, c, k, b, 1, x, x, nullptr, nullptr, nullptr, L.grp, dup, uws, 2, 0, idx, 0, nullptr};
-    int threads = ((n + 63) / 64) * 64;
-    if (threads > 512) threads = 256;
+    const int threads = kg_graph_threads(b, n);
     const dim3 g((n + threads - 1) / threads, b);
     int r = launch_graph_first_pass(s, g, threads, a);
     if (r) return r;
@@ -1675,8 +1692,7 @@ extern "C" int tpu3_knn_graph_self_optimistic_f32(tpu3_stream_t stream, int b, i
     if (L.pts_of || L.n_arr || L.m_arr) return TPU3_EINVAL;      // dense self query only
     hipStream_t s = (hipStream_t)stream;
     KnnArgs a{n, n, c, k, b, 1, x, x, nullptr, nullptr, nullptr, L.grp, nullptr, events, 2, 0, idx, 0, nullptr};
-    int threads = ((n + 63) / 64) * 64;
-    if (threads > 512) threads = 256;
+    const int threads = kg_graph_threads(b, n);
     const dim3 g((n + threads - 1) / threads, b);
     return launch_graph_first_pass(s, g, threads, a);
 }
