@@ -51,7 +51,7 @@ SIGNATURES = {
     "tpu3_linear_small_st_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "tpu3_dec_train_fwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_dec_train_bwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _sz]),
     "tpu3_gather_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_scatter_add_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_linear_wide_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i]),
@@ -60,9 +60,8 @@ SIGNATURES = {
     "tpu3_linear_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),
     "tpu3_linear_wgrad_bias_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz]),
     "tpu3_linear_wgrad_bias_workspace_bytes": (_sz, [ctypes.c_long, _i, _i]),
-    "tpu3_dec_train_wgrad_f32": (_i, [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "tpu3_dec_train_wgrad_f32": (_i, [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "tpu3_dec_train_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),
-    "tpu3_dec_train_plane_stride": (ctypes.c_long, [ctypes.c_long]),
     "tpu3_knn_tiles_build_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "tpu3_knn_tiles_workspace_bytes": (_sz, [_i, _i]),
     "tpu3_knn_tiles_query_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

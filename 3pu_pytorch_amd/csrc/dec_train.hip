@@ -18,8 +18,9 @@
 // forward:  y (P,N,60) and arg (P,N,36) u8 = the edge slot that attains each maximum (lowest slot on ties).
 // backward: the forward chain is recomputed per edge, the incoming gradient of channel c goes to the edge
 //           arg[c], and with g_2, g_1 = relu'(a_1) (.. + W_2h1^T g_2), g_0 = relu'(a_0) (.. + W_2h0^T g_2 + W_1h^T g_1)
-//   G (36 per edge) = [g_2 | g_1 | g_0],  Z (48 per edge) = [h_1 | h_0 | d_j]  -> weight gradients of the edge parts
-//                                      (tpu3_dec_train_wgrad_f32); both as float4 PLANES over the edges (r4, see the stores)
+//   G (36 per edge) = [g_2 | g_1 | g_0],  Z (48 per edge) = [h_1 | h_0 | d_j]  -> weight gradients of the edge parts:
+//                                      G^T Z is ACCUMULATED IN THIS KERNEL (r4, dt_wgrad_round; one 36 x 48 block per
+//                                      workgroup for tpu3_dec_train_wgrad_f32 to add up) -- G and Z never reach memory
 //   S (points, 36) = sum over the point's edges of G                            -> weight gradients of the x_i parts
 //                                                                                  (S^T X) and all bias gradients
 //   gx (points, 24) += gy_x + [W_2x; W_1x; W_0a - W_0b]^T S   (own point)   and   gx[j] += W_0b^T g_0   (neighbour),
@@ -30,6 +31,7 @@ namespace {
 
 constexpr int DT_C = 24, DT_G = 12, DT_K = 32;
 constexpr int DT_THREADS = 256;             // 4 waves = 8 points per pass
+constexpr int DT_TRS = 61;                  // floats per edge row of the transposition region (60 used)
 
 struct DtArgs {
     long points;                    // P * N
@@ -42,8 +44,8 @@ struct DtArgs {
     uint8_t *arg;                   // (P,N,36)
     const float *gy;                // bwd: (P,N,60)
     float *gx;                      // (P,N,24), accumulated
-    float *G, *Z, *S;               // 9 / 12 float4 planes over the P*N*32 edges; (P*N, 36)
-    long plane;                     // float4 entries between planes (tpu3_dec_train_plane_stride)
+    float *S;                       // (P*N, 36)
+    float *wpart;                   // (gridDim.x, 64, 64): the workgroups' G^T Z blocks (rows 0 .. 35, columns 0 .. 47 used)
 };
 
 // LDS image of the weights:
@@ -60,8 +62,11 @@ struct DtLds {
     float xw[36 * 25];
     float xb[36];
     float stage[DT_THREADS / 32][40];
-    float nb[DT_THREADS / 32][DT_K][25];    // backward: the 32 neighbour shares of a half wave, [edge][channel] (padded)
-    int nbrow[DT_THREADS / 32][DT_K];       //           and their rows
+    // backward: per wave, its 64 edges' rows [g (12, one of g_2 / g_1 / g_0 at a time) | h_1 | h_0 | d_j] with an odd
+    // stride -- written a lane per edge, read back a lane per CHANNEL as the operands of the weight-gradient matrix
+    // instructions (dt_wgrad_round); afterwards the same floats hold the 2 x 32 neighbour shares [edge][25] of the scatter
+    float tr[DT_THREADS / 64][64 * DT_TRS + 8];
+    int nbrow[DT_THREADS / 32][DT_K];       // rows of the neighbour shares
     float sgy[DT_THREADS / 32][64];         //           the point's incoming gradient row (60) ...
     int sarg[DT_THREADS / 32][40];          //           ... and its 36 arg-max slots, requested with the pass's first loads
 };
@@ -316,7 +321,39 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_fwd_kernel(DtArgs a)
     }
 }
 
-__global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
+// ---- (r4) the weight gradients of the edge parts, in the backward kernel ------------------------------------------------
+// dW[o][c] = sum over edges of g[e][o] z[e][c] is a matrix product with the EDGES as the inner dimension, and the kernel
+// holds an edge per lane: the wave's 64 rows [g | h_1 | h_0 | d_j] go through LDS once (a lane per edge writes its row, stride
+// 61: conflict-free both ways) and come back a lane per channel as operands of v_mfma_f32_16x16x4_f32 -- A[o][k] = g of
+// edge 4 t + k, B[k][c] = z of edge 4 t + k, 16 steps of four edges.  Three rounds (g_2 x [h_1 h_0], g_1 x h_0, g_0 x d_j),
+// five 16 x 16 accumulators per wave that live across the passes: 80 matrix instructions per 64 edges.  Before, G and Z
+// went to memory (107 MB per block, 21 store instructions per lane) and a second kernel streamed them back through LDS
+// for the same product: 57 us of a block's 135.  Columns beyond a block's width and rows beyond 12 compute on whatever
+// the neighbouring LDS words hold and are never stored.
+typedef float dt_v4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ void dt_wgrad_round(const float *tw, int bcol, dt_v4 (&acc)[NT])
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float *r = tw + g * DT_TRS + i;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float av = r[(4 * t) * DT_TRS];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, r[(4 * t) * DT_TRS + bcol + 16 * n], acc[n], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void dt_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_train_bwd_kernel(DtArgs a)
 {
     __shared__ DtLds s;
     DtFwdOps ops;
@@ -330,6 +367,13 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
     dt_load_weights(a, s);
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
     float *st = s.stage[half];
+    float *tw = s.tr[threadIdx.x >> 6];                             // the wave's transposition region
+    float *trow = tw + (threadIdx.x & 63) * DT_TRS;                 // ... and the lane's (edge's) row in it
+    dt_v4 wacc2[2], wacc1[1], wacc0[2];                             // G2^T [h1 h0] (cols 0-15, 16-31), G1^T h0, G0^T d_j (0-15, 16-31)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        wacc2[n] = wacc0[n] = (dt_v4){0.f, 0.f, 0.f, 0.f};
+    wacc1[0] = (dt_v4){0.f, 0.f, 0.f, 0.f};
     const long per_pass = (long)gridDim.x * (DT_THREADS / 32);
     const long passes = (a.points + per_pass - 1) / per_pass;
     for (long it = 0; it < passes; ++it) {
@@ -338,8 +382,8 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         const long pt = live ? pt0 : a.points - 1;
         float xi[DT_C], dj[DT_C];
         long jrow;
-        // the point's incoming gradient and arg-max record: requested together with the rows (behind the Z / G stores
-        // their loads waited for every store before them: 45 % of the kernel), handed to the half wave through LDS
+        // the point's incoming gradient and arg-max record: requested together with the rows (behind other memory
+        // operations their loads waited for everything before them: 45 % of the kernel once), handed over through LDS
         const float gy_a = a.gy[pt * 60 + hl], gy_b = hl < 28 ? a.gy[pt * 60 + 32 + hl] : 0.f;
         const int ar_a = a.arg[pt * 36 + hl], ar_b = hl < 4 ? a.arg[pt * 36 + 32 + hl] : 0;
         dt_load_edge(a, pt, hl, xi, dj, jrow);
@@ -354,22 +398,15 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float a0[DT_G], a1[DT_G], h2[DT_G];
         dt_edge_forward<false>(ops, st, dj, a0, a1, h2);
-        const long edge = pt * DT_K + hl;
-        if (live) {                                                 // Z = [h1 | h0 | d_j], float4 planes over the edges
-            float4 *zo = (float4 *)a.Z + edge;
-            const size_t ps = (size_t)a.plane;
+        // Z = [h1 | h0 | d_j] into the edge's row of the transposition region (columns 12 .. 59)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                zo[q * ps] = make_float4(fmaxf(a1[4 * q], 0.f), fmaxf(a1[4 * q + 1], 0.f), fmaxf(a1[4 * q + 2], 0.f),
-                                         fmaxf(a1[4 * q + 3], 0.f));
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                zo[(3 + q) * ps] = make_float4(fmaxf(a0[4 * q], 0.f), fmaxf(a0[4 * q + 1], 0.f), fmaxf(a0[4 * q + 2], 0.f),
-                                               fmaxf(a0[4 * q + 3], 0.f));
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                zo[(6 + q) * ps] = make_float4(dj[4 * q], dj[4 * q + 1], dj[4 * q + 2], dj[4 * q + 3]);
+        for (int c = 0; c < DT_G; ++c) {
+            trow[12 + c] = fmaxf(a1[c], 0.f);
+            trow[24 + c] = fmaxf(a0[c], 0.f);
         }
+#pragma unroll
+        for (int d = 0; d < DT_C; ++d)
+            trow[36 + d] = dj[d];
         __builtin_amdgcn_sched_barrier(0);
         // incoming gradient of channel c goes to the edge that attained the maximum
         const float *gyp = s.sgy[half];
@@ -377,7 +414,20 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         float g2[DT_G], g1[DT_G], g0[DT_G];
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
-            g2[c] = (int)ap[c] == hl ? gyp[c] : 0.f;
+            g2[c] = (live && (int)ap[c] == hl) ? gyp[c] : 0.f;        // (idle halves: no contribution to anything)
+#pragma unroll
+        for (int c = 0; c < DT_G; ++c)
+            trow[c] = g2[c];
+        // S = sums over the point's edges, 12 at a time as the g's appear (`st`'s forward terms are all read by now):
+        // taken at the end of the pass they kept all 36 values alive across the three rounds
+#pragma unroll
+        for (int c = 0; c < DT_G; ++c) {
+            const float v = dt_half_sum(g2[c]);
+            if (hl == 0)
+                st[c] = v;
+        }
+        dt_wave_sync();
+        dt_wgrad_round<2>(tw, 12, wacc2);
         float t[24];                                                // W_2h^T g_2: gradient w.r.t. [h_1, h_0]
 #pragma unroll
         for (int d = 0; d < 24; ++d)
@@ -385,8 +435,19 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         dt_matvec<6, 12>(t2, g2, t);
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
-            g1[c] = a1[c] > 0.f ? ((int)ap[12 + c] == hl ? gyp[12 + c] : 0.f) + t[c] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
+            g1[c] = (live && a1[c] > 0.f) ? ((int)ap[12 + c] == hl ? gyp[12 + c] : 0.f) + t[c] : 0.f;
+        dt_wave_sync();                                             // (round 1's reads of column block 0 are done)
+#pragma unroll
+        for (int c = 0; c < DT_G; ++c)
+            trow[c] = g1[c];
+#pragma unroll
+        for (int c = 0; c < DT_G; ++c) {
+            const float v = dt_half_sum(g1[c]);
+            if (hl == 0)
+                st[12 + c] = v;
+        }
+        dt_wave_sync();
+        dt_wgrad_round<1>(tw, 24, wacc1);
         float u[DT_G];                                              // W_1h^T g_1: gradient w.r.t. h_0
 #pragma unroll
         for (int d = 0; d < DT_G; ++d)
@@ -394,20 +455,20 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         dt_matvec<3, 12>(t1, g1, u);
 #pragma unroll
         for (int c = 0; c < DT_G; ++c)
-            g0[c] = a0[c] > 0.f ? ((int)ap[24 + c] == hl ? gyp[24 + c] : 0.f) + t[12 + c] + u[c] : 0.f;
-        if (live) {
-            float4 *go = (float4 *)a.G + edge;
-            const size_t ps = (size_t)a.plane;
+            g0[c] = (live && a0[c] > 0.f) ? ((int)ap[24 + c] == hl ? gyp[24 + c] : 0.f) + t[12 + c] + u[c] : 0.f;
+        dt_wave_sync();
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                go[q * ps] = make_float4(g2[4 * q], g2[4 * q + 1], g2[4 * q + 2], g2[4 * q + 3]);
+        for (int c = 0; c < DT_G; ++c)
+            trow[c] = g0[c];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                go[(3 + q) * ps] = make_float4(g1[4 * q], g1[4 * q + 1], g1[4 * q + 2], g1[4 * q + 3]);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                go[(6 + q) * ps] = make_float4(g0[4 * q], g0[4 * q + 1], g0[4 * q + 2], g0[4 * q + 3]);
+        for (int c = 0; c < DT_G; ++c) {
+            const float v = dt_half_sum(g0[c]);
+            if (hl == 0)
+                st[24 + c] = v;
         }
+        dt_wave_sync();
+        dt_wgrad_round<2>(tw, 36, wacc0);
+        dt_wave_sync();                                             // (the region is free for the neighbour shares)
         __builtin_amdgcn_sched_barrier(0);
         // neighbour's share: W_0b^T g_0
         {
@@ -419,7 +480,7 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
             // scatter with a lane per CHANNEL: 24 lanes add one neighbour's 96 contiguous bytes per instruction (a
             // lane per edge would issue 64 separate 4-byte atomics per instruction: 0.46 ms per launch, 24x the
             // L2 transactions)
-            float *nbs = &s.nb[half][hl][0];
+            float *nbs = tw + ((threadIdx.x & 63) >> 5) * (DT_K * 25) + hl * 25;   // [half of the wave][edge][25]
 #pragma unroll
             for (int d = 0; d < DT_C; ++d)
                 nbs[d] = vb[d];
@@ -431,16 +492,9 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
         if (live && hl < DT_C) {
 #pragma unroll
             for (int e = 0; e < DT_K; ++e)
-                atomicAdd(a.gx + (long)s.nbrow[half][e] * DT_C + hl, s.nb[half][e][hl]);
+                atomicAdd(a.gx + (long)s.nbrow[half][e] * DT_C + hl, tw[((threadIdx.x & 63) >> 5) * (DT_K * 25) + e * 25 + hl]);
         }
-        // S = sum over the point's edges of [g_2 | g_1 | g_0]; every lane of the half ends with all 36 in `st`
-        __builtin_amdgcn_wave_barrier();                            // (`st` still holds the forward terms: all read by now)
-#pragma unroll
-        for (int c = 0; c < 36; ++c) {
-            const float v = dt_half_sum(c < 12 ? g2[c] : (c < 24 ? g1[c - 12] : g0[c - 24]));
-            if (hl == 0)
-                st[c] = v;
-        }
+        // (S = the sums over the point's edges of [g_2 | g_1 | g_0] are in `st` by now, see above)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -459,7 +513,35 @@ __global__ __launch_bounds__(DT_THREADS) void dec_train_bwd_kernel(DtArgs a)
                 atomicAdd(a.gx + pt * DT_C + hl, acc);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        dt_wave_sync();                                             // (the shares are read: the region takes rows again)
+    }
+    // the workgroup's G^T Z block: the four waves' accumulators added in a fixed order (through the transposition
+    // regions), rows = G column (g_2 0-11, g_1 12-23, g_0 24-35), columns = Z column, (64, 64) per workgroup
+    __syncthreads();
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float *red = &s.tr[0][0] + wv * (5 * 4 * 64);               // [pair][q][lane]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[(0 * 4 + q) * 64 + lane] = wacc2[0][q];
+            red[(1 * 4 + q) * 64 + lane] = wacc2[1][q];
+            red[(2 * 4 + q) * 64 + lane] = wacc1[0][q];
+            red[(3 * 4 + q) * 64 + lane] = wacc0[0][q];
+            red[(4 * 4 + q) * 64 + lane] = wacc0[1][q];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 5 * 4 * 64; e += DT_THREADS) {
+        const float *red = &s.tr[0][0];
+        const float v = (red[e] + red[e + 1280]) + (red[e + 2560] + red[e + 3840]);
+        const int pair = e >> 8, q = (e >> 6) & 3, lane = e & 63, i = lane & 15, o = 4 * (lane >> 4) + q;
+        // pair 0 / 1: rows o, columns i / 16 + i (< 24); pair 2: rows 12 + o, columns 12 + i (< 24); pair 3 / 4: rows
+        // 24 + o, columns 24 + i / 40 + i (< 48)
+        const int row = pair < 2 ? o : (pair == 2 ? 12 + o : 24 + o);
+        const int col = pair == 0 ? i : pair == 1 ? 16 + i : pair == 2 ? 12 + i : pair == 3 ? 24 + i : 40 + i;
+        const bool ok = o < 12 && (pair == 1 ? i < 8 : pair == 2 ? i < 12 : pair == 4 ? i < 8 : true);
+        if (ok)
+            a.wpart[(size_t)blockIdx.x * 4096 + row * 64 + col] = v;
     }
 }
 
@@ -470,23 +552,17 @@ int dt_check(long p, int n, int k, int idx_stride, int idx_off)
     return TPU3_OK;
 }
 
-// One workgroup per compute-unit slot, walking its passes (r4).  The backward kernel holds 256 registers per lane --
-// ONE workgroup per compute unit -- and a training batch is ~1250 passes of 8 points: launched as 1248 workgroups of one
-// pass each (the cap used to be 2048) it ran five rounds of (weights into LDS, ~10 dependent load -> LDS-store round
-// trips; then one pass) with nothing to hide either behind: 112 us per launch.  `per_cu` = workgroups a compute unit
-// holds (backward 1, forward 2 at 188 registers); TPU3_DT_GRID overrides the cap (tuning hook).
 } // namespace
 
-// float4 entries between consecutive planes of G / Z: the edge count rounded up to 64 plus 17 -- with the bare count
-// (a multiple of 2^13 for the training batch) the same edge of all 21 planes fell into the same memory channel
-extern "C" long tpu3_dec_train_plane_stride(long points)
-{
-    const long e = points * DT_K;
-    return (e + 63) / 64 * 64 + 17;
-}
+// workgroups of the backward launch = blocks of its weight-gradient output (tpu3_dec_train_wgrad_f32 adds them up)
+int tpu3_dec_train_bwd_blocks(long points);
 
 namespace {
 
+// One workgroup per compute-unit slot, walking its passes (r4): a training batch is ~1250 passes of 8 points; launched as
+// 1248 workgroups of one pass each (the cap used to be 2048) every workgroup paid the weight image and the operand
+// registers for a single pass.  `per_cu` = workgroups a compute unit holds (two at ~200 registers); TPU3_DT_GRID
+// overrides the cap (tuning hook).
 unsigned dt_grid(long points, int per_cu)
 {
     static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
@@ -508,24 +584,30 @@ extern "C" int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k
     if (p == 0) return TPU3_OK;
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !y || !arg) return TPU3_EINVAL;
     if (((uintptr_t)x & 15) != 0) return TPU3_ELIMIT;
-    DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, y, arg, nullptr, nullptr, nullptr, nullptr,
-             nullptr, 0};
+    DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, y, arg, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(dec_train_fwd_kernel, dim3(dt_grid(a.points, 2)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
+}
+
+int tpu3_dec_train_bwd_blocks(long points)
+{
+    return (int)dt_grid(points, 2);
 }
 
 extern "C" int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
                                       int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                                       const float *b1, const float *w2, const float *b2, const uint8_t *arg,
-                                      const float *gy, float *gx, float *G, float *Z, float *S)
+                                      const float *gy, float *gx, float *S, void *workspace, size_t workspace_bytes)
 {
     const int r = dt_check(p, n, k, idx_stride, idx_off);
     if (r) return r;
     if (p == 0) return TPU3_OK;
-    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !arg || !gy || !gx || !G || !Z || !S) return TPU3_EINVAL;
-    if ((((uintptr_t)x | (uintptr_t)G | (uintptr_t)Z | (uintptr_t)S) & 15) != 0) return TPU3_ELIMIT;
+    if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !arg || !gy || !gx || !S || !workspace) return TPU3_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)S | (uintptr_t)workspace) & 15) != 0) return TPU3_EINVAL;
+    const unsigned grid = dt_grid(p * n, 2);
+    if (workspace_bytes < (size_t)grid * 4096 * sizeof(float)) return TPU3_EINVAL;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, nullptr, const_cast<uint8_t *>(arg), gy, gx,
-             G, Z, S, tpu3_dec_train_plane_stride(p * n)};
-    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(dt_grid(a.points, 2)), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
+             S, (float *)workspace};
+    hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(grid), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }

@@ -1043,16 +1043,12 @@ struct WgradAllArgs {
     float *partial;                      // (blocks, OG * 16, ct * 16)
     long rows_per_block;
     int ct;                              // 16-column tiles of cin + 1 columns
-    long plane = 0;                      // FLAT == 2: float4 entries between the planes of x and of dy
 };
 
 // FLAT (CTW == 1 only): x and dy are dense row-major with 4 | cin, 4 | cout -- a tile's 64 rows are one contiguous
 // block of each, fetched as float4 (6 loads per lane for the 48 -> 36 edge tensors of a DenseEdgeConv block instead of
 // 32 dword loads of which a quarter of the lanes idle: 62 -> 40 us for its 107 MB)
-// FLAT == 2 (r4): x and dy are stored as float4 PLANES -- plane q = columns 4 q .. 4 q + 3 of all m rows, (m, 4) dense --
-// the layout in which the DenseEdgeConv training backward writes its edge tensors (a lane per edge: 64 lanes x 16 B of a
-// plane are one contiguous KB per store instruction; row-major they were 64 pieces of 64 different lines)
-template <int OG, int CTW, int FLAT = 0>
+template <int OG, int CTW, bool FLAT = false>
 __global__ __launch_bounds__(256) void linear_wgrad_all_kernel(WgradAllArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -1075,40 +1071,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_all_kernel(WgradAllArgs a)
         // a store per element was 56 us per tile of the 265 -> 128 layer)
         constexpr int YL = (OG * 16 + 63) / 64;
         constexpr int RB = CTW == 1 ? 16 : CTW == 2 ? 8 : 4;        // rows per batch: ~30 loads per lane in flight
-        if constexpr (FLAT == 2) {
-            const int left = (int)(r_hi - r0 < 64 ? r_hi - r0 : 64);
-            const int nxq = a.cin / 4, nyq = a.cout / 4;
-            const float4 *X4 = (const float4 *)a.x + r0, *Y4 = (const float4 *)a.dy + r0;
-            float4 xq[4], yq[OG];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
-                xq[u] = (q < nxq && r < left) ? X4[(size_t)q * a.plane + r] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < OG; ++u) {
-                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
-                yq[u] = (q < nyq && r < left) ? Y4[(size_t)q * a.plane + r] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
-                if (q < nxq) {
-                    float *d = xs + r * xw + 4 * q;
-                    d[0] = xq[u].x; d[1] = xq[u].y; d[2] = xq[u].z; d[3] = xq[u].w;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < OG; ++u) {
-                const int f = tid + 256 * u, q = f >> 6, r = f & 63;
-                if (q < nyq) {
-                    float *d = dys + r * yw + 4 * q;
-                    d[0] = yq[u].x; d[1] = yq[u].y; d[2] = yq[u].z; d[3] = yq[u].w;
-                }
-            }
-            if (tid < 64)
-                xs[tid * xw + a.cin] = tid < left ? 1.f : 0.f;
-        } else if constexpr (FLAT == 1) {
+        if constexpr (FLAT) {
             const long left = (r_hi - r0 < 64 ? r_hi - r0 : 64);
             const int nx = (int)left * a.cin / 4, ny = (int)left * a.cout / 4;
             const float4 *X4 = (const float4 *)(a.x + r0 * a.cin), *Y4 = (const float4 *)(a.dy + r0 * a.cout);
@@ -1264,20 +1227,14 @@ WgradAllPlan wgrad_all_plan(long m, int cin, int cout)
 }
 
 template <int OG, int CTW>
-int wgrad_all_launch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a, bool planes = false)
+int wgrad_all_launch(hipStream_t s, const WgradAllPlan &p, const WgradAllArgs &a)
 {
     auto kern = linear_wgrad_all_kernel<OG, CTW>;
     if constexpr (CTW == 1) {
-        if (planes) {
-            if (a.cin % 4 || a.cout % 4 || a.cin > 60 || a.cout > 16 * OG || ((((uintptr_t)a.x | (uintptr_t)a.dy) & 15) != 0))
-                return TPU3_EINVAL;
-            kern = linear_wgrad_all_kernel<OG, 1, 2>;
-        } else {
         const bool flat = a.xs == a.cin && a.dys == a.cout && a.cin % 4 == 0 && a.cout % 4 == 0 && a.cin <= 60 &&
                           (((uintptr_t)a.x | (uintptr_t)a.dy) & 15) == 0;
         if (flat)
-            kern = linear_wgrad_all_kernel<OG, 1, 1>;
-        }
+            kern = linear_wgrad_all_kernel<OG, 1, true>;
     }
     if (p.lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
@@ -1448,9 +1405,10 @@ extern "C" int tpu3_linear_wgrad_bias_f32(tpu3_stream_t stream, long m, int cin,
 }
 
 // ---- the weight and bias gradients of a DenseEdgeConv block from what its backward kernel leaves behind ---------
-// (csrc/dec_train.hip: G (edges,36) = [g2 | g1 | g0], Z (edges,48) = [h1 | h0 | d_j], S (points,36) = G summed over
-// a point's edges.)  Two streaming passes -- G^T Z over the 3e5 edges, S^T [x | 1] over the points -- and ONE kernel
-// that adds the row ranges' blocks and writes the three layers' gradients in their own layout:
+// (csrc/dec_train.hip: one block G^T Z per workgroup of the backward launch -- G (edges,36) = [g2 | g1 | g0], Z (edges,48)
+// = [h1 | h0 | d_j] never reach memory since round 4 --, S (points,36) = G summed over a point's edges.)  One streaming
+// pass S^T [x | 1] over the points and ONE kernel that adds the blocks and writes the three layers' gradients in their
+// own layout:
 //   W_2 (12,48) = [G2^T Z[:, 0:24]  | S2^T x],  W_1 (12,36) = [G1^T Z[:, 12:24] | S1^T x],
 //   W_0 (12,48) = [S0^T x           | G0^T Z[:, 24:48]],  biases = column sums of S.
 namespace {
@@ -1510,33 +1468,30 @@ __global__ __launch_bounds__(1024) void dec_wgrad_assemble_kernel(int blocks_e, 
 
 } // namespace
 
+int tpu3_dec_train_bwd_blocks(long points);           // csrc/dec_train.hip
+
 extern "C" size_t tpu3_dec_train_wgrad_workspace_bytes(long points)
 {
     if (points <= 0) return 0;
-    return wgrad_all_plan(points * 32, 48, 36).bytes + wgrad_all_plan(points, 24, 36).bytes;
+    return (size_t)tpu3_dec_train_bwd_blocks(points) * 4096 * sizeof(float) + wgrad_all_plan(points, 24, 36).bytes;
 }
 
-extern "C" long tpu3_dec_train_plane_stride(long points);
-
-extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S,
-                                        const float *Z, const float *G, float *gw0, float *gw1, float *gw2, float *gb,
-                                        void *workspace, size_t workspace_bytes)
+extern "C" int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S, float *gw0,
+                                        float *gw1, float *gw2, float *gb, void *workspace, size_t workspace_bytes)
 {
     if (points <= 0) return TPU3_EINVAL;
-    if (!x || !S || !Z || !G || !gw0 || !gw1 || !gw2 || !gb) return TPU3_EINVAL;
-    const WgradAllPlan pe = wgrad_all_plan(points * 32, 48, 36), pp = wgrad_all_plan(points, 24, 36);
-    if (!workspace || workspace_bytes < pe.bytes + pp.bytes) return TPU3_EINVAL;
+    if (!x || !S || !gw0 || !gw1 || !gw2 || !gb) return TPU3_EINVAL;
+    const int blocks_e = tpu3_dec_train_bwd_blocks(points);
+    const size_t ebytes = (size_t)blocks_e * 4096 * sizeof(float);
+    const WgradAllPlan pp = wgrad_all_plan(points, 24, 36);
+    if (!workspace || workspace_bytes < ebytes + pp.bytes) return TPU3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    float *we = (float *)workspace, *wp = (float *)((char *)workspace + pe.bytes);
-    WgradAllArgs ae{points * 32, 48, 36, 48, 36, Z, G, we, pe.rpb, pe.ct, tpu3_dec_train_plane_stride(points)};
+    float *we = (float *)workspace, *wp = (float *)((char *)workspace + ebytes);
     WgradAllArgs ap{points, 24, 36, 24, 36, x, S, wp, pp.rpb, pp.ct};
-    int r = wgrad_all_launch<4, 1>(s, pe, ae, true);    // (49 columns: 4 tiles, one per wave; 36 outputs: 4 groups; Z and G
-                                                        //  arrive as float4 planes, see tpu3_dec_train_bwd_f32)
-    if (r) return r;
-    r = wgrad_all_launch<4, 1>(s, pp, ap);              // (25 columns: 2 tiles)
+    const int r = wgrad_all_launch<4, 1>(s, pp, ap);    // (25 columns: 2 tiles)
     if (r) return r;
     hipLaunchKernelGGL(dec_wgrad_assemble_kernel, dim3((12 * 48 * 2 + 12 * 36 + 36 + 63) / 64), dim3(1024), 0, s,
-                       (int)pe.blocks, (int)pp.blocks, (const float *)we, (const float *)wp, gw0, gw1, gw2, gb);
+                       blocks_e, (int)pp.blocks, (const float *)we, (const float *)wp, gw0, gw1, gw2, gb);
     return tpu3_launch_status();
 }
 

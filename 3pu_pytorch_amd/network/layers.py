@@ -140,9 +140,9 @@ def gather_neighbours(x, idx):
 
 class _FusedDECTrain(torch.autograd.Function):
     """The (24, 12, 3, k = 32) DenseEdgeConv block as ONE autograd node (csrc/dec_train.hip): forward and backward
-    are one launch each; the weight and bias gradients come from the two edge tensors and the per-point sums S the
-    backward kernel leaves behind, in three more launches (tpu3_dec_train_wgrad_f32: two streaming passes and
-    one kernel that writes the layers' own layouts)."""
+    are one launch each; the backward kernel accumulates the weight gradients of the edge parts on the matrix cores (one
+    block per workgroup) and leaves the per-point sums S; tpu3_dec_train_wgrad_f32 adds a streaming pass S^T [x | 1] and
+    one kernel that sums the blocks and writes the layers' own layouts."""
 
     @staticmethod
     def forward(ctx, x, idx, idx_off, w0, b0, w1, b1, w2, b2):
@@ -160,9 +160,8 @@ class _FusedDECTrain(torch.autograd.Function):
         x, idx, arg = ctx.saved_tensors[:3]
         weights = ctx.saved_tensors[3:]
         be = operations.BACKEND
-        gx, G, Z, S = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
-        # (G and Z are float4 planes over the edges, the layout tpu3_dec_train_wgrad_f32 reads -- include/tpu3.h)
-        gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, Z, G)
+        gx, S, ws = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
+        gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, ws)
         return (gx, None, None, gw0.view(ctx.shapes[0]), gb[24:36], gw1.view(ctx.shapes[1]), gb[12:24],
                 gw2.view(ctx.shapes[2]), gb[0:12])
 

@@ -455,36 +455,34 @@ class HipBackend(object):
         return y, arg
 
     def dec_train_backward(self, x, idx, idx_off, weights, arg, gy):
-        """-> gx (P,N,24), G (9 float4 planes over the P*N*32 edges), Z (12 planes), S (P*N, 36); see
-        tpu3_dec_train_bwd_f32.  G and Z are for dec_train_wgrad only."""
+        """-> gx (P,N,24), S (P*N, 36) and the workspace that holds the workgroups' weight-gradient blocks of the edge
+        parts (for dec_train_wgrad); see tpu3_dec_train_bwd_f32."""
         P, N, _ = x.shape
         dev = x.device
+        lib = L.lib()
         gx = torch.zeros((P, N, 24), dtype=torch.float32, device=dev)
-        stride = int(L.lib().tpu3_dec_train_plane_stride(P * N))
-        G = torch.empty((9, stride, 4), dtype=torch.float32, device=dev)
-        Z = torch.empty((12, stride, 4), dtype=torch.float32, device=dev)
         S = torch.empty((P * N, 36), dtype=torch.float32, device=dev)
+        need = lib.tpu3_dec_train_wgrad_workspace_bytes(P * N)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.check(L.lib().tpu3_dec_train_bwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
-                                                   *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), L.ptr(gx),
-                                                   L.ptr(G), L.ptr(Z), L.ptr(S)), "tpu3_dec_train_bwd_f32")
-        return gx, G, Z, S
+            L.check(lib.tpu3_dec_train_bwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
+                                               *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), L.ptr(gx),
+                                               L.ptr(S), L.ptr(ws), need), "tpu3_dec_train_bwd_f32")
+        return gx, S, ws
 
-    def dec_train_wgrad(self, x, S, Z, G):
-        """The block's weight gradients (12,48), (12,36), (12,48) and bias gradients (36) = [b2 | b1 | b0] from the
-        backward kernel's tensors: tpu3_dec_train_wgrad_f32 (three launches)."""
+    def dec_train_wgrad(self, x, S, ws):
+        """The block's weight gradients (12,48), (12,36), (12,48) and bias gradients (36) = [b2 | b1 | b0] from what the
+        backward kernel left behind: tpu3_dec_train_wgrad_f32 (two launches)."""
         points = S.size(0)
         dev = x.device
         lib = L.lib()
-        need = lib.tpu3_dec_train_wgrad_workspace_bytes(points)
-        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         gw0 = torch.empty((12, 48), dtype=torch.float32, device=dev)
         gw1 = torch.empty((12, 36), dtype=torch.float32, device=dev)
         gw2 = torch.empty((12, 48), dtype=torch.float32, device=dev)
         gb = torch.empty((36,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            L.check(lib.tpu3_dec_train_wgrad_f32(L.stream_of(x), points, L.ptr(x), L.ptr(S), L.ptr(Z), L.ptr(G),
-                                                 L.ptr(gw0), L.ptr(gw1), L.ptr(gw2), L.ptr(gb), L.ptr(ws), need),
+            L.check(lib.tpu3_dec_train_wgrad_f32(L.stream_of(x), points, L.ptr(x), L.ptr(S), L.ptr(gw0), L.ptr(gw1),
+                                                 L.ptr(gw2), L.ptr(gb), L.ptr(ws), ws.numel()),
                     "tpu3_dec_train_wgrad_f32")
         return gw0, gw1, gw2, gb
 

@@ -364,7 +364,7 @@ def train_rooflines(ops, ups, dev, ratio=16, reps=3):
     shape0 = lambda t, *a, **kw: tuple(t.shape)
     kt.wrap("dec_train_forward", lambda x, idx, off, w: tuple(x.shape))
     kt.wrap("dec_train_backward", lambda x, idx, off, w, arg, gy: tuple(x.shape))
-    kt.wrap("dec_train_wgrad", lambda x, S, Z, G: (S.shape[0], G.shape[0]))
+    kt.wrap("dec_train_wgrad", lambda x, S, ws: (S.shape[0], ws.shape[0]))
     kt.wrap("knn_graph", lambda k, x, layout=None, optimistic=None: tuple(x.shape))
     kt.wrap("linear_wgrad_bias", lambda x, dy, want_bias=True: (x.shape[0], x.shape[1], dy.shape[1]))
     kt.wrap("linear_dgrad", lambda dy, w: (dy.shape[0], w.shape[0], w.shape[1]))
@@ -383,9 +383,9 @@ def train_rooflines(ops, ups, dev, ratio=16, reps=3):
     finally:
         kt.restore()
     names = {"dec_train_backward": "dec_train_bwd_kernel (DenseEdgeConv block backward: recompute, route to the arg-max edges, "
-                                   "three layers back, edge operands of the weight gradients)",
-             "dec_train_forward": "dec_train_fwd_kernel", "dec_train_wgrad": "linear_wgrad_all_kernel x2 + dec_wgrad_assemble_kernel "
-             "(the block's weight gradients from the edge tensors)", "knn_graph": "knn_graph kernels (feature graphs, exact form)",
+                                   "three layers back, the edge parts' weight gradients G^T Z accumulated on the matrix cores)",
+             "dec_train_forward": "dec_train_fwd_kernel", "dec_train_wgrad": "linear_wgrad_all_kernel (S^T [x | 1]) + "
+             "dec_wgrad_assemble_kernel (adds the backward workgroups' blocks)", "knn_graph": "knn_graph kernels (feature graphs, exact form)",
              "linear_wgrad_bias": "linear_wgrad_all_kernel (per-point layers: dW and db in one streaming pass)",
              "linear_dgrad": "linear_dgrad_small_kernel", "interlevel_skip_train": "skip_dist + skip_apply (weights kept)",
              "interlevel_skip_backward": "skip_bwd_kernel"}
@@ -401,14 +401,15 @@ def train_rooflines(ops, ups, dev, ratio=16, reps=3):
         shp = r.pop("_shapes")
         nm = r.pop("_name")
         if nm == "dec_train_backward":
-            # what the kernel must move: per edge 36 + 48 floats of weight-gradient operands written (G, Z), per point the
-            # 24-float row and gradient in, 24 + 36 floats out -- the edge tensors are 99 % of it (107 MB per block at B = 32)
-            byt = sum(p * n * (32 * 84 + 24 + 60 + 24 + 36) * 4.0 for p, n, _ in shp)
-            ach = byt / (r["ms_per_step"] * 1e-3) / 1e9
-            r.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                      "algorithmic_bytes_per_step": byt,
-                      "basis": "bytes the formulation writes and reads per launch (edge operands G, Z of the weight gradients: "
-                               "336 B per edge) / launch time (HIP events)"})
+            # executed matrix-core work per 64 edges: 288 v_mfma_f32_4x4x1 (512 FLOP: the recomputed forward chains and
+            # the three transposed products) + 80 v_mfma_f32_16x16x4_f32 (2048 FLOP: G^T Z); the kernel is bound by
+            # its dependent loads and the 32 x 24-lane float atomics of the neighbour shares, not by this
+            flop = sum(p * n * 32 / 64.0 * (288 * 512.0 + 80 * 2048.0) for p, n, _ in shp)
+            ach = flop / (r["ms_per_step"] * 1e-3) / 1e12
+            r.update({"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                      "frac": ach / FP32_PEAK_TF, "algorithmic_flop_per_step": flop,
+                      "basis": "executed fp32 matrix-core FLOP per launch / launch time (HIP events); latency-bound: a pass "
+                               "of 8 points is index -> row loads, ~370 matrix instructions, 32 atomics per lane group"})
         if dom is None:
             dom = dict(r)
     return {"config": "C3: B=32 patches x 312 pts, up_ratio=%d (%d levels), Chamfer fwd+bwd, clip, Adam; eager step with events "

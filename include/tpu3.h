@@ -414,31 +414,25 @@ int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr,
  * idx_off .. idx_off+31, w0 (12,48) / w1 (12,36) / w2 (12,48) = the convolution weights, b* (12).
  *   fwd: y (p,n,60) = [max_k h2 | max_k h1 | max_k h0 | x_i], arg (p,n,36) u8 = the neighbour slot attaining each max.
  *   bwd: gy (p,n,60) -> gx (p,n,24) ACCUMULATED with hardware float atomics (zeroed by the caller),
- *        G = [g2 | g1 | g0] (36 values) and Z = [h1 | h0 | x_j - x_i] (48 values) per edge, the operands of the
- *        weight gradients of the edge parts, for tpu3_dec_train_wgrad_f32 ONLY: each is stored as float4 PLANES --
- *        plane q (E = p*n*32 edges x 4 floats, dense) holds values 4 q .. 4 q + 3 of every edge, 9 planes of G and 12
- *        of Z, consecutive planes tpu3_dec_train_plane_stride(p*n) float4 entries apart (a lane of the kernel owns
- *        an edge, so a store instruction writes one contiguous KB of a plane; as (E, 36) / (E, 48) rows every
- *        instruction wrote 64 pieces of 64 different cache lines; the stride is E rounded up plus 17 so that the
- *        planes do not all start in the same memory channel): G holds 9 x stride x 4 floats, Z 12 x stride x 4 --;
- *        S (p*n, 36) = G summed over a point's edges, row-major (weight gradients of the x_i parts = S^T X, bias
- *        gradients = column sums of S). */
+ *        S (p*n, 36) = [g2 | g1 | g0] summed over a point's edges (weight gradients of the x_i parts = S^T X, bias
+ *        gradients = column sums of S), and into `workspace` one block G^T Z per workgroup of the launch -- the weight
+ *        gradients of the edge parts (G = [g2 | g1 | g0], Z = [h1 | h0 | x_j - x_i] per edge, accumulated on the matrix
+ *        cores inside the kernel; the edge tensors themselves never reach memory).  `workspace` =
+ *        tpu3_dec_train_wgrad_workspace_bytes(p*n) bytes, 16-byte aligned, handed on to tpu3_dec_train_wgrad_f32. */
 int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
                            int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, float *y, uint8_t *arg);
 int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
                            int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, const uint8_t *arg, const float *gy,
-                           float *gx, float *G, float *Z, float *S);
-/* Weight and bias gradients of the block from the tensors tpu3_dec_train_bwd_f32 leaves behind (what autograd
- * computes for the three nn.Conv2d of network/layers.py:53-61): gw0 (12,48), gw1 (12,36), gw2 (12,48) in the layers'
- * own column order, gb (36) = [b2 | b1 | b0].  points = p * n.  Deterministic; workspace =
- * tpu3_dec_train_wgrad_workspace_bytes(points). */
-int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S, const float *Z,
-                             const float *G, float *gw0, float *gw1, float *gw2, float *gb, void *workspace,
-                             size_t workspace_bytes);
+                           float *gx, float *S, void *workspace, size_t workspace_bytes);
+/* Weight and bias gradients of the block from what tpu3_dec_train_bwd_f32 leaves behind (what autograd computes for the
+ * three nn.Conv2d of network/layers.py:53-61): gw0 (12,48), gw1 (12,36), gw2 (12,48) in the layers' own column order,
+ * gb (36) = [b2 | b1 | b0].  points = p * n; `workspace` = the one the backward call filled.  Deterministic (the
+ * workgroups' blocks are added in a fixed order). */
+int tpu3_dec_train_wgrad_f32(tpu3_stream_t stream, long points, const float *x, const float *S, float *gw0, float *gw1,
+                             float *gw2, float *gb, void *workspace, size_t workspace_bytes);
 size_t tpu3_dec_train_wgrad_workspace_bytes(long points);
-long tpu3_dec_train_plane_stride(long points);
 
 /* The differentiable neighbour gather of group_knn (network/operations.py:209-211: torch.gather over the expanded
  * point tensor; its backward is an index accumulation) on channel-last rows, training:
