@@ -262,7 +262,7 @@ class DenseEdgeConv(nn.Module):
                     full, _, _ = operations.knn_query(k + 1, x.detach(), x.detach(), unique=True, layout=layout,
                                                       want_dist=False, want_grouped=False)
                 full = full.to(torch.int32)
-            idx32, off, idx = full.contiguous(), 1, full[:, :, 1:].long()
+            idx32, off, idx = full.contiguous(), 1, full[:, :, 1:]      # (a view, like the inference path's)
         else:
             idx32, off = idx.to(torch.int32).contiguous(), 0
         m = self.mlps
