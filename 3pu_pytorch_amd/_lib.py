@@ -51,7 +51,7 @@ SIGNATURES = {
     "tpu3_linear_small_st_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "tpu3_dec_train_fwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_dec_train_bwd_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _vp, _sz]),
+                                    _i, _vp, _vp, _vp, _sz]),
     "tpu3_gather_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_scatter_add_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_linear_wide_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i]),

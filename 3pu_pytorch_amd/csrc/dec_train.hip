@@ -42,10 +42,11 @@ struct DtArgs {
     const float *w0, *b0, *w1, *b1, *w2, *b2;      // (12,48), (12,36), (12,48) row-major + biases
     float *y;                       // fwd: (P,N,60)
     uint8_t *arg;                   // (P,N,36)
-    const float *gy;                // bwd: (P,N,60)
+    const float *gy;                // bwd: (P,N,60) rows, `gys` floats apart
     float *gx;                      // (P,N,24), accumulated
     float *S;                       // (P*N, 36)
     float *wpart;                   // (gridDim.x, 64, 64): the workgroups' G^T Z blocks (rows 0 .. 35, columns 0 .. 47 used)
+    int gys = 60;
 };
 
 // LDS image of the weights:
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         long jrow;
         // the point's incoming gradient and arg-max record: requested together with the rows (behind other memory
         // operations their loads waited for everything before them: 45 % of the kernel once), handed over through LDS
-        const float gy_a = a.gy[pt * 60 + hl], gy_b = hl < 28 ? a.gy[pt * 60 + 32 + hl] : 0.f;
+        const float gy_a = a.gy[pt * a.gys + hl], gy_b = hl < 28 ? a.gy[pt * a.gys + 32 + hl] : 0.f;
         const int ar_a = a.arg[pt * 36 + hl], ar_b = hl < 4 ? a.arg[pt * 36 + 32 + hl] : 0;
         dt_load_edge(a, pt, hl, xi, dj, jrow);
         s.sgy[half][hl] = gy_a;
@@ -597,9 +598,11 @@ int tpu3_dec_train_bwd_blocks(long points)
 extern "C" int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
                                       int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                                       const float *b1, const float *w2, const float *b2, const uint8_t *arg,
-                                      const float *gy, float *gx, float *S, void *workspace, size_t workspace_bytes)
+                                      const float *gy, int gy_stride, float *gx, float *S, void *workspace,
+                                      size_t workspace_bytes)
 {
     const int r = dt_check(p, n, k, idx_stride, idx_off);
+    if (gy_stride < 60) return TPU3_EINVAL;
     if (r) return r;
     if (p == 0) return TPU3_OK;
     if (!x || !idx || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !arg || !gy || !gx || !S || !workspace) return TPU3_EINVAL;
@@ -607,7 +610,7 @@ extern "C" int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k
     const unsigned grid = dt_grid(p * n, 2);
     if (workspace_bytes < (size_t)grid * 4096 * sizeof(float)) return TPU3_EINVAL;
     DtArgs a{p * n, n, idx_stride, idx_off, x, idx, w0, b0, w1, b1, w2, b2, nullptr, const_cast<uint8_t *>(arg), gy, gx,
-             S, (float *)workspace};
+             S, (float *)workspace, gy_stride};
     hipLaunchKernelGGL(dec_train_bwd_kernel, dim3(grid), dim3(DT_THREADS), 0, (hipStream_t)stream, a);
     return tpu3_launch_status();
 }

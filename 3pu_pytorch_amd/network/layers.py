@@ -160,7 +160,7 @@ class _FusedDECTrain(torch.autograd.Function):
         x, idx, arg = ctx.saved_tensors[:3]
         weights = ctx.saved_tensors[3:]
         be = operations.BACKEND
-        gx, S, ws = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy.contiguous())
+        gx, S, ws = be.dec_train_backward(x, idx, ctx.idx_off, weights, arg, gy)
         gw0, gw1, gw2, gb = be.dec_train_wgrad(x.view(-1, x.size(-1)), S, ws)
         return (gx, None, None, gw0.view(ctx.shapes[0]), gb[24:36], gw1.view(ctx.shapes[1]), gb[12:24],
                 gw2.view(ctx.shapes[2]), gb[0:12])

@@ -460,14 +460,17 @@ class HipBackend(object):
         P, N, _ = x.shape
         dev = x.device
         lib = L.lib()
+        # gy may be a channel slice of the concatenated features' gradient: rows gy.stride(1) floats apart, no copy
+        if not (gy.stride(2) == 1 and gy.stride(0) == N * gy.stride(1) and gy.stride(1) >= 60):
+            gy = gy.contiguous()
         gx = torch.zeros((P, N, 24), dtype=torch.float32, device=dev)
         S = torch.empty((P * N, 36), dtype=torch.float32, device=dev)
         need = lib.tpu3_dec_train_wgrad_workspace_bytes(P * N)
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             L.check(lib.tpu3_dec_train_bwd_f32(L.stream_of(x), P, N, 32, L.ptr(x), L.ptr(idx), idx.size(2), idx_off,
-                                               *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), L.ptr(gx),
-                                               L.ptr(S), L.ptr(ws), need), "tpu3_dec_train_bwd_f32")
+                                               *[L.ptr(w) for w in weights], L.ptr(arg), L.ptr(gy), gy.stride(1),
+                                               L.ptr(gx), L.ptr(S), L.ptr(ws), need), "tpu3_dec_train_bwd_f32")
         return gx, S, ws
 
     def dec_train_wgrad(self, x, S, ws):

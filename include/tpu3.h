@@ -413,7 +413,7 @@ int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr,
  * autograd formulation).  x (p,n,24), idx (p,n,idx_stride) i32 with the 32 neighbours of a point at
  * idx_off .. idx_off+31, w0 (12,48) / w1 (12,36) / w2 (12,48) = the convolution weights, b* (12).
  *   fwd: y (p,n,60) = [max_k h2 | max_k h1 | max_k h0 | x_i], arg (p,n,36) u8 = the neighbour slot attaining each max.
- *   bwd: gy (p,n,60) -> gx (p,n,24) ACCUMULATED with hardware float atomics (zeroed by the caller),
+ *   bwd: gy (p,n,60) with rows gy_stride >= 60 floats apart (a channel slice of a wider gradient) -> gx (p,n,24) ACCUMULATED with hardware float atomics (zeroed by the caller),
  *        S (p*n, 36) = [g2 | g1 | g0] summed over a point's edges (weight gradients of the x_i parts = S^T X, bias
  *        gradients = column sums of S), and into `workspace` one block G^T Z per workgroup of the launch -- the weight
  *        gradients of the edge parts (G = [g2 | g1 | g0], Z = [h1 | h0 | x_j - x_i] per edge, accumulated on the matrix
@@ -425,7 +425,7 @@ int tpu3_dec_train_fwd_f32(tpu3_stream_t stream, long p, int n, int k, const flo
 int tpu3_dec_train_bwd_f32(tpu3_stream_t stream, long p, int n, int k, const float *x, const int32_t *idx,
                            int idx_stride, int idx_off, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, const uint8_t *arg, const float *gy,
-                           float *gx, float *S, void *workspace, size_t workspace_bytes);
+                           int gy_stride, float *gx, float *S, void *workspace, size_t workspace_bytes);
 /* Weight and bias gradients of the block from what tpu3_dec_train_bwd_f32 leaves behind (what autograd computes for the
  * three nn.Conv2d of network/layers.py:53-61): gw0 (12,48), gw1 (12,36), gw2 (12,48) in the layers' own column order,
  * gb (36) = [b2 | b1 | b0].  points = p * n; `workspace` = the one the backward call filled.  Deterministic (the
