@@ -1835,7 +1835,10 @@ using FbOffsetIt = rocprim::transform_iterator<FbCount, FbSegOffset>;
 bool fb_plan(int b, int n, FbPlan &p)
 {
     p.rb_rows = 0;                  // rows per wave (16 waves)
-    if (n <= RB_MAX_N) {
+    // TPU3_FPS_FORCE_TILE=1: measurement hook (tools/fps_level_dispatch_probe.py) -- the per-level sets (4097 .. 25 600
+    // points) on the tile form / the cluster form instead of the register-resident kernels
+    static const bool force_tile = getenv("TPU3_FPS_FORCE_TILE") && atoi(getenv("TPU3_FPS_FORCE_TILE")) != 0;
+    if (n <= RB_MAX_N && !(force_tile && n > 4096)) {
         const int rows = ((n + 63) / 64 + 15) / 16;
         for (int r : {4, 7, 10, 13, 16, 20, 25})
             if (r >= rows) {

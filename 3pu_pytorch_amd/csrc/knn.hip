@@ -40,6 +40,7 @@ struct KnnArgs {
     float *dist;             // (b,m,k) or null
     const int32_t *cand;     // (bp,n) ascending indices of the first occurrences, or null
     const int32_t *cand_count;   // (bp)
+    int dbg;                 // measurement switches of knn_graph_slab_kernel (TPU3_KG_SLAB_DBG), 0 in production
 };
 
 __device__ __forceinline__ void store_idx(const KnnArgs &a, size_t off, int v)
@@ -822,6 +823,421 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < L; ++i)
             out[1 + i] = lst[i] & ~keep;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self kNN graph of one patch, SLAB form (r5): a wave's queries are neighbours, far chunks are skipped
+// ---------------------------------------------------------------------------------------------
+// knn_graph_key_kernel runs every chunk of 32 candidates through the sorting network for every wave, because in
+// patch order some lane of a wave always accepts something.  The top-k SET does not depend on the visiting order,
+// so here the workgroup first orders its patch along ONE direction v of feature space:
+//     v   = one power iteration of the centred second moment, started at (the row farthest from row 0) - row 0
+//           (tools/knn_accept_sim.py: as good as the first principal axis for this purpose);
+//     t_i = <x_i, v>, |v| < 1;   rows sorted by t (a binned counting sort: order inside a bin is arbitrary).
+// A wave then owns 64 consecutive rows of that order -- a SLAB of the patch -- and visits the 32-row chunks outwards
+// from its own, left and right alternately.  (t_q - t_c)^2 <= |x_q - x_c|^2 for every pair, so once every lane's
+// gap to the chunk's t-range, squared, exceeds the lane's current 32nd key (with a margin for the rounding of t
+// and of the expanded-form distance, see E1 / E2), the chunk AND every chunk beyond it on that side cannot change
+// any list: that side is closed without computing a single distance (~31 % of all chunks on the feature rows of a
+// 16x run).  A chunk that survives the bound still skips the sorting network when no lane's smallest new key
+// beats its 32nd (~10 %).  Keys carry the sorted POSITION in their low bits; truncation ties are only ever resolved
+// at the list's boundary, and there by (distance, ORIGINAL index) exactly like the oracle.  A skipped key has a
+// truncated distance strictly above the list's last one at that time (hence above the final one), so it can never
+// be the boundary collision `e` / `e2` watch for.
+// n <= 320 (one tile), one workgroup of ceil(n / 64) waves per patch.  Output as knn_graph_key_kernel.
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside each row of 16 (row_shr), then the rows'
+// totals handed on with row_bcast15 / row_bcast31
+__device__ __forceinline__ int kg_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+// Pre-pass of the slab form: the order of every patch along its direction v.  One workgroup per patch, a thread per
+// row; cheap in registers, so many waves per SIMD hide its seven barriers (fused into the graph kernel, whose 158
+// registers allow two workgroups per compute unit, the same work cost 13 % of that kernel's time).  Output, in the
+// head of the patch's own (n, K) index rows -- scratch until the graph kernel overwrites them with the result:
+// words [0, n) = t of the row at each sorted position, words [n, 2n) = that row's number.
+template <int C>
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(6, 6))) void knn_slab_order_kernel(KnnArgs a)
+{
+    constexpr int TILE = 320;
+    constexpr int NW = TILE / 64;
+    constexpr int RMAX = 26;                        // rows per (channel, row group) thread of the transposed sums
+    __shared__ __attribute__((aligned(16))) float tile[TILE * C];      // the patch's rows, original order
+    __shared__ float ts[TILE];                      // s_i = <x_i, v0>
+    __shared__ int hist[TILE];                      // bin counts, then exclusive offsets
+    __shared__ __attribute__((aligned(16))) float vec[2 * C];
+    __shared__ int wfar[NW];                        // per wave: arg-max key of |x_i - x_0|^2
+    if (a.uws && a.uws[0] != 0)
+        return;
+    const int b = blockIdx.y;
+    const int n = a.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x;                // ceil(n / 64) * 64
+    const int nwaves = nthreads >> 6;
+    const bool live = tid < n;
+    const float *X = a.query + (size_t)b * n * a.c;
+
+    // (registers: nothing but scalars lives across a barrier -- rows and directions are re-read from LDS -- so that
+    // four workgroups fit a compute unit: <= 96 VGPRs)
+    {
+        float x[C], rq;
+        load_query<C>(x, rq, X + (size_t)(live ? tid : 0) * a.c, a.c, live);
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i)             // (dead threads: zero rows, never summed)
+            ((float4 *)tile)[tid * (C / 4) + i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+        hist[tid] = 0;
+        if (tid < 2 * C)
+            vec[tid] = 0.f;
+        // the row farthest from row 0 (any of the farthest: the row number rides in the low bits)
+        float r0[C], d0 = 0.f, unused;
+        load_query<C>(r0, unused, X, a.c, true);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const float e = x[i] - r0[i];
+            d0 = __builtin_fmaf(e, e, d0);
+        }
+        // (a NaN / Inf row may win: the direction is then useless, never unsafe -- the graph kernel's bound uses
+        // the t values written here whatever they are)
+        const int key = live ? (int)((__float_as_uint(d0) & 0x7FFFFE00u) | (uint32_t)tid) : 0;
+        const int wmax = tpu3_wave_max_i32(key);
+        if (lane == 0)
+            wfar[wave] = wmax;
+    }
+    __syncthreads();
+    int far = wfar[0];
+    for (int w = 1; w < nwaves; ++w)
+        far = max(far, wfar[w]);
+    const int p = far & 0x1FF;
+    const float4 *own4 = (const float4 *)tile + tid * (C / 4);
+    const float4 *row0 = (const float4 *)tile, *rowp = (const float4 *)tile + p * (C / 4);
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 xo = own4[i], a0 = row0[i], ap = rowp[i];
+            s = __builtin_fmaf(xo.x, ap.x - a0.x, s), s = __builtin_fmaf(xo.y, ap.y - a0.y, s);
+            s = __builtin_fmaf(xo.z, ap.z - a0.z, s), s = __builtin_fmaf(xo.w, ap.w - a0.w, s);
+        }
+        ts[tid] = live ? s : 0.f;                   // s_i = <x_i, v0>, v0 = x_p - x_0
+    }
+    __syncthreads();
+    // [A | S] = [sum_i s_i x_i | sum_i x_i]: thread (channel k, row group g) adds its rows (half of its loads in
+    // flight at a time), one LDS float atomic per thread and sum adds the groups (their order does not matter: v is a
+    // heuristic)
+    {
+        const int G = nthreads / C;
+        const int k = tid % C, g = tid / C;
+        if (g < G) {
+            const int R = (n + G - 1) / G;
+            const int r0 = g * R, r1 = min(n, r0 + R);
+            float accA = 0.f, accS = 0.f;
+#pragma unroll
+            for (int h0 = 0; h0 < RMAX; h0 += RMAX / 2) {
+                float xv[RMAX / 2], sv[RMAX / 2];
+#pragma unroll
+                for (int u = 0; u < RMAX / 2; ++u) {
+                    const bool in = r0 + h0 + u < r1;
+                    const int r = in ? r0 + h0 + u : r0;
+                    xv[u] = tile[r * C + k];
+                    sv[u] = ts[r];
+                    xv[u] = in ? xv[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < RMAX / 2; ++u) {
+                    accA = __builtin_fmaf(sv[u], xv[u], accA);
+                    accS += xv[u];
+                }
+            }
+            atomicAdd(&vec[k], accA);
+            atomicAdd(&vec[C + k], accS);
+        }
+    }
+    __syncthreads();
+    float t;
+    int bin, slot = 0;
+    {
+        // v' = A - (<S, v0> / n) S  (= the centred second moment times v0), scaled to |v| < 1
+        float sv = 0.f, n0sq = 0.f;
+        float v[C];
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 a0 = row0[i], ap = rowp[i], S4 = ((const float4 *)vec)[C / 4 + i];
+            v[4 * i] = ap.x - a0.x, v[4 * i + 1] = ap.y - a0.y, v[4 * i + 2] = ap.z - a0.z, v[4 * i + 3] = ap.w - a0.w;
+            sv = __builtin_fmaf(S4.x, v[4 * i], sv), sv = __builtin_fmaf(S4.y, v[4 * i + 1], sv);
+            sv = __builtin_fmaf(S4.z, v[4 * i + 2], sv), sv = __builtin_fmaf(S4.w, v[4 * i + 3], sv);
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            n0sq = __builtin_fmaf(v[i], v[i], n0sq);
+        sv = sv / (float)n;
+        float nrm2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            v[i] = __builtin_fmaf(-sv, vec[C + i], vec[i]);
+            nrm2 = __builtin_fmaf(v[i], v[i], nrm2);
+        }
+        // (1 - 2^-10): the rounding of nrm2 and of the reciprocal square root stays far inside
+        const bool ok = nrm2 > 0.f && nrm2 < __builtin_inff();
+        const float inv = ok ? __builtin_amdgcn_rsqf(nrm2) * 0.9990234375f : 0.f;
+        float mean = 0.f;
+        t = 0.f;
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 xo = own4[i];
+            const float xs[4] = {xo.x, xo.y, xo.z, xo.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float vi = ok ? v[4 * i + j] * inv : 0.f;
+                t = __builtin_fmaf(xs[j], vi, t);
+                mean = __builtin_fmaf(vec[C + 4 * i + j], vi, mean);
+            }
+        }
+        mean = mean / (float)n;
+        // binned counting sort by t: position = (rows in lower bins) + (arrival order inside the bin).
+        // nthreads bins over mean +- 2.5 sigma with sigma^2 ~ |C v0| / (|v0| n), the iteration's own estimate of the
+        // variance along v (no min / max reduction); rows beyond land in the end bins.  The bins only make the
+        // order GOOD; the graph kernel's bound uses each chunk's true t-range.
+        const float sig = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(nrm2) * __builtin_amdgcn_rsqf(n0sq) / (float)n);
+        const float half = 0.5f * (float)nthreads;
+        float f = __builtin_fmaf((t - mean) * (0.4f * half), __builtin_amdgcn_rcpf(sig), half);
+        f = __builtin_fminf(__builtin_fmaxf(f, 0.f), (float)(nthreads - 1));   // (NaN -> bin 0 through the max)
+        bin = (int)f;
+        if (live)
+            slot = atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // exclusive offsets of the bins, by one wave: five consecutive bins per lane
+        int h[NW], sum = 0;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            h[u] = lane * NW + u < nthreads ? hist[lane * NW + u] : 0;
+            sum += h[u];
+        }
+        int off = kg_wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if (lane * NW + u < nthreads)
+                hist[lane * NW + u] = off;
+            off += h[u];
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int pos = (a.dbg & 4) ? tid : hist[bin] + slot;
+        int32_t *scr = (int32_t *)a.idx + (size_t)b * n * a.k;
+        scr[pos] = __float_as_int(t);
+        scr[n + pos] = tid;
+    }
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) void knn_graph_slab_kernel(KnnArgs a)
+{
+    constexpr int TILE = 320;
+    constexpr int F4 = Row<C>::F4;
+    constexpr int L = K - 1;
+    constexpr int NCH = TILE / L;
+    constexpr int NW = TILE / 64;
+    static_assert(C % 4 == 0 && L == 32 && TILE % L == 0, "slab form: 4 | C, k = 33");
+    __shared__ float4 tile[TILE * F4];              // the patch's rows in SORTED order
+    __shared__ __attribute__((aligned(16))) float rps[TILE];
+    __shared__ int orig[TILE];                      // original row of a sorted position
+    __shared__ float crange[2 * NCH];               // t-range of each chunk: [c] = min, [NCH + c] = max
+    __shared__ uint32_t wrq[NW];                    // per wave: mono(max |x_i|^2)
+    if (a.uws && a.uws[0] != 0)
+        return;
+    const int b = blockIdx.y;
+    const int n = a.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;             // blockDim.x = ceil(n / 64) * 64
+    const bool live = tid < n;
+    const float *X = a.query + (size_t)b * n * a.c;
+    const int IB = 32 - __clz(n - 1);
+    const int keep = ~((1 << IB) - 1);
+
+    // ---- the lane's query = the row at sorted position tid (knn_slab_order_kernel), staged at that position ----
+    const int qi = tid;
+    const int32_t *scr = (const int32_t *)a.idx + (size_t)b * n * K;
+    const float tq = live ? __int_as_float(scr[tid]) : 0.f;
+    const int my_row = live ? min(max(scr[n + tid], 0), n - 1) : 0;
+    float q[C], rq;
+    load_query<C>(q, rq, X + (size_t)my_row * a.c, a.c, live);
+    {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i)
+            tile[tid * F4 + i] = make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);   // (dead: zeros)
+        const float r = live ? rq : __builtin_inff();       // pad rows n .. blockDim-1: never among the nearest
+        tile[tid * F4 + C / 4] = make_float4(r, 0.f, 0.f, 0.f);
+        rps[tid] = r;
+        orig[tid] = my_row;
+        // t-range of every chunk; max |x|^2 of the patch
+        const uint32_t mt = tpu3_mono(tq);
+        uint32_t lo = tpu3_row_min_u32(live ? mt : 0xFFFFFFFFu), hi = tpu3_row_max_u32(live ? mt : 0u);
+        lo = min(lo, (uint32_t)tpu3_dpp<0x142, 0xA>((int)lo));     // rows 1, 3 += rows 0, 2: lanes 31 / 63 hold a chunk
+        hi = max(hi, (uint32_t)tpu3_dpp<0x142, 0xA>((int)hi));
+        if ((lane & 31) == 31) {
+            crange[tid >> 5] = tpu3_unmono(lo);                    // (an all-pad chunk: NaN / -NaN, never closed by a bound)
+            crange[NCH + (tid >> 5)] = tpu3_unmono(hi);
+        }
+        const uint32_t wm = tpu3_wave_max_u32(live ? tpu3_mono(rq) : 0u);
+        if (lane == 0)
+            wrq[wave] = wm;
+    }
+    __syncthreads();
+    uint32_t mm = wrq[0];
+    for (int w = 1; w < nwaves; ++w)
+        mm = max(mm, wrq[w]);
+    const float M = tpu3_unmono(mm);                // max |x_i|^2 over the patch
+    // margins of the bound (DESIGN / docs): |t - <x, v>| <= 2^-19.4 sqrt(M) per row, the expanded-form distance is
+    // within 2^-17.3 M of the true one; E1, E2 are 10x / 5x those
+    const float E1 = 3.0517578125e-05f * __builtin_amdgcn_sqrtf(M), E2 = 3.0517578125e-05f * M;
+
+    int lst[L], e = 0x7FFFFFFF, e2 = 0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+        lst[i] = 0x7FFFFFFF;
+    const int nch = (n + L - 1) / L;
+    int lo_c = 2 * wave - 1, hi_c = 2 * wave + 2;
+    int side = 0;
+    for (int step = 0;; ++step) {
+        int c;
+        const bool own = step < 2;
+        bool try_skip = false;
+        if (own) {
+            c = 2 * wave + step;
+        } else {
+            const bool lopen = lo_c >= 0, hopen = hi_c < nch;
+            if (!lopen && !hopen)
+                break;
+            const bool left = lopen && (!hopen || side == 0);
+            side ^= 1;
+            c = left ? lo_c : hi_c;
+            // the bound: every row of chunk c (and beyond) is farther than the lane's 32nd key, for EVERY lane?
+            const float gap = __builtin_fmaxf(crange[c] - tq, tq - crange[NCH + c]) - E1;
+            const float tau = __int_as_float(lst[L - 1] | ~keep);      // top of the 32nd key's truncation bucket (NaN while the list is short)
+            const bool out = !live || (gap > 0.f && __builtin_fmaf(gap, gap, -E2) > tau);
+            const uint64_t outs = __builtin_amdgcn_ballot_w64(out);
+            if (!(a.dbg & 1) && outs == ~0ull) {
+                if (left) lo_c = -1; else hi_c = nch;
+                continue;
+            }
+            if (left) --lo_c; else ++hi_c;
+            // the key test below pays only where the bound already rules out a good share of the lanes (a quarter:
+            // 55 % of the visited chunks, 96 % of the chunks it would skip -- tools/knn_accept_sim.py)
+            try_skip = __builtin_popcountll(outs) >= 16;
+        }
+        const int j = c * L;
+        float d[L];
+#pragma unroll
+        for (int u = 0; u < L; u += 16)
+            kg_dist<C, 4>(tile, rps, j + u, q, rq, d + u);
+        int nw[L];
+#pragma unroll
+        for (int u = 0; u < L; ++u)
+            nw[u] = (__float_as_int(d[u]) & keep) | (j + u);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < L; ++u)
+                nw[u] = j + u == qi ? 0x7FFFFFFF : nw[u];
+        } else if (try_skip) {
+            // no lane's smallest new key reaches its list: the sorting network is skipped
+            int m0 = nw[0], m1 = nw[1], m2 = nw[2], m3 = nw[3];
+#pragma unroll
+            for (int u = 4; u < L; u += 4) {
+                m0 = min(m0, nw[u]), m1 = min(m1, nw[u + 1]);
+                m2 = min(m2, nw[u + 2]), m3 = min(m3, nw[u + 3]);
+            }
+            const int mn = min(min(m0, m1), min(m2, m3));
+            if (!(a.dbg & 2) && __builtin_amdgcn_ballot_w64(!live || mn > (lst[L - 1] | ~keep)) == ~0ull)
+                continue;
+        }
+        kg_fold_i32<L>(lst, e, e2, nw);
+    }
+    // ---- boundary collisions after truncation: as knn_graph_key_kernel, ties by the ORIGINAL index ------------
+    bool redo = live && (lst[0] >> IB) <= 0;
+    const int T = lst[L - 1] >> IB;
+    bool amb = live && !redo && (e >> IB) == T && e != 0x7FFFFFFF;
+    if (__builtin_amdgcn_ballot_w64(amb)) {
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            cnt += (lst[i] >> IB) == T ? 1 : 0;
+        const bool easy = amb && (e2 >> IB) != T && cnt <= 2;
+        if (easy) {
+            const int ja = lst[L - 1] & ~keep, jb = lst[L - 2] & ~keep, jc = e & ~keep;
+            const int oa = orig[ja], ob = orig[jb], oc = orig[jc];
+            __builtin_amdgcn_sched_barrier(0);
+            const int da = __float_as_int(row_dist<C>(tile + ja * F4, q, rq));
+            __builtin_amdgcn_sched_barrier(0);
+            const int dc = __float_as_int(row_dist<C>(tile + jc * F4, q, rq));
+            __builtin_amdgcn_sched_barrier(0);
+            auto less = [](int d0, int j0, int d1, int j1) { return d0 < d1 || (d0 == d1 && j0 < j1); };
+            if (cnt == 1) {
+                if (less(dc, oc, da, oa))
+                    lst[L - 1] = (dc & keep) | jc;
+            } else {
+                const int db = __float_as_int(row_dist<C>(tile + jb * F4, q, rq));
+                const bool a_worst = !less(da, oa, db, ob) && !less(da, oa, dc, oc);
+                const bool b_worst = !a_worst && !less(db, ob, dc, oc);
+                if (a_worst)
+                    lst[L - 1] = (dc & keep) | jc;
+                else if (b_worst)
+                    lst[L - 2] = (dc & keep) | jc;
+            }
+            amb = false;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(amb)) {
+        // second sweep, wave-uniform: among the rows with truncated distance T the two smallest (D, original index)
+        int b0 = 0x7FFFFFFF, b1 = 0x7FFFFFFF, p0 = 0, p1 = 0, o0 = 0x7FFFFFFF, o1 = 0x7FFFFFFF;
+        for (int j = 0; j < nch * L; j += 16) {
+            float d[16];
+            kg_dist<C, 4>(tile, rps, j, q, rq, d);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int pos = j + u;
+                const int bits = __float_as_int(d[u]);
+                if ((bits >> IB) == T && pos != qi) {
+                    const int o = orig[pos];
+                    if (bits < b0 || (bits == b0 && o < o0)) {
+                        b1 = b0; p1 = p0; o1 = o0; b0 = bits; p0 = pos; o0 = o;
+                    } else if (bits < b1 || (bits == b1 && o < o1)) {
+                        b1 = bits; p1 = pos; o1 = o;
+                    }
+                }
+            }
+        }
+        if (amb) {
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+                cnt += (lst[i] >> IB) == T ? 1 : 0;
+            if (cnt > 2) {
+                redo = true;
+            } else {
+                lst[L - 1] = ((cnt == 1 ? b0 : b1) & keep) | (cnt == 1 ? p0 : p1);
+                if (cnt == 2)
+                    lst[L - 2] = (b0 & keep) | p0;
+            }
+        }
+    }
+    if (redo)
+        a.uws[2] = 1u;
+    if (live) {
+        int32_t *out = (int32_t *)a.idx + ((size_t)b * n + my_row) * K;
+        out[0] = my_row;
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+            out[1 + i] = orig[lst[i] & ~keep];
     }
 }
 
@@ -1609,6 +2025,17 @@ int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a
 #define KG(CC, KK) hipLaunchKernelGGL((knn_graph_kernel<CC, KK>), g, dim3(threads), 0, s, a)
 #define KK1(CC, KK) hipLaunchKernelGGL((knn_graph_key_kernel<CC, KK>), g, dim3(threads), 0, s, a)
     const bool onepass = a.n > k && a.n <= 8192;
+    // (r5) one patch per workgroup, ordered along its principal direction, far chunks skipped: see knn_graph_slab_kernel
+    static const bool slab_on = !(getenv("TPU3_KG_SLAB") && atoi(getenv("TPU3_KG_SLAB")) == 0);
+    if (slab_on && onepass && k == 33 && c > 16 && c <= 24 && a.n > 64 && a.n <= 320 && (int)g.x * threads >= a.n
+        && threads == ((a.n + 63) / 64) * 64) {
+        static const int dbg = getenv("TPU3_KG_SLAB_DBG") ? atoi(getenv("TPU3_KG_SLAB_DBG")) : 0;
+        KnnArgs as = a;
+        as.dbg = dbg;
+        hipLaunchKernelGGL((knn_slab_order_kernel<24>), g, dim3(threads), 0, s, as);
+        hipLaunchKernelGGL((knn_graph_slab_kernel<24, 33>), g, dim3(threads), 0, s, as);
+        return tpu3_launch_status();
+    }
     if (k == 33) {
         if (c == 3) { if (onepass) KK1(3, 33); else KG(3, 33); }
         else if (c <= 8) { if (onepass) KK1(8, 33); else KG(8, 33); }
@@ -1669,7 +2096,10 @@ extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c
     d.mode = 0; d.gate = 0; d.dup = nullptr;
     r = launch_dmax(s, b, d, uws);
     if (r) return r;
-    a.mode = 0; a.gate = -1;
+    // (r5) the exact sorted kernel runs whenever the first pass raised uws[2] -- duplicated rows, but also a computed
+    // distance <= 0 to a DIFFERENT row (features far from the origin: the oracle's slot 0 is then not the query
+    // itself) or a truncation collision three slots deep -- not only when the hash pass found duplicates
+    a.mode = 0; a.gate = 2;
     return dispatch_insert(s, b, a);
 }
 

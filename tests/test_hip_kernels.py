@@ -616,6 +616,52 @@ def test_knn_graph_one_pass_settles_boundary_collisions(orc, dev):
     assert per[0] == 0 and per[3] == 0, per              # generic rows and the line never need the exact path
 
 
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 257, 312, 320])
+def test_knn_graph_slab_form_on_low_dimensional_rows(orc, dev, n):
+    """The slab form of the self graph (csrc/knn.hip, knn_graph_slab_kernel: k = 33, 24 channels, one tile) orders a
+    patch along one direction and CLOSES a side as soon as the projected gap proves that no row beyond can enter any
+    list.  The bound only bites on rows that really are low-dimensional, so: a surface patch pushed through a random
+    linear map (what layer0 produces), the same with a relu (what the prep layers produce), rows on a LINE (the
+    projected gap equals the true distance: the rounding margins E1 / E2 carry the whole proof), two far-apart
+    clusters, one huge outlier row, and coordinates around 1e3 (|x|^2 ~ 1e7: large cancellation in the expanded-form
+    distance).  Every result must be the oracle's set, for every patch size between one and five waves."""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(n)
+    c, k = 24, 33
+    u = rng.random((8, n, 2)).astype(np.float32)
+    surf = np.concatenate([u, (0.3 * np.sin(3 * u[..., :1]) * np.cos(2 * u[..., 1:]))], axis=-1)      # (8,n,3)
+    W = rng.standard_normal((3, c)).astype(np.float32)
+    x = np.empty((8, n, c), np.float32)
+    x[0] = surf[0] @ W
+    x[1] = np.maximum(surf[1] @ W + np.float32(0.2), 0)
+    x[2] = np.maximum((surf[2] @ W) @ rng.standard_normal((c, c)).astype(np.float32) * np.float32(0.3), 0)
+    line = rng.permutation(n).astype(np.float32)[:, None] * np.float32(0.37)
+    x[3] = line * (W[0] / np.linalg.norm(W[0]))[None, :]
+    x[4] = surf[4] @ W
+    x[4, n // 2:] += np.float32(50.0)                                     # two clusters
+    x[5] = surf[5] @ W
+    x[5, 7] = np.float32(1e4)                                             # an outlier row
+    x[6] = surf[6] @ W + np.float32(1e3)                                  # far from the origin
+    x[7] = rng.standard_normal((n, c)).astype(np.float32)                 # nothing to skip
+    x = np.ascontiguousarray(x)
+    ri, _ = orc.knn(k, x, x, True)
+    ops.BACKEND.graph_dup_events(reset=True)
+    for i in range(x.shape[0]):
+        opt = ops.BACKEND.knn_graph(k, _t(x[i:i + 1], dev), optimistic=True).cpu().numpy()
+        ev = ops.BACKEND.graph_dup_events(reset=True)
+        if i in (0, 1, 2, 7):
+            assert ev == 0, (i, ev)
+        elif ev:
+            # exact ties on the line, truncated distances of 0 at coordinates of 50 .. 1e4: the kernel may
+            # legitimately ask for the exact path (like the one-pass kernel it replaces)
+            opt = ops.BACKEND.knn_graph(k, _t(x[i:i + 1], dev), optimistic=False).cpu().numpy()
+        np.testing.assert_array_equal(opt[:, :, 0], ri[i:i + 1, :, 0], err_msg="rows %d" % i)
+        np.testing.assert_array_equal(np.sort(opt[:, :, 1:], -1), np.sort(ri[i:i + 1, :, 1:], -1), err_msg="rows %d" % i)
+    # all eight at once (one workgroup per patch)
+    both = ops.BACKEND.knn_graph(k, _t(x, dev), optimistic=False).cpu().numpy()
+    np.testing.assert_array_equal(np.sort(both[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
+
+
 def test_knn_select_ragged_sets_and_exact_ties(orc, dev):
     """The patch extraction's shape (k = 312) with ragged point sets (upsampler.py:59-86 after the outlier
     filter), exact distance ties (lattice points: ties go to the lowest index) and a set with fewer live points
