@@ -80,6 +80,7 @@ SIGNATURES = {
     "tpu3_debug_dec_split": (_i, [_i]),
     "tpu3_debug_fps_plan": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int)]),
     "tpu3_fps_cluster_faults": (ctypes.c_long, [_i]),
+    "tpu3_debug_fps_cluster_absent": (_i, [_i]),
     "tpu3_dense_edge_conv_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _i]),
     "tpu3_dense_edge_conv_st_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

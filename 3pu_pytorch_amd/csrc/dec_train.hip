@@ -56,13 +56,17 @@ struct DtArgs {
 //   xw  [36][25]  rows 0-11 W_2x, 12-23 W_1x, 24-35 W_0a (x_i parts, padded rows: a lane per row reads conflict-free)
 //   xb  [36]      b_2, b_1, b_0
 //   stage [8][36] per half wave: the per-point terms (forward) / the summed gradients S (backward)
-struct DtLds {
+struct DtWeights {
     float eh[12 * 24];
     float h1w[12 * 12];
     float h2w[12 * 24];
     float xw[36 * 25];
     float xb[36];
     float stage[DT_THREADS / 32][40];
+};
+// (advisor, r4) the forward kernel declares only the image above (~7 KB); the backward kernel adds its transposition
+// regions -- about 75 KB, two workgroups per compute unit of gfx950's 160 KB (it runs one wave per SIMD pair anyway)
+struct DtLds : DtWeights {
     // backward: per wave, its 64 edges' rows [g (12, one of g_2 / g_1 / g_0 at a time) | h_1 | h_0 | d_j] with an odd
     // stride -- written a lane per edge, read back a lane per CHANNEL as the operands of the weight-gradient matrix
     // instructions (dt_wgrad_round); afterwards the same floats hold the 2 x 32 neighbour shares [edge][25] of the scatter
@@ -71,8 +75,9 @@ struct DtLds {
     float sgy[DT_THREADS / 32][64];         //           the point's incoming gradient row (60) ...
     int sarg[DT_THREADS / 32][40];          //           ... and its 36 arg-max slots, requested with the pass's first loads
 };
+static_assert(sizeof(DtLds) <= 80 * 1024, "dec_train_bwd_kernel: two workgroups per compute unit");
 
-__device__ __forceinline__ void dt_load_weights(const DtArgs &a, DtLds &s)
+__device__ __forceinline__ void dt_load_weights(const DtArgs &a, DtWeights &s)
 {
     // every global load is requested before the first LDS store (r4): as ten load -> store iterations the image cost
     // ten dependent round trips at the head of every workgroup
@@ -139,7 +144,7 @@ __device__ __forceinline__ float dt_half_sum(float v)
 
 // Per-point terms of point `pt` by its half wave: lane c < 32 computes term c, lanes 0-3 also terms 32-35; every
 // lane then reads all 36 from `st`.  (pt may be a clamped duplicate for idle halves.)
-__device__ __forceinline__ void dt_point_terms(const DtLds &s, float *st, const float *xi, int hl)
+__device__ __forceinline__ void dt_point_terms(const DtWeights &s, float *st, const float *xi, int hl)
 {
     float t0 = s.xb[hl], t1 = s.xb[32 + (hl & 3)];
 #pragma unroll
@@ -273,7 +278,7 @@ __device__ __forceinline__ void dt_load_edge(const DtArgs &a, long pt, int hl, f
 
 __global__ __launch_bounds__(DT_THREADS) void dec_train_fwd_kernel(DtArgs a)
 {
-    __shared__ DtLds s;
+    __shared__ DtWeights s;
     DtFwdOps ops;
     dt_load_fwd_ops(a, ops, true);
     dt_load_weights(a, s);

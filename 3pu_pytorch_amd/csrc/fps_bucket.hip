@@ -1925,7 +1925,17 @@ bool fb_plan(int b, int n, FbPlan &p)
                 gg /= 2;                        // fewer than four tiles per member: not worth an exchange per round
         if (gg > 1 && gg < gmin && (long)b * gmin <= 64)
             gg = gmin;
-        if (gg >= 2 && gg >= gmin && gg <= 64 && (gg & (gg - 1)) == 0 &&
+        // residency (advisor, r4): all b * G workgroups of a cluster launch take a whole compute unit each and spin on
+        // each other -- forced values obey the bound too, and a device (partition, CU mask) with fewer than 64 units
+        // lowers it; whatever does not fit runs on the single-workgroup kernel
+        static const int ncu = []() {
+            int d = 0, v = 256;
+            (void)hipGetDevice(&d);
+            (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d);
+            return v;
+        }();
+        const long resident = ncu < 64 ? ncu : 64;
+        if (gg >= 2 && gg >= gmin && gg <= 64 && (gg & (gg - 1)) == 0 && (long)b * gg <= resident &&
             tpu3_fps_cluster_lds_bytes(p.ntile, gg) <= 160 * 1024)
             p.cluster = gg;
     }

@@ -72,6 +72,9 @@ __device__ __forceinline__ u64 fc_get(const u64 *p)
 
 // faulted workgroups since the last reset (tpu3_fps_cluster_faults)
 __device__ u64 fc_fault_count;
+// fault injection (tpu3_debug_fps_cluster_absent, tests only): non-zero = member 1 of every cluster leaves at once, as
+// if it had never become resident, and the others give up after 4096 polls instead of 2^23
+__device__ unsigned fc_debug_absent;
 
 struct FcShared {
     float pick[2][FC_CAP][4];           // the round's samples in rank order: x, y, z, distance
@@ -140,6 +143,16 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
     u64 *mb = mbox0 + (size_t)cl * fc_mbox_words(G);        // this cluster's mailboxes: [parity][member][FC_MB]
     u64 *tb = mb + (size_t)2 * G * FC_MB;                   // tie exchange: [parity][member][2]
     u64 *faultw = tb + (size_t)2 * G * 2;
+    const unsigned absent = fc_debug_absent;
+    const unsigned spin_max = absent ? 4096u : FC_SPIN_MAX;
+    if (absent && g == 1)
+        return;
+    // a member gives up when its own polls run out, when another wave of its workgroup did, or when ANOTHER member
+    // of the cluster has published its fault (looked at every 1024 polls): the cluster leaves together
+    auto gave_up = [&](unsigned spins) __attribute__((always_inline)) {
+        return spins > spin_max || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
+               ((spins & 1023u) == 0 && fc_get(faultw) != 0);
+    };
 
     // local bucket index <-> global bucket id (tile t = lt * G + g)
     auto gbucket = [&](int lbk) __attribute__((always_inline)) { return ((((lbk >> 6) << lg) | g) << 6) | (lbk & 63); };
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     miss |= q * 64 + lane < need && (unsigned)(x[q] >> 32) != epoch;
                 if (hdr && !__ballot(miss))
                     break;
-                if (++spins > FC_SPIN_MAX || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if (gave_up(++spins)) {
                     if (lane == 0)
                         sh.fail = 1;
                     cnt = 0;
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     x = fc_get(src + (lane & 1));
                     if ((__ballot((unsigned)(x >> 32) == te) & 3ull) == 3ull)
                         break;
-                    if (++spins > FC_SPIN_MAX || __hip_atomic_load(&sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    if (gave_up(++spins)) {
                         if (lane == 0)
                             sh.fail = 1;
                         break;
@@ -859,7 +872,11 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
             return;
         }
     }
-    // a poll gave up (a member of this cluster never became resident, or died): tell the host
+    // a poll gave up (a member of this cluster never became resident, or died): tell the host and the partners;
+    // member 0 fills the samples not taken with index 0, so that whatever gathers through idx stays in range
+    if (g == 0)
+        for (int i = r + tid; i < a.m; i += 1024)
+            a.idx[i] = 0;
     if (tid == 0) {
         __hip_atomic_store(faultw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&fc_fault_count, 1ull);
@@ -943,6 +960,14 @@ int tpu3_fps_cluster_launch(hipStream_t s, int b, int g, const void *fb_args, vo
     e = hipEventRecord(ring[dev][slot], s);
     ++issued[dev];
     return e == hipSuccess ? TPU3_OK : (int)e;
+}
+
+// Test hook (not part of the path): on != 0 makes member 1 of every cluster of the following launches leave at once
+// (a workgroup that never became resident) and shortens the partners' patience to 4096 polls.  Returns 0 on success.
+extern "C" int tpu3_debug_fps_cluster_absent(int on)
+{
+    const unsigned v = on ? 1u : 0u;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fc_debug_absent), &v, sizeof(v)) == hipSuccess ? TPU3_OK : TPU3_EINVAL;
 }
 
 extern "C" long tpu3_fps_cluster_faults(int reset)

@@ -262,7 +262,9 @@ class DenseEdgeConv(nn.Module):
                     full, _, _ = operations.knn_query(k + 1, x.detach(), x.detach(), unique=True, layout=layout,
                                                       want_dist=False, want_grouped=False)
                 full = full.to(torch.int32)
-            idx32, off, idx = full.contiguous(), 1, full[:, :, 1:]      # (a view, like the inference path's)
+            # the kernels read the int32 buffer; the idx handed back is int64 like the sibling training paths' (and the
+            # reference's), so that it can be fed back through `idx=` / torch.gather (advisor, r4)
+            idx32, off, idx = full.contiguous(), 1, full[:, :, 1:].long()
         else:
             idx32, off = idx.to(torch.int32).contiguous(), 0
         m = self.mlps

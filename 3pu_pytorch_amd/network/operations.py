@@ -90,6 +90,12 @@ class HipBackend(object):
         the last reset is incomplete."""
         return int(L.lib().tpu3_fps_cluster_faults(1 if reset else 0))
 
+    def fps_cluster(self, g):
+        """Workgroups per point set of the tile-form FPS for the calls that follow (-1: the default policy, 0: the
+        single-workgroup kernels only); returns the previous setting.  pipeline.upsample recomputes with 0 after a
+        cluster launch reported a fault."""
+        return int(L.lib().tpu3_debug_fps_cluster(int(g)))
+
     def knn(self, k, query, points, unique, layout=None, want_dist=True, want_grouped=True, unique_cache=None):
         """query (B,M,C), points (Bp,N,C) f32 contiguous device tensors ->
         idx int64 (B,M,k), dist f32 (B,M,k) | None, grouped f32 (B,M,k,C) | None.

@@ -167,11 +167,23 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
                 del timing[n_timing:]                   # the first pass's events are not this call's result
             out = run(False)
     if check_small and hasattr(be, "fps_cluster_faults"):
-        # (rank-local: a faulted launch leaves THIS rank's result incomplete; no collective depends on it)
-        faults = be.fps_cluster_faults(reset=True)
-        if faults:
-            raise RuntimeError("%d workgroups of a multi-workgroup FPS launch gave up waiting for their partners (too "
-                               "many cluster launches in flight at once?): the sampled cloud is incomplete" % faults)
+        # A multi-workgroup FPS launch whose members never all became resident gives up (bounded polls), counts a
+        # fault and leaves its samples incomplete (filled with index 0).  Like the optimistic graph above, the call is
+        # then recomputed -- on the single-workgroup kernels, which need no residency.  The decision is taken on EVERY
+        # rank together (one MAX all-reduce): a rank that recomputed alone would issue collectives the others do not.
+        hit = be.fps_cluster_faults(reset=True) > 0
+        if _any_rank(hit, clouds.device) if sharded else hit:
+            if timing is not None:
+                del timing[n_timing:]
+            saved = be.fps_cluster(0)
+            try:
+                out = run(False)
+            finally:
+                be.fps_cluster(saved)
+            again = be.fps_cluster_faults(reset=True)
+            if again:           # (cannot happen: no cluster launch was issued)
+                raise RuntimeError("%d workgroups of an FPS launch gave up although the single-workgroup kernels "
+                                   "were forced" % again)
     if check_small and hasattr(net, "small_cloud_events"):
         bad = net.small_cloud_events
         if _any_rank(bad, clouds.device) if sharded else bad:

@@ -491,6 +491,11 @@ int tpu3_debug_dec_split(int on);
  * workgroups since the last reset on the current device (synchronises the device: call at a synchronisation point,
  * as pipeline.upsample and bench.py do).  0 in every correct run. */
 long tpu3_fps_cluster_faults(int reset);
+/* Test hook: on != 0 makes member 1 of every cluster of the FOLLOWING multi-workgroup FPS launches leave at once (a
+ * workgroup that never became resident) and shortens its partners' patience to 4096 polls, so that the fault path
+ * (fault counted, members leave together, samples not taken filled with index 0, caller recomputes on the
+ * single-workgroup kernel) can be exercised; 0 restores the product behaviour. */
+int tpu3_debug_fps_cluster_absent(int on);
 
 #ifdef __cplusplus
 }

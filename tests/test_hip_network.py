@@ -543,6 +543,60 @@ def test_pipeline_on_device_against_reference_driver(orc, dev):
     assert _set_close(orc, final, g["final"]) >= 0.99
 
 
+def test_dense_edge_conv_training_idx_can_be_fed_back(dev):
+    """DenseEdgeConv under autograd on the device (the fused training kernels, csrc/dec_train.hip) returns its
+    neighbour indices as int64 like the reference (network/layers.py:6-42: torch.topk indices) and like the sibling
+    training paths; handing them back through `idx=` must reproduce the block's output (advisor, round 4)."""
+    layers = pkg("network.layers")
+    torch.manual_seed(3)
+    blk = layers.DenseEdgeConv(24, growth_rate=12, n=3, k=32).to(dev).train()
+    x = torch.randn(4, 312, 24, device=dev, requires_grad=True)
+    y, idx = blk.forward_cl(x)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (4, 312, 32)
+    y2, idx2 = blk.forward_cl(x, idx=idx)
+    assert torch.equal(y, y2) and torch.equal(idx, idx2)
+    blk.fused_train = False                               # the hoisted autograd formulation takes int64 too
+    try:
+        y3, _ = blk.forward_cl(x, idx=idx)
+    finally:
+        del blk.fused_train
+    torch.testing.assert_close(y3, y, rtol=1e-4, atol=1e-5)
+    gathered = torch.gather(x.detach(), 1, idx[:, :, :1].expand(-1, -1, 24))     # torch.gather needs int64
+    assert gathered.shape == x.shape
+
+
+def test_pipeline_recomputes_when_a_cluster_fps_launch_faults(dev):
+    """The final FPS of one cloud runs on 16 workgroups that spin on each other (csrc/fps_cluster.hip).  With a member
+    made absent (tpu3_debug_fps_cluster_absent: it leaves at once, as if it had never become resident) the others give
+    up together after a bounded number of polls, the fault is counted and the samples not taken are index 0 (in
+    range).  pipeline.upsample must notice at its synchronisation point and recompute on the single-workgroup
+    kernels: the result equals a run that never used the cluster form."""
+    pipe, ops, lib = pkg("pipeline"), pkg("network.operations"), pkg("_lib").lib()
+    net = _net(dev)
+    x = torch.from_numpy(np.ascontiguousarray(sphere(5, 5000).transpose(0, 2, 1))).to(dev)
+    be = ops.BACKEND
+    saved = be.fps_cluster(0)
+    try:
+        ref = pipe.upsample(net, x, 312, 16, 3)
+    finally:
+        be.fps_cluster(saved)
+    assert be.fps_cluster_faults(reset=True) == 0
+    # the kernel level first: a faulted launch counts, and leaves nothing out of range behind
+    pts = torch.from_numpy(sphere(9, 30000)).to(dev)
+    assert lib.tpu3_debug_fps_cluster_absent(1) == 0
+    try:
+        idx = be.fps(pts, 3000)
+        torch.cuda.synchronize()
+        assert be.fps_cluster_faults(reset=True) > 0
+        assert int(idx.min()) >= 0 and int(idx.max()) < 30000
+        out = pipe.upsample(net, x, 312, 16, 3)          # faults inside, recomputed without the cluster form
+    finally:
+        assert lib.tpu3_debug_fps_cluster_absent(0) == 0
+    assert be.fps_cluster_faults(reset=True) == 0            # the recomputation consumed and cleared the count
+    assert torch.equal(out, ref)
+    assert be.fps_cluster(-1) == -1                          # the default policy is back
+
+
 def test_pipeline_recomputes_when_an_optimistic_graph_reports_duplicates(orc, dev):
     """The inference path launches the feature-space kNN graphs optimistically (no gated fallback launches).
     A cloud with duplicated points makes duplicated feature rows: the event must be seen by pipeline.upsample,
