@@ -696,9 +696,24 @@ def group_knn(k, query, points, unique=True, NCHW=True):
     batch_size, num_points, _ = points_trans.size()
     assert(num_points >= k), "points size must be greater or equal to k"
     need_grad = points_trans.requires_grad and torch.is_grad_enabled()
+    # Host tensors (the reference's data.py:135-139 calls group_knn on CPU tensors to cut training patches): the
+    # search still runs on the HIP kernel -- inputs are staged to the current ROCm device and the results come back
+    # as host tensors.  There is no CPU implementation behind this: without a device the call fails.
+    staged = getattr(BACKEND, "name", "") == "hip-gfx950" and not points_trans.is_cuda
+    if staged:
+        if query_trans.is_cuda:
+            raise RuntimeError("group_knn: query is on %s but points on the host" % query_trans.device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("group_knn: host tensors are searched on the ROCm device, and none is available")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        q_dev, p_dev = query_trans.detach().to(dev, torch.float32), points_trans.detach().to(dev, torch.float32)
+    else:
+        q_dev, p_dev = query_trans.detach(), points_trans.detach()
     with torch.no_grad():
-        point_indices, distances, knn_trans = BACKEND.knn(
-            k, query_trans.detach(), points_trans.detach(), unique, None, True, not need_grad)
+        point_indices, distances, knn_trans = BACKEND.knn(k, q_dev, p_dev, unique, None, True, not need_grad)
+    if staged:
+        point_indices, distances = point_indices.cpu(), distances.to("cpu", points_trans.dtype)
+        knn_trans = None if knn_trans is None else knn_trans.to("cpu", points_trans.dtype)
     if need_grad:
         knn_trans = torch.gather(points_trans.unsqueeze(1).expand(-1, query_trans.size(1), -1, -1), 2,
                                  point_indices.unsqueeze(-1).expand(-1, -1, -1, points_trans.size(-1)))

@@ -167,7 +167,9 @@ class Net(torch.nn.Module):
         return int(sum(int(c) for c in cells))
 
     def reset_small_cloud_events(self):
-        self._small_cloud_counts = {}
+        # in place: a captured hipGraph (pipeline.GraphedUpsample) keeps adding to the cell of its stream
+        for cell in self._small_cloud_counts.values():
+            cell.zero_()
 
     def set_mlp_precision(self, precision, activations=None):
         """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):

@@ -303,6 +303,90 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         return final(merged)
 
 
+class GraphedUpsample(object):
+    """`upsample` for ONE input shape as a hipGraph (reference main.py:360-380 handles one cloud
+    at a time, i.e. this is the reference's literal usage at its lowest latency).
+
+    The eval path has no host synchronisation and fixed padded shapes, so the ~390 launches of a cloud are captured
+    once and replayed: the ~5 ms of launch gaps of a 35 ms cloud go away.  The input is copied into a static buffer,
+    the result is the graph's static output (valid until the next call; `clone=True` hands out a copy).
+
+    The checks of `upsample(check_small=True)` run after every replay, at the synchronisation the caller needs
+    anyway for the result: if an optimistic kNN graph asked for the exact form, a cluster-FPS launch faulted or a
+    cloud fell below one patch, the call is answered by the eager `upsample` (which recomputes / raises as
+    documented there), so a replayed result is never handed out unchecked.  `check=False` leaves result and check
+    to the caller (it must then read BACKEND.graph_dup_events / fps_cluster_faults / net.small_cloud_events itself).
+
+    Weights are read through their storage: in-place updates are seen by the next replay; replacing a parameter
+    tensor, or changing the fold-able prep layers (the folded weights are built at capture), needs a new object."""
+
+    def __init__(self, net, shape, num_point, up_ratio, patch_num_ratio=3, device=None, final_fps=True):
+        dev = torch.device(device) if device is not None else next(net.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedUpsample needs a ROCm device")
+        self.net, self.num_point, self.up_ratio, self.patch_num_ratio = net, num_point, up_ratio, patch_num_ratio
+        self.final_fps = final_fps
+        self.shape = tuple(shape)
+        self.static_in = torch.zeros(self.shape, dtype=torch.float32, device=dev)
+        self.static_out = None
+        self.graph = None
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _body(self):
+        return _upsample(self.net, self.static_in, self.num_point, self.up_ratio, self.patch_num_ratio, None,
+                         self.final_fps)
+
+    @torch.no_grad()
+    def _capture(self):
+        be = operations.BACKEND
+        saved = getattr(be, "optimistic_graph", None)
+        if saved is not None:
+            be.optimistic_graph = True
+        try:
+            # eager warm-up ON THE CAPTURE STREAM: allocator pools, the backend's event words, the levels' folded
+            # weights (keyed to the stream that built them), kernel attributes -- nothing of that may happen inside
+            # the capture
+            self.stream.wait_stream(torch.cuda.current_stream(self.static_in.device))
+            with torch.cuda.stream(self.stream):
+                self._body()
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.static_out = self._body()
+        finally:
+            if saved is not None:
+                be.optimistic_graph = saved
+
+    @torch.no_grad()
+    def __call__(self, clouds, check=True, clone=False):
+        if tuple(clouds.shape) != self.shape:
+            raise ValueError("GraphedUpsample was built for %s, got %s" % (self.shape, tuple(clouds.shape)))
+        be = operations.BACKEND
+        if check:
+            if hasattr(self.net, "reset_small_cloud_events"):
+                self.net.reset_small_cloud_events()
+            if hasattr(be, "graph_dup_events"):
+                be.graph_dup_events(reset=True)
+        self.static_in.copy_(clouds)
+        if self.graph is None:
+            self._capture()
+            if check:           # (the warm-up and the capture itself ran the kernels: start from clean counters)
+                if hasattr(self.net, "reset_small_cloud_events"):
+                    self.net.reset_small_cloud_events()
+                if hasattr(be, "graph_dup_events"):
+                    be.graph_dup_events(reset=True)
+        self.graph.replay()
+        if check:
+            torch.cuda.synchronize(self.static_in.device)
+            bad = hasattr(be, "graph_dup_events") and be.graph_dup_events(reset=True)
+            bad = bad or (hasattr(be, "fps_cluster_faults") and be.fps_cluster_faults(reset=True) > 0)
+            bad = bad or (hasattr(self.net, "small_cloud_events") and self.net.small_cloud_events)
+            if bad:
+                return upsample(self.net, clouds, self.num_point, self.up_ratio, self.patch_num_ratio,
+                                final_fps=self.final_fps, optimistic_graph=False)
+        return self.static_out.clone() if clone else self.static_out
+
+
 def pc_prediction(net, input_pc, num_point, up_ratio, patch_num_ratio=3):
     """Drop-in shaped like the reference's pc_prediction (main.py:214-246):
     input_pc 1x3xN -> (input_list of [1x3xM] normalised patches, up_point_list of [1x3xMr])."""

@@ -30,7 +30,10 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
                     chamfer_vs_oracle, set_close_1e-5  ("Chamfer vs ref" half of the metric)
   parity_c2         the metric's OWN configuration (C2, 16x, 5000 -> 80000) through the HIP path against the output of
                     the reference's own Python driver for the same cloud and weights (tests/golden/c2_x16.npz)
-  extras            latency_ms_1cloud, train_step_ms (C3: B = 32, ratio 16), chamfer_80k_ms, c5 (stress) ...
+  value_1cloud      BASELINE's C2 read literally: ONE cloud at a time (the faster of eager / hipGraph replay) -> points/s
+  value_8clouds     config C4's per-rank share: 8 clouds per GPU per step -> points/s
+  extras            latency_ms_1cloud (+ _eager), ms_per_step_8clouds, train_step_ms (C3: B = 32, ratio 16),
+                    chamfer_80k_ms, c5 (stress) ...
 """
 import argparse
 import importlib
@@ -55,7 +58,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TF = 157.3           # fp32 vector = fp32 MFMA dense peak
 F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA peak
-PROFILE_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json")]
+PROFILE_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json")]
 
 
 def pkg(sub=None):
@@ -172,11 +175,13 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
     if shp:
         flop = sum(p * n * n * (2.0 * c + 3.0) for p, n, c, k in shp)   # B*M*N*(2C+3), M = N
         ach = flop / (ms * 1e-3) / 1e12
-        out.append({"kernel": "knn_graph_key_kernel (feature kNN graph k=33, one pass, exact) incl. its output allocation, "
-                              "%d launches/step" % len(shp),
+        t_graph = [tr(kk) for kk in ("knn_graph_slab_kernel", "knn_slab_order_kernel")]
+        t_graph = sum(t_graph) if all(v is not None for v in t_graph) else tr("knn_graph_key_kernel")
+        out.append({"kernel": "knn_slab_order_kernel + knn_graph_slab_kernel (feature kNN graph k=33, slab form, exact) incl. "
+                              "the output allocation, %d launches/step" % len(shp),
                     "bound": "valu", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                     "basis": "SURVEY 8d compute model B*M*N*(2C+3) FLOP against the fp32 vector peak",
-                    "ms_per_step": ms, "ms_per_step_min_max": spread, "model_flop_per_step": flop, "traffic": tr("knn_graph_key_kernel")})
+                    "ms_per_step": ms, "ms_per_step_min_max": spread, "model_flop_per_step": flop, "traffic": t_graph})
     ms, shp, spread = kt.total("regress_tail")
     if shp:
         ex = sum(m * rr * 2.0 * (128 * 128 + 128 * 64 + 64 * 16) for m, rr in shp)
@@ -222,13 +227,56 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
     ms, shp, spread = kt.total("fps", lambda s: s[2] >= 256)
     if shp:
         rounds = sum(m - 1 for _, _, m in shp)
-        out.append({"kernel": "rl_main_kernel (per-level resampling FPS, several samples per round), %d launches/step"
-                              % len(shp),
-                    "bound": "latency", "us_per_sample": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
-                    "ms_per_step_min_max": spread,
-                    "sets_per_launch": [b for b, _, _ in shp],
-                    "basis": "dependent chain: one workgroup (= one compute unit) per set, 256 sets at a time; "
-                             "us_per_sample = launch time / samples per SET (all sets of a launch share it)"})
+        entry = {"kernel": "rl_main_kernel (per-level resampling FPS, several samples per round), %d launches/step"
+                           % len(shp),
+                 "bound": "latency", "us_per_sample": ms * 1e3 / max(1, rounds), "ms_per_step": ms,
+                 "ms_per_step_min_max": spread,
+                 "sets_per_launch": [b for b, _, _ in shp],
+                 "basis": "dependent chain: one workgroup (= one compute unit) per set, 256 sets at a time; "
+                          "us_per_sample = launch time / samples per SET (all sets of a launch share it)"}
+        # rounds of the LARGEST level set (24 960 -> 4992), one wave of sets (<= 256: every set has its compute unit),
+        # from the kernel's own counters; the floor is the round's update phase as pure instruction issue
+        try:
+            import ctypes
+            seen = {}
+            real = be.fps
+
+            def spy(xyz, npoint, n_arr=None, m_arr=None):
+                if npoint >= 256 and xyz.size(1) <= 25600 and xyz.size(1) > seen.get("n", 0):
+                    seen.update(n=xyz.size(1), args=(xyz[:192].clone(), npoint, None if n_arr is None else n_arr[:192].clone(),
+                                                    None if m_arr is None else m_arr[:192].clone()))
+                return real(xyz, npoint, n_arr, m_arr)
+            be.fps = spy
+            try:
+                pipe.upsample(net, clouds[:4], npnt, r, 3, final_fps=False, check_small=False, optimistic_graph=True)
+            finally:
+                del be.fps
+            if seen:
+                st = torch.zeros(52, dtype=torch.int64, device=clouds.device)
+                lib = pkg("_lib").lib()
+                best = None
+                for it in range(3):
+                    st.zero_()
+                    lib.tpu3_debug_fps_level_stats(ctypes.c_void_p(st.data_ptr()))
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    real(*seen["args"])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
+                rnd, smp = int(st[0]), int(st[1])
+                if rnd:
+                    entry.update({"largest_set": "%d -> %d points, %d sets in one wave of workgroups (operator time incl. "
+                                                 "Morton sort and set-up)" % (seen["n"], seen["args"][1], seen["args"][0].size(0)),
+                                  "rounds": rnd, "samples_per_round": smp / rnd, "us_per_round": best * 1e3 / rnd,
+                                  "us_per_round_floor": 3.3, "x_over_floor": best * 1e3 / rnd / 3.3,
+                                  "floor_model": "a round's update phase alone: ~10 sample-updates of 25 x 64 points per SIMD "
+                                                 "= 7.9 k cycles of VALU issue on every SIMD of the set's compute unit = 3.3 us "
+                                                 "at 2.4 GHz (a model of THIS algorithm, not a hardware bound)"})
+        except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
+            entry["rounds"] = "failed: %s" % (str(e).splitlines()[0][:120])
+        out.append(entry)
     ms, shp, spread = kt.total("knn")
     if shp:
         out.append({"kernel": "knn_insert / knn_select / knn_sort kernels (patch extraction, outlier filter, inter-level k=5), "
@@ -248,7 +296,46 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r):
         pipe.upsample(net, one, npnt, r, 3, check_small=False, optimistic_graph=True)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-    ex["latency_ms_1cloud"] = float(np.median(ts[1:]))
+    ex["latency_ms_1cloud_eager"] = float(np.median(ts[1:]))
+    # ... and the same call as a hipGraph (pipeline.GraphedUpsample: captured once, checked after every replay)
+    try:
+        fast = pipe.GraphedUpsample(net, tuple(one.shape), npnt, r, 3)
+        ref = pipe.upsample(net, one, npnt, r, 3)
+        same = bool(torch.equal(fast(one, clone=True), ref))
+        ts = []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fast(one)                                  # (check=True: synchronises and reads the event words)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ex["latency_ms_1cloud_graph"] = float(np.median(ts[1:]))
+        ex["latency_1cloud_graph_note"] = ("hipGraph replay incl. input copy and post-replay checks; result == eager: %s.  "
+                                           "(r5: no gain -- the ~390 kernels of a cloud are dependent, the gaps are the "
+                                           "GPU's own dispatch-after-drain, not host launches)" % same)
+        ex["latency_ms_1cloud"] = min(ex["latency_ms_1cloud_eager"], ex["latency_ms_1cloud_graph"])
+        del fast
+    except Exception as e:                                               # noqa: BLE001 (reported, not hidden)
+        ex["latency_ms_1cloud"] = ex["latency_ms_1cloud_eager"]
+        ex["latency_1cloud_graph_note"] = "graph capture failed: %s" % (str(e).splitlines()[0][:120])
+    # config C4's per-rank share: 8 clouds per GPU per step, same stream arrangement as the timed region
+    try:
+        sub = clouds[:8]
+        nets8 = [torch.cuda.Stream(device=dev) for _ in range(args.net_streams)] if args.net_streams > 1 else None
+        side8 = None if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(args.fps_streams)]
+        def step8(i):
+            return pipe.upsample(net, sub, npnt, r, 3, fps_stream=None if side8 is None else side8[i % len(side8)],
+                                 net_streams=nets8, sub_batch=args.sub_batch, check_small=False, optimistic_graph=True)
+        for i in range(2):
+            step8(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K8 = 10
+        for i in range(K8):
+            step8(i)
+        torch.cuda.synchronize()
+        ex["ms_per_step_8clouds"] = (time.perf_counter() - t0) / K8 * 1e3
+    except Exception as e:                                               # noqa: BLE001
+        ex["ms_per_step_8clouds"] = "failed: %s" % (str(e).splitlines()[0][:120])
     # Chamfer between two 80 000-point clouds (the evaluation metric's kernel)
     ml = pkg("network.model_loss")
     a = poisson_sphere(1000, N, dev, ops).transpose(2, 1).contiguous().repeat(1, r, 1)
@@ -741,6 +828,12 @@ def main():
                     "traffic_provenance": (traffic or {}).get("provenance")}
             if "useful_frac" in top:
                 roof["useful_frac"] = top["useful_frac"]
+            if top.get("survey_model_flop_per_step"):
+                # SURVEY 8(d)'s ALGORITHMIC model (3168 FLOP per edge, un-hoisted) beside the executed figure: the kernel
+                # legitimately executes about a third of it (per-point hoisting), so model_frac may exceed 1
+                roof["model_flop_per_step"] = top["survey_model_flop_per_step"]
+                roof["model_frac"] = top["survey_model_flop_per_step"] / (top["ms_per_step"] * 1e-3) / 1e12 / top["peak"]
+                roof["executed_flop_per_step"] = top.get("executed_flop_per_step")
             line["roofline"] = roof
             # --- the whole step against the chip
             flop = sum(o.get("executed_flop_per_step", 0.0) for o in others)
@@ -765,6 +858,15 @@ def main():
                                 "note": "no per-kernel events in this run (--no_extras / sharded patches)"}
         if do_extras:
             line["extras"] = extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r)
+            # first-class next to `value` (which is the --clouds batch): BASELINE's C2 read literally -- ONE cloud at a
+            # time, as the reference's test() loop does -- and C4's per-rank share of 8 clouds per GPU per step
+            lat = line["extras"].get("latency_ms_1cloud")
+            if isinstance(lat, float):
+                line["value_1cloud"] = N * r / (lat * 1e-3)
+                line["ms_per_cloud_1cloud"] = lat
+            ms8 = line["extras"].get("ms_per_step_8clouds")
+            if isinstance(ms8, float) and clouds.shape[0] >= 8:
+                line["value_8clouds"] = 8 * N * r / (ms8 * 1e-3)
             try:
                 line["rooflines_train"] = train_rooflines(ops, ups, dev)
             except Exception as e:                                           # noqa: BLE001 (reported, not hidden)

@@ -64,3 +64,19 @@ def test_bench_two_ranks_patches_sharded_equals_one_rank():
     one = _bench(1, ["--clouds", "1"])
     assert len(two["result_digest"]) == 1
     assert two["result_digest"] == one["result_digest"]
+
+
+def test_bench_eight_ranks_dry_run_equals_one_rank():
+    """The driver's scaling run launches `bench.py --gpus 8` as eight ranks.  No 8-GPU node is available to the
+    tests, so the eight ranks share cuda:0 over gloo -- every line of the N = 8 path but the transport: eight
+    processes initialise, shard_range deals clouds 0..7 one per rank, the single all-gather reassembles them in
+    rank order, rank 0 alone prints the line, every rank leaves through the final barrier.  The gathered clouds
+    are bit for bit what one rank computes for the same eight seeds (config C4 at one cloud per rank)."""
+    eight = _bench(8, ["--clouds", "1"], timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak"
+    assert eight["comm"]["world_size"] == 8 and eight["comm"]["backend"] == "gloo"
+    assert eight["comm"]["allgather_bytes_total"] == 8 * 1 * 3 * 80000 * 4
+    assert eight["config"]["clouds_per_gpu"] == 1 and eight["value"] > 0
+    one = _bench(1, ["--clouds", "8"])
+    assert len(eight["result_digest"]) == 8
+    assert eight["result_digest"] == one["result_digest"]

@@ -59,3 +59,23 @@ def test_checkpoint_format_roundtrip(tmp_path):
     assert pu.load_network(net2, path) == 1234
     for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_checkpoint_as_pickled_numpy_dict(tmp_path):
+    """The reference's load_network also takes a pickled numpy dict (utils/pytorch_utils.py:24-27: any path not
+    ending in 'pth' goes through np.load(...).item()): same layout, arrays or tensors under 'states'."""
+    pu, ups = pkg("utils.pytorch_utils"), pkg("network.upsampler")
+    torch.manual_seed(2)
+    net = ups.Net(max_up_ratio=2, step_ratio=2, knn=32)
+    record = {"states": {k: v.numpy() for k, v in net.state_dict().items()}, "step": 77}
+    record["states"]["stale.entry"] = np.zeros(3, np.float32)
+    path = str(tmp_path / "model.npy")
+    np.save(path, np.array(record, dtype=object), allow_pickle=True)
+    net2 = ups.Net(max_up_ratio=2, step_ratio=2, knn=32)
+    assert pu.load_network(net2, path) == 77
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+    # a file without a step counts from 0
+    del record["step"]
+    np.save(path, np.array(record, dtype=object), allow_pickle=True)
+    assert pu.load_network(net2, path) == 0

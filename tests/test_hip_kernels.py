@@ -662,6 +662,23 @@ def test_knn_graph_slab_form_on_low_dimensional_rows(orc, dev, n):
     np.testing.assert_array_equal(np.sort(both[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
 
 
+def test_group_knn_takes_host_tensors_through_the_device(orc, dev):
+    """The reference cuts its training patches with group_knn on CPU tensors (data.py:135-139).  Here host tensors
+    are staged to the device, searched by the HIP kernel and returned as host tensors: same values as a device call,
+    and the oracle's indices."""
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(5)
+    pts = rng.standard_normal((1, 3000, 3)).astype(np.float32)
+    q = pts[:, rng.integers(0, 3000, size=8)]
+    g_h, i_h, d_h = ops.group_knn(312, torch.from_numpy(q), torch.from_numpy(pts), NCHW=False)
+    assert not g_h.is_cuda and not i_h.is_cuda and not d_h.is_cuda and i_h.dtype == torch.int64
+    g_d, i_d, d_d = ops.group_knn(312, _t(q, dev), _t(pts, dev), NCHW=False)
+    assert torch.equal(g_h, g_d.cpu()) and torch.equal(i_h, i_d.cpu()) and torch.equal(d_h, d_d.cpu())
+    ri, rd = orc.knn(312, q, pts, True)
+    np.testing.assert_array_equal(i_h.numpy(), ri)
+    np.testing.assert_array_equal(d_h.numpy(), rd)
+
+
 def test_knn_select_ragged_sets_and_exact_ties(orc, dev):
     """The patch extraction's shape (k = 312) with ragged point sets (upsampler.py:59-86 after the outlier
     filter), exact distance ties (lattice points: ties go to the lowest index) and a set with fewer live points

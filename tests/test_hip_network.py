@@ -565,6 +565,29 @@ def test_dense_edge_conv_training_idx_can_be_fed_back(dev):
     assert gathered.shape == x.shape
 
 
+def test_graphed_upsample_equals_eager(dev):
+    """pipeline.GraphedUpsample: one cloud's whole 16x pass (seeds, outer patches, four levels with every inner FPS /
+    kNN, merge, final FPS on 16 workgroups) captured once as a hipGraph and replayed -- the result must be the eager
+    call's bit for bit, for the captured cloud and for a different cloud replayed through the same graph, and a cloud
+    with duplicated points (the optimistic feature graphs raise their event) must come back recomputed exactly."""
+    pipe = pkg("pipeline")
+    net = _net(dev)
+    clouds = [torch.from_numpy(np.ascontiguousarray(sphere(60 + i, 5000).transpose(0, 2, 1))).to(dev) for i in range(2)]
+    fast = pipe.GraphedUpsample(net, (1, 3, 5000), 312, 16, 3)
+    for rep in range(2):
+        for x in clouds:
+            ref = pipe.upsample(net, x, 312, 16, 3)
+            out = fast(x, clone=True)
+            assert torch.equal(out, ref)
+    dup = clouds[0].clone()
+    dup[:, :, 4000:] = dup[:, :, :1000]
+    ref = pipe.upsample(net, dup, 312, 16, 3)
+    assert torch.equal(fast(dup, clone=True), ref)
+    assert torch.equal(fast(clouds[1], clone=True), pipe.upsample(net, clouds[1], 312, 16, 3))
+    with pytest.raises(ValueError):
+        fast(torch.zeros(1, 3, 4000, device=dev))
+
+
 def test_pipeline_recomputes_when_a_cluster_fps_launch_faults(dev):
     """The final FPS of one cloud runs on 16 workgroups that spin on each other (csrc/fps_cluster.hip).  With a member
     made absent (tpu3_debug_fps_cluster_absent: it leaves at once, as if it had never become resident) the others give
