@@ -106,3 +106,50 @@ def test_c1_hip_path_against_the_oracle_driven_path(dev):
     assert r["chamfer_vs_oracle"] < 1e-10
     assert r["set_close_1e-5"] >= 0.998
     assert r["position_wise_close_1e-5"] >= 0.98
+
+
+def _chain_errors(g, ids, levels, x16):
+    err = np.zeros((len(ids), 4))
+    for i, q in enumerate(ids):
+        for l in (1, 2, 3, 4):
+            ref = g["p%d_l%d_out" % (q, l)]
+            mine = levels[l - 1][i].T if l < 4 else x16[i]
+            err[i, l - 1] = np.abs(mine - ref).max()
+    return err
+
+
+def test_c2_chain_replayed_on_device_is_within_1e5_end_to_end(dev):
+    """Four outer patches of the C2 cloud through ALL FOUR levels on the HIP path with every discrete choice of the
+    reference's run replayed (tests/golden/c2_chain.npz, tests/chain_replay.py: outlier masks, inner seeds, inner
+    patches, the 16 feature graphs, the inter-level neighbour sets, the per-level FPS picks -- patch 16 with the
+    ragged 19-of-20 inner patches at level 3): the final 4992 points of every patch, and the cloud after every level,
+    within 1e-5 of the reference's.  north_star's "upsampled xyz within 1e-5" holds end to end wherever the discrete
+    choices agree (the CPU twin: tests/test_c2_chain_cpu.py)."""
+    from chain_replay import run_chain
+    ops = pkg("network.operations")
+    g = golden("c2_chain.npz")
+    ids = [int(q) for q in g["patch_ids"]]
+    chain, levels, x16 = run_chain(ops, _net(dev), g, ids, dev, "replay")
+    assert chain.graph_calls == 16 and chain.levels_closed == 3
+    err = _chain_errors(g, ids, levels, x16)
+    print("chained replay on the device: max |dx| per outer patch %s (rows) and level 1..4 (columns):\n%s" % (ids, err))
+    assert err.max() <= 1e-5, err
+
+
+def test_c2_chain_on_device_departs_only_at_named_flips(dev):
+    """The same four patches on the HIP path's OWN choices: the first choice that differs from the reference's is
+    named per patch, and every level before it is within 1e-5 -- no patch drifts without a named flip (patches 16 and
+    23 flip a feature-graph row already at level 1 on this path, tools/c2_level_flips.py)."""
+    from chain_replay import ORDER, first_flip, run_chain
+    ops = pkg("network.operations")
+    g = golden("c2_chain.npz")
+    ids = [int(q) for q in g["patch_ids"]]
+    chain, levels, x16 = run_chain(ops, _net(dev), g, ids, dev, "record")
+    assert sorted(chain.seen) == sorted(ORDER)
+    err = _chain_errors(g, ids, levels, x16)
+    for i, q in enumerate(ids):
+        flip = first_flip(chain, g, i, q)
+        upto = 4 if flip is None else int(flip[1]) - 1
+        print("outer patch %2d on the device: first choice that differs from the reference's: %-10s max |dx| per level %s"
+              % (q, flip, " ".join("%.1e" % e for e in err[i])))
+        assert (err[i, :upto] <= 1e-5).all(), (q, flip, err[i])
