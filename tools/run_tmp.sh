@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r5
-(timeout 900 python -m pytest tests/test_c2_parity.py -q -x -s -k chain 2>&1 | grep -v "^$" | tail -25) > gpurun_out/r5/chain_test.txt; cat gpurun_out/r5/chain_test.txt
+(timeout 300 ./tools/split_mfma_probe) > gpurun_out/r5/split_mfma_probe.txt 2>&1; cat gpurun_out/r5/split_mfma_probe.txt
