@@ -40,7 +40,6 @@ struct KnnArgs {
     float *dist;             // (b,m,k) or null
     const int32_t *cand;     // (bp,n) ascending indices of the first occurrences, or null
     const int32_t *cand_count;   // (bp)
-    int dbg;                 // measurement switches of knn_graph_slab_kernel (TPU3_KG_SLAB_DBG), 0 in production
 };
 
 __device__ __forceinline__ void store_idx(const KnnArgs &a, size_t off, int v)
@@ -1032,7 +1031,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     __syncthreads();
     if (live) {
-        const int pos = (a.dbg & 4) ? tid : hist[bin] + slot;
+        const int pos = hist[bin] + slot;
         int32_t *scr = (int32_t *)a.idx + (size_t)b * n * a.k;
         scr[pos] = __float_as_int(t);
         scr[n + pos] = tid;
@@ -1126,7 +1125,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const float tau = __int_as_float(lst[L - 1] | ~keep);      // top of the 32nd key's truncation bucket (NaN while the list is short)
             const bool out = !live || (gap > 0.f && __builtin_fmaf(gap, gap, -E2) > tau);
             const uint64_t outs = __builtin_amdgcn_ballot_w64(out);
-            if (!(a.dbg & 1) && outs == ~0ull) {
+            if (outs == ~0ull) {
                 if (left) lo_c = -1; else hi_c = nch;
                 continue;
             }
@@ -1157,9 +1156,11 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 m2 = min(m2, nw[u + 2]), m3 = min(m3, nw[u + 3]);
             }
             const int mn = min(min(m0, m1), min(m2, m3));
-            if (!(a.dbg & 2) && __builtin_amdgcn_ballot_w64(!live || mn > (lst[L - 1] | ~keep)) == ~0ull)
+            if (__builtin_amdgcn_ballot_w64(!live || mn > (lst[L - 1] | ~keep)) == ~0ull)
                 continue;
         }
+        // (taking the wave's first chunk -- empty list -- through the sorting network alone was measured: no gain, the
+        // second code path costs five spilled registers)
         kg_fold_i32<L>(lst, e, e2, nw);
     }
     // ---- boundary collisions after truncation: as knn_graph_key_kernel, ties by the ORIGINAL index ------------
@@ -2029,11 +2030,8 @@ int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a
     static const bool slab_on = !(getenv("TPU3_KG_SLAB") && atoi(getenv("TPU3_KG_SLAB")) == 0);
     if (slab_on && onepass && k == 33 && c > 16 && c <= 24 && a.n > 64 && a.n <= 320 && (int)g.x * threads >= a.n
         && threads == ((a.n + 63) / 64) * 64) {
-        static const int dbg = getenv("TPU3_KG_SLAB_DBG") ? atoi(getenv("TPU3_KG_SLAB_DBG")) : 0;
-        KnnArgs as = a;
-        as.dbg = dbg;
-        hipLaunchKernelGGL((knn_slab_order_kernel<24>), g, dim3(threads), 0, s, as);
-        hipLaunchKernelGGL((knn_graph_slab_kernel<24, 33>), g, dim3(threads), 0, s, as);
+        hipLaunchKernelGGL((knn_slab_order_kernel<24>), g, dim3(threads), 0, s, a);
+        hipLaunchKernelGGL((knn_graph_slab_kernel<24, 33>), g, dim3(threads), 0, s, a);
         return tpu3_launch_status();
     }
     if (k == 33) {
