@@ -12,7 +12,11 @@ This script measures both on the features the network's DenseEdgeConv blocks act
 input rows of every feature graph of a 16x run on one outer patch of the C2 cloud, queries dealt to waves as the kernel
 deals them (64 consecutive points), candidates in patch order.
 
-usage: python tools/knn_accept_sim.py            (CPU only; ~1 min)"""
+usage: python tools/knn_accept_sim.py            (CPU only; ~1 min)
+       python tools/knn_accept_sim.py --slab     (r5) the SLAB form: rows ordered along one direction, a wave's 64 queries
+                                                 consecutive in that order, chunks visited outwards -- the share of (wave, chunk)
+                                                 pairs closed by the projected-gap bound before any distance, and skipped after
+                                                 the distances because no lane accepts (csrc/knn.hip, knn_graph_slab_kernel)"""
 import importlib
 import os
 import sys
@@ -91,7 +95,106 @@ def simulate(x):
     return tot_pairs, c_accept_any, c_chunk_max, float(np.mean(acc_mean))
 
 
+def slab_axis(x, kind):
+    """t = projection of the rows on a unit direction chosen like the kernel's pre-pass (float64 here)."""
+    n = len(x)
+    if kind == "pca1":
+        xc = x - x.mean(0)
+        return xc @ np.linalg.svd(xc, full_matrices=False)[2][0]
+    if kind == "ones-2":
+        xc = x - x.mean(0)
+        v = np.ones(x.shape[1])
+        for _ in range(2):
+            v = xc.T @ (xc @ v)
+            v /= np.linalg.norm(v)
+        return xc @ v
+    v0 = (x[((x - x[0]) ** 2).sum(1).argmax()] if kind == "far-1" else x[n - 1]) - x[0]
+    S = x.sum(0)
+    v = x.T @ (x @ v0) - (S @ v0) / n * S
+    return x @ (v / np.linalg.norm(v))
+
+
+def slab_sim(x, perm, t=None):
+    """(chunks in all, closed by the bound, skipped after the distances) for one patch; t None: no bound (an order
+    that is not a projection of the current rows)."""
+    n = x.shape[0]
+    xp = x[perm]
+    tp = None if t is None else t[perm]
+    d = ((xp[:, None, :] - xp[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d, np.inf)
+    L, nch = K - 1, (n + 31) // 32
+    tot = lb = post = 0
+    for wi, w0 in enumerate(range(0, n, 64)):
+        q = d[w0:w0 + 64]
+        lst = np.full((q.shape[0], L), np.inf)
+        lo, hi, side, step = 2 * wi - 1, 2 * wi + 2, 0, 0
+        while True:
+            if step < 2:
+                c, own = 2 * wi + step, True
+                if c >= nch:
+                    step += 1
+                    continue
+            else:
+                own = False
+                lopen, hopen = lo >= 0, hi < nch
+                if not lopen and not hopen:
+                    break
+                left = lopen and (not hopen or side == 0)
+                side ^= 1
+                c = lo if left else hi
+                if tp is not None:
+                    tc = tp[c * 32:c * 32 + 32]
+                    gap = np.maximum(tc.min() - tp[w0:w0 + 64], tp[w0:w0 + 64] - tc.max())
+                    if ((gap > 0) & (gap * gap > lst.max(axis=1))).all():
+                        closed = lo + 1 if left else nch - hi
+                        tot += closed
+                        lb += closed
+                        if left:
+                            lo = -1
+                        else:
+                            hi = nch
+                        continue
+                if left:
+                    lo -= 1
+                else:
+                    hi += 1
+            step += 1
+            tot += 1
+            nw = q[:, c * 32:c * 32 + 32]
+            if not own and not (nw.min(axis=1) < lst.max(axis=1)).any():
+                post += 1
+                continue
+            lst = np.partition(np.concatenate([lst, nw], axis=1), L - 1, axis=1)[:, :L]
+    return tot, lb, post
+
+
+def main_slab():
+    feats = graphs_inputs()
+    print("feature graphs seen: %d calls, shapes %s" % (len(feats), sorted({r.shape for r in feats})))
+    res = {}
+    for gi, x in enumerate(feats):
+        for p in range(min(x.shape[0], 6)):
+            xx = x[p].astype(np.float64)
+            runs = {"patch order, chunks in sequence (shipped one-pass kernel)": (np.arange(len(xx)), None)}
+            for kind, label in (("pca1", "first principal axis (exact)"), ("ones-2", "two power iterations from ones"),
+                                ("far-1", "x_far - x_0, one power iteration (built)"),
+                                ("last-1", "x_last - x_0, one power iteration")):
+                t = slab_axis(xx, kind)
+                runs[label] = (np.argsort(t, kind="stable"), t)
+            for label, (perm, t) in runs.items():
+                r = slab_sim(xx, perm, t)
+                acc = res.setdefault(label, [0, 0, 0])
+                for i in range(3):
+                    acc[i] += r[i]
+    print("share of (wave, chunk) pairs, over the feature rows of %d graphs (up to 6 patches each):" % len(feats))
+    print("%-62s %-22s %s" % ("order of the patch's rows", "closed by the bound", "skipped after the distances"))
+    for label, (tot, lb, post) in res.items():
+        print("%-62s %-22.3f %.3f" % (label, lb / tot, post / tot))
+
+
 def main():
+    if "--slab" in sys.argv:
+        return main_slab()
     rows = graphs_inputs()
     print("feature graphs seen: %d calls, shapes %s" % (len(rows), sorted({r.shape for r in rows})))
     tp = ca = cc = 0.0
