@@ -859,20 +859,27 @@ __device__ __forceinline__ int kg_wave_incl_scan(int v)
 }
 
 // Pre-pass of the slab form: the order of every patch along its direction v.  One workgroup per patch, a thread per
-// row; cheap in registers, so many waves per SIMD hide its seven barriers (fused into the graph kernel, whose 158
-// registers allow two workgroups per compute unit, the same work cost 13 % of that kernel's time).  Output, in the
-// head of the patch's own (n, K) index rows -- scratch until the graph kernel overwrites them with the result:
-// words [0, n) = t of the row at each sorted position, words [n, 2n) = that row's number.
+// row.  Cheap in registers, four workgroups per compute unit -- which makes it bound by instruction ISSUE (20 waves
+// per compute unit), so every phase is written for few instructions: rows and directions are re-read from LDS rather
+// than kept, the transposed sums run without per-lane predicates over zero-padded rows, and what is the same for
+// every thread (the direction, its norm, the bin scale) is computed once by 24 lanes of wave 0.  (Fused into the graph
+// kernel, whose 158 registers allow two workgroups per compute unit, the same work cost 13 % of that kernel's time.)
+// Output, in the head of the patch's own (n, K) index rows -- scratch until the graph kernel overwrites them with
+// the result: words [0, n) = t of the row at each sorted position, words [n, 2n) = that row's number.
+// Rows are exactly C floats wide and 16-byte aligned (the launcher checks).
 template <int C>
-__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(6, 6))) void knn_slab_order_kernel(KnnArgs a)
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(5, 8))) void knn_slab_order_kernel(KnnArgs a)
 {
     constexpr int TILE = 320;
     constexpr int NW = TILE / 64;
     constexpr int RMAX = 26;                        // rows per (channel, row group) thread of the transposed sums
-    __shared__ __attribute__((aligned(16))) float tile[TILE * C];      // the patch's rows, original order
-    __shared__ float ts[TILE];                      // s_i = <x_i, v0>
+    constexpr int ROWS = (TILE / C) * RMAX;         // 338: every row a group may touch exists (zero beyond n)
+    constexpr int Q = C / 4;
+    __shared__ __attribute__((aligned(16))) float tile[ROWS * C];      // the patch's rows, original order
+    __shared__ float ts[ROWS];                      // s_i = <x_i, v0>
     __shared__ int hist[TILE];                      // bin counts, then exclusive offsets
-    __shared__ __attribute__((aligned(16))) float vec[2 * C];
+    __shared__ __attribute__((aligned(16))) float vec[2 * C + 4];      // [A | S | sum of s]
+    __shared__ __attribute__((aligned(16))) float dir[C + 4];          // v (|v| < 1), then mean of t, bin scale
     __shared__ int wfar[NW];                        // per wave: arg-max key of |x_i - x_0|^2
     if (a.uws && a.uws[0] != 0)
         return;
@@ -882,131 +889,121 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int nthreads = blockDim.x;                // ceil(n / 64) * 64
     const int nwaves = nthreads >> 6;
     const bool live = tid < n;
-    const float *X = a.query + (size_t)b * n * a.c;
-
-    // (registers: nothing but scalars lives across a barrier -- rows and directions are re-read from LDS -- so that
-    // four workgroups fit a compute unit: <= 96 VGPRs)
+    const float4 *X4 = (const float4 *)(a.query + (size_t)b * n * C);
+    float4 *tile4 = (float4 *)tile;
+    const float4 *own4 = tile4 + tid * Q;
     {
-        float x[C], rq;
-        load_query<C>(x, rq, X + (size_t)(live ? tid : 0) * a.c, a.c, live);
+        float4 x[Q], r0[Q];
+        float d0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i)             // (dead threads: zero rows, never summed)
-            ((float4 *)tile)[tid * (C / 4) + i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
-        hist[tid] = 0;
-        if (tid < 2 * C)
-            vec[tid] = 0.f;
-        // the row farthest from row 0 (any of the farthest: the row number rides in the low bits)
-        float r0[C], d0 = 0.f, unused;
-        load_query<C>(r0, unused, X, a.c, true);
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const float e = x[i] - r0[i];
-            d0 = __builtin_fmaf(e, e, d0);
+        for (int i = 0; i < Q; ++i) {
+            x[i] = X4[(size_t)(live ? tid : 0) * Q + i];
+            r0[i] = X4[i];
         }
-        // (a NaN / Inf row may win: the direction is then useless, never unsafe -- the graph kernel's bound uses
-        // the t values written here whatever they are)
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            if (!live)
+                x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tile4[tid * Q + i] = x[i];
+            const float e0 = x[i].x - r0[i].x, e1 = x[i].y - r0[i].y, e2 = x[i].z - r0[i].z, e3 = x[i].w - r0[i].w;
+            d0 = __builtin_fmaf(e0, e0, d0), d0 = __builtin_fmaf(e1, e1, d0);
+            d0 = __builtin_fmaf(e2, e2, d0), d0 = __builtin_fmaf(e3, e3, d0);
+        }
+        // zero rows behind the workgroup's own (the transposed sums read up to ROWS rows)
+        for (int r = nthreads * Q + tid; r < ROWS * Q; r += nthreads)
+            tile4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = nthreads + tid; r < ROWS; r += nthreads)
+            ts[r] = 0.f;
+        hist[tid] = 0;
+        if (tid < 2 * C + 4)
+            vec[tid] = 0.f;
+        // the row farthest from row 0 (any of the farthest: the row number rides in the low bits; a NaN / Inf row may
+        // win: the direction is then useless, never unsafe -- the graph kernel's bound uses the t values whatever they are)
         const int key = live ? (int)((__float_as_uint(d0) & 0x7FFFFE00u) | (uint32_t)tid) : 0;
         const int wmax = tpu3_wave_max_i32(key);
         if (lane == 0)
             wfar[wave] = wmax;
     }
     __syncthreads();
-    int far = wfar[0];
-    for (int w = 1; w < nwaves; ++w)
-        far = max(far, wfar[w]);
-    const int p = far & 0x1FF;
-    const float4 *own4 = (const float4 *)tile + tid * (C / 4);
-    const float4 *row0 = (const float4 *)tile, *rowp = (const float4 *)tile + p * (C / 4);
+    float n0sq = 0.f;
     {
+        int far = wfar[0];
+        for (int w = 1; w < nwaves; ++w)
+            far = max(far, wfar[w]);
+        const float4 *rowp = tile4 + (far & 0x1FF) * Q;
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i) {
-            const float4 xo = own4[i], a0 = row0[i], ap = rowp[i];
-            s = __builtin_fmaf(xo.x, ap.x - a0.x, s), s = __builtin_fmaf(xo.y, ap.y - a0.y, s);
-            s = __builtin_fmaf(xo.z, ap.z - a0.z, s), s = __builtin_fmaf(xo.w, ap.w - a0.w, s);
+        for (int i = 0; i < Q; ++i) {
+            const float4 xo = own4[i], a0 = tile4[i], ap = rowp[i];
+            const float v0 = ap.x - a0.x, v1 = ap.y - a0.y, v2 = ap.z - a0.z, v3 = ap.w - a0.w;
+            s = __builtin_fmaf(xo.x, v0, s), s = __builtin_fmaf(xo.y, v1, s);
+            s = __builtin_fmaf(xo.z, v2, s), s = __builtin_fmaf(xo.w, v3, s);
+            n0sq = __builtin_fmaf(v0, v0, n0sq), n0sq = __builtin_fmaf(v1, v1, n0sq);
+            n0sq = __builtin_fmaf(v2, v2, n0sq), n0sq = __builtin_fmaf(v3, v3, n0sq);
         }
-        ts[tid] = live ? s : 0.f;                   // s_i = <x_i, v0>, v0 = x_p - x_0
+        ts[tid] = s;                                // s_i = <x_i, v0>, v0 = x_far - x_0 (dead rows: 0)
     }
     __syncthreads();
-    // [A | S] = [sum_i s_i x_i | sum_i x_i]: thread (channel k, row group g) adds its rows (half of its loads in
-    // flight at a time), one LDS float atomic per thread and sum adds the groups (their order does not matter: v is a
-    // heuristic)
+    // [A | S | sum s] = [sum_i s_i x_i | sum_i x_i | sum_i s_i]: thread (channel k, row group g) adds its R rows (zero
+    // rows beyond n: no predicates), one LDS float atomic per thread and sum adds the groups (their order does not
+    // matter: v is a heuristic)
     {
         const int G = nthreads / C;
         const int k = tid % C, g = tid / C;
         if (g < G) {
-            const int R = (n + G - 1) / G;
-            const int r0 = g * R, r1 = min(n, r0 + R);
-            float accA = 0.f, accS = 0.f;
+            const int R = (n + G - 1) / G;          // <= RMAX, wave-uniform
+            const float *tp = tile + (g * R) * C + k, *sp = ts + g * R;
+            float accA = 0.f, accS = 0.f, accT = 0.f;
 #pragma unroll
-            for (int h0 = 0; h0 < RMAX; h0 += RMAX / 2) {
-                float xv[RMAX / 2], sv[RMAX / 2];
-#pragma unroll
-                for (int u = 0; u < RMAX / 2; ++u) {
-                    const bool in = r0 + h0 + u < r1;
-                    const int r = in ? r0 + h0 + u : r0;
-                    xv[u] = tile[r * C + k];
-                    sv[u] = ts[r];
-                    xv[u] = in ? xv[u] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < RMAX / 2; ++u) {
-                    accA = __builtin_fmaf(sv[u], xv[u], accA);
-                    accS += xv[u];
+            for (int u = 0; u < RMAX; ++u) {
+                if (u < R) {
+                    const float xv = tp[u * C], sv = sp[u];
+                    accA = __builtin_fmaf(sv, xv, accA);
+                    accS += xv;
+                    accT += sv;
                 }
             }
             atomicAdd(&vec[k], accA);
             atomicAdd(&vec[C + k], accS);
+            if (k == 0)
+                atomicAdd(&vec[2 * C], accT);
         }
     }
     __syncthreads();
-    float t;
-    int bin, slot = 0;
-    {
-        // v' = A - (<S, v0> / n) S  (= the centred second moment times v0), scaled to |v| < 1
-        float sv = 0.f, n0sq = 0.f;
-        float v[C];
-#pragma unroll
-        for (int i = 0; i < C / 4; ++i) {
-            const float4 a0 = row0[i], ap = rowp[i], S4 = ((const float4 *)vec)[C / 4 + i];
-            v[4 * i] = ap.x - a0.x, v[4 * i + 1] = ap.y - a0.y, v[4 * i + 2] = ap.z - a0.z, v[4 * i + 3] = ap.w - a0.w;
-            sv = __builtin_fmaf(S4.x, v[4 * i], sv), sv = __builtin_fmaf(S4.y, v[4 * i + 1], sv);
-            sv = __builtin_fmaf(S4.z, v[4 * i + 2], sv), sv = __builtin_fmaf(S4.w, v[4 * i + 3], sv);
-        }
-#pragma unroll
-        for (int i = 0; i < C; ++i)
-            n0sq = __builtin_fmaf(v[i], v[i], n0sq);
-        sv = sv / (float)n;
-        float nrm2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            v[i] = __builtin_fmaf(-sv, vec[C + i], vec[i]);
-            nrm2 = __builtin_fmaf(v[i], v[i], nrm2);
-        }
+    if (wave == 0) {
+        // v' = A - (sum s / n) S  (= the centred second moment times v0), scaled to |v| < 1; by C lanes, once
+        const int k = lane < C ? lane : 0;
+        const float sv = vec[2 * C] / (float)n;
+        const float S = vec[C + k];
+        float v = lane < C ? __builtin_fmaf(-sv, S, vec[k]) : 0.f;
+        const float nrm2 = tpu3_wave_sum_f32(v * v);
         // (1 - 2^-10): the rounding of nrm2 and of the reciprocal square root stays far inside
         const bool ok = nrm2 > 0.f && nrm2 < __builtin_inff();
-        const float inv = ok ? __builtin_amdgcn_rsqf(nrm2) * 0.9990234375f : 0.f;
-        float mean = 0.f;
-        t = 0.f;
-#pragma unroll
-        for (int i = 0; i < C / 4; ++i) {
-            const float4 xo = own4[i];
-            const float xs[4] = {xo.x, xo.y, xo.z, xo.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float vi = ok ? v[4 * i + j] * inv : 0.f;
-                t = __builtin_fmaf(xs[j], vi, t);
-                mean = __builtin_fmaf(vec[C + 4 * i + j], vi, mean);
-            }
+        v = ok ? v * (__builtin_amdgcn_rsqf(nrm2) * 0.9990234375f) : 0.f;
+        const float mean = tpu3_wave_sum_f32(lane < C ? S * v : 0.f) / (float)n;
+        if (lane < C)
+            dir[lane] = v;
+        if (lane == 0) {
+            // nthreads bins over mean +- 2.5 sigma with sigma^2 ~ |C v0| / (|v0| n), the iteration's own estimate of
+            // the variance along v (no min / max reduction); rows beyond land in the end bins.  The bins only make
+            // the order GOOD; the graph kernel's bound uses each chunk's true t-range.
+            const float sig = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(nrm2) * __builtin_amdgcn_rsqf(n0sq) / (float)n);
+            dir[C] = mean;
+            dir[C + 1] = 0.2f * (float)nthreads * __builtin_amdgcn_rcpf(sig);       // (nthreads / 2) / (2.5 sigma)
         }
-        mean = mean / (float)n;
-        // binned counting sort by t: position = (rows in lower bins) + (arrival order inside the bin).
-        // nthreads bins over mean +- 2.5 sigma with sigma^2 ~ |C v0| / (|v0| n), the iteration's own estimate of the
-        // variance along v (no min / max reduction); rows beyond land in the end bins.  The bins only make the
-        // order GOOD; the graph kernel's bound uses each chunk's true t-range.
-        const float sig = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(nrm2) * __builtin_amdgcn_rsqf(n0sq) / (float)n);
-        const float half = 0.5f * (float)nthreads;
-        float f = __builtin_fmaf((t - mean) * (0.4f * half), __builtin_amdgcn_rcpf(sig), half);
+    }
+    __syncthreads();
+    float t = 0.f;
+    int bin, slot = 0;
+    {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const float4 xo = own4[i], v4 = ((const float4 *)dir)[i];
+            t = __builtin_fmaf(xo.x, v4.x, t), t = __builtin_fmaf(xo.y, v4.y, t);
+            t = __builtin_fmaf(xo.z, v4.z, t), t = __builtin_fmaf(xo.w, v4.w, t);
+        }
+        // binned counting sort by t: position = (rows in lower bins) + (arrival order inside the bin)
+        float f = __builtin_fmaf(t - dir[C], dir[C + 1], 0.5f * (float)nthreads);
         f = __builtin_fminf(__builtin_fmaxf(f, 0.f), (float)(nthreads - 1));   // (NaN -> bin 0 through the max)
         bin = (int)f;
         if (live)
@@ -2028,7 +2025,7 @@ int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a
     const bool onepass = a.n > k && a.n <= 8192;
     // (r5) one patch per workgroup, ordered along its principal direction, far chunks skipped: see knn_graph_slab_kernel
     static const bool slab_on = !(getenv("TPU3_KG_SLAB") && atoi(getenv("TPU3_KG_SLAB")) == 0);
-    if (slab_on && onepass && k == 33 && c > 16 && c <= 24 && a.n > 64 && a.n <= 320 && (int)g.x * threads >= a.n
+    if (slab_on && onepass && k == 33 && c == 24 && ((uintptr_t)a.query & 15) == 0 && a.n > 64 && a.n <= 320 && (int)g.x * threads >= a.n
         && threads == ((a.n + 63) / 64) * 64) {
         hipLaunchKernelGGL((knn_slab_order_kernel<24>), g, dim3(threads), 0, s, a);
         hipLaunchKernelGGL((knn_graph_slab_kernel<24, 33>), g, dim3(threads), 0, s, a);

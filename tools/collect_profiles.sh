@@ -27,5 +27,5 @@ pass SQ_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAVES SQ_I
 pass GRBM GRBM_GUI_ACTIVE GRBM_COUNT
 tail -1 $O/bench_default.json | cut -c1-300
 python tools/kstats.py $O/kernel_stats_single_stream.csv 5 16
-grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
+grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|knn_slab\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
 rm -rf gpurun_out/prof

@@ -1,4 +1,4 @@
-"""Derive profiles/r03_traffic.json (read by bench.py) from the PMC passes of tools/collect_profiles.sh.
+"""Derive profiles/rNN_traffic.json (read by bench.py: the newest of r05 / r04 / r03) from the PMC passes of tools/collect_profiles.sh.
 
 usage: python tools/make_traffic_json.py <dir with pmc_*_by_kernel.txt and pmc_*_fm_main.csv> <clouds per launch> [out.json] [commit]
   traffic of the dominant kernel (final FPS: fl_main_kernel, fm_main_kernel until round 2): mean over the bench's launches (the dispatches
@@ -54,7 +54,7 @@ def find(tab, key):
 
 
 others, mfma = {}, {}
-for key in ("dec_fused", "knn_graph_key_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
+for key in ("dec_fused", "knn_graph_key_kernel", "knn_graph_slab_kernel", "knn_slab_order_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
             "linear_lift_kernel", "skip_", "rl_main_kernel", "knn_insert_kernel", "knn_select_kernel", "knn_dup_lds"):
     f, w = find(F, key), find(Wr, key)
     if f and w:

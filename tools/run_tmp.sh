@@ -1,7 +1,6 @@
 mkdir -p gpurun_out/r5
-for cfg in "32 8 4" "48 8 6" "64 8 8" "64 16 4" "96 8 12"; do
-  set -- $cfg
-  echo -n "clouds=$1 net_streams=$2 sub_batch=$3 : "
-  timeout 400 python bench.py --no_cpu_baseline --no_extras --clouds $1 --net_streams $2 --sub_batch $3 --steps 10 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f ms/step  %.3f M pts/s' % (l['ms_per_step'], l['value']/1e6))"
-done > gpurun_out/r5/sweep_clouds.txt 2>&1
-cat gpurun_out/r5/sweep_clouds.txt
+export TMPDIR=/tmp
+(timeout 600 python -m pytest tests/test_hip_kernels.py -q -k "knn_graph" 2>&1 | tail -3; CHECK=1 timeout 300 python tools/knn_slab_probe.py) > gpurun_out/r5/slab_probe3.txt 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof/k -- python /root/repo/tools/knn_slab_probe.py > /dev/null 2>&1)
+python tools/kstats.py $(find gpurun_out/prof/k -name '*kernel_stats.csv' | head -1) 1 4 >> gpurun_out/r5/slab_probe3.txt; rm -rf gpurun_out/prof
+cat gpurun_out/r5/slab_probe3.txt | cut -c1-170
