@@ -574,7 +574,12 @@ class Level(torch.nn.Module):
                     a = operations.BACKEND.linear_wide(x, w[:, :cin], up1.conv.bias)    # (B,N,128), csrc/mlp.hip
                 if a is None:
                     a = torch.nn.functional.linear(x, w[:, :cin], up1.conv.bias)
-            c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])          # (r,128)
+            if code_length == 1:
+                # a 1-d code: W_c code_j is ONE product per entry -- an outer product, bit for bit what the (r,1) x
+                # (1,128) GEMM gives, without a vendor GEMM launch per Level call on the inference path
+                c = code[0].t() * w[:, cin:].t()                                          # (r,1) * (1,128)
+            else:
+                c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])      # (r,128)
             up2, fc1, fc2 = self.up_layer.up_layer2, self.fc_layer1, self.fc_layer2
             be = operations.BACKEND
             if (hasattr(be, "regress_tail") and x.is_cuda and ratio <= 4 and a.size(-1) == 128

@@ -1,6 +1,7 @@
 mkdir -p gpurun_out/r5
-export TMPDIR=/tmp
-(timeout 600 python -m pytest tests/test_hip_kernels.py -q -k "knn_graph" 2>&1 | tail -3; CHECK=1 timeout 300 python tools/knn_slab_probe.py) > gpurun_out/r5/slab_probe3.txt 2>&1
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof/k -- python /root/repo/tools/knn_slab_probe.py > /dev/null 2>&1)
-python tools/kstats.py $(find gpurun_out/prof/k -name '*kernel_stats.csv' | head -1) 1 4 >> gpurun_out/r5/slab_probe3.txt; rm -rf gpurun_out/prof
-cat gpurun_out/r5/slab_probe3.txt | cut -c1-170
+for env in "X=0" "TPU3_DEC_PERSIST=3" "TPU3_DEC_PERSIST=2" "TPU3_DEC_PERSIST=6"; do
+  echo -n "$env : "
+  env $env timeout 300 python bench.py --no_cpu_baseline --no_extras 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f ms/step  %.3f M pts/s' % (l['ms_per_step'], l['value']/1e6))"
+done > gpurun_out/r5/dec_hooks.txt 2>&1
+(timeout 600 python -m pytest tests/test_hip_network.py -q -x -k "regress or level_forward or net_eval or teacher" 2>&1 | tail -3) >> gpurun_out/r5/dec_hooks.txt
+cat gpurun_out/r5/dec_hooks.txt
