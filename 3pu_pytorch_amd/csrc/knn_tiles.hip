@@ -216,30 +216,120 @@ struct KtQueryArgs {
     unsigned *dbg;                   // development probe: waves, tiles searched, tiles tested per query, tiles per set
 };
 
-template <int K>
-__global__ __launch_bounds__(256) void kt_query_kernel(KtQueryArgs a)
+// SORTED (r5): a workgroup per query set of up to KT_QMAX queries (a 312-point patch: five waves).  The queries of a
+// patch arrive in kNN order from its seed, so 64 consecutive ones lie on a RING around the seed and their box covers
+// most of the patch (6.4 of 10 / 9.0 of 20 tiles searched per wave on the pipeline's previous sets).  Here the
+// workgroup first orders its queries by a 9-bit Morton cell of the set's own box (an LDS counting sort, four barriers)
+// and wave w takes sorted positions 64 w ..: a compact blob.  Each result row is written to the query's ORIGINAL
+// position; the search itself -- exact for any grouping of queries into waves -- is unchanged.
+constexpr int KT_QMAX = 512;
+constexpr int KT_QCELLS = 512;
+
+template <int K, bool SORTED>
+__global__ __launch_bounds__(SORTED ? KT_QMAX : 256) void kt_query_kernel(KtQueryArgs a)
 {
-    __shared__ float4 stage[4][KT_TILE];                 // per wave: the tile being searched, (x, y, z, |p|^2) rows
-    __shared__ int32_t srow[4][KT_TILE];                 // ... and its members' row indices
+    constexpr int NWV = SORTED ? KT_QMAX / 64 : 4;
+    __shared__ float4 stage[NWV][KT_TILE];               // per wave: the tile being searched, (x, y, z, |p|^2) rows
+    __shared__ int32_t srow[NWV][KT_TILE];               // ... and its members' row indices
+    __shared__ float4 sq[SORTED ? KT_QMAX : 1];          // SORTED: the queries in Morton order, .w = original position
+    __shared__ int qhist[SORTED ? KT_QCELLS : 1];
+    __shared__ float qred[SORTED ? NWV : 1][6];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wpq = (a.m + 63) >> 6;
-    const long w = (long)blockIdx.x * 4 + wv;
-    if (w >= (long)a.b * wpq)
-        return;
-    const int b = (int)(w / wpq), qi = (int)(w - (long)b * wpq) * 64 + lane;
+    int b, qi;
+    if constexpr (SORTED) {
+        b = blockIdx.x;
+        qi = threadIdx.x;
+    } else {
+        const long w = (long)blockIdx.x * 4 + wv;
+        if (w >= (long)a.b * wpq)
+            return;
+        b = (int)(w / wpq);
+        qi = (int)(w - (long)b * wpq) * 64 + lane;
+    }
     const int pb = a.pts_of ? a.pts_of[b] : b;
     const int m = a.m_arr ? a.m_arr[b] : a.m;
-    const bool live = qi < m;
+    const float inf = __builtin_inff();
+    bool live = qi < m;
+    float q0, q1, q2;
+    {
+        const float *qp = a.query + ((size_t)b * a.m + (live ? qi : 0)) * 3;
+        q0 = live ? qp[0] : 0.f, q1 = live ? qp[1] : 0.f, q2 = live ? qp[2] : 0.f;
+    }
+    if constexpr (SORTED) {
+        const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+        // the set's box
+        {
+            const float l0 = kt_wave_min_f32(live ? q0 : inf), l1 = kt_wave_min_f32(live ? q1 : inf), l2 = kt_wave_min_f32(live ? q2 : inf);
+            const float h0 = tpu3_wave_max_f32(live ? q0 : -inf), h1 = tpu3_wave_max_f32(live ? q1 : -inf);
+            const float h2 = tpu3_wave_max_f32(live ? q2 : -inf);
+            if (lane == 0) {
+                qred[wv][0] = l0; qred[wv][1] = l1; qred[wv][2] = l2;
+                qred[wv][3] = h0; qred[wv][4] = h1; qred[wv][5] = h2;
+            }
+        }
+        for (int i = threadIdx.x; i < KT_QCELLS; i += nthreads)
+            qhist[i] = 0;
+        __syncthreads();
+        float lo[3], sc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float l = qred[0][c], h = qred[0][3 + c];
+            for (int w = 1; w < nwaves; ++w) {
+                l = fminf(l, qred[w][c]);
+                h = fmaxf(h, qred[w][3 + c]);
+            }
+            lo[c] = l;
+            sc[c] = h - l > 0.f ? 8.f / (h - l) : 0.f;
+        }
+        // 3 bits per axis (NaN coordinates fall into cell 0 through the clamps: any order is a valid order)
+        auto bits3 = [](float v) __attribute__((always_inline)) {
+            const int i = (int)fminf(fmaxf(v, 0.f), 7.f);
+            return (uint32_t)((i & 1) | ((i & 2) << 2) | ((i & 4) << 4));
+        };
+        const int cell = (int)(bits3((q0 - lo[0]) * sc[0]) | (bits3((q1 - lo[1]) * sc[1]) << 1) | (bits3((q2 - lo[2]) * sc[2]) << 2));
+        int slot = 0;
+        if (live)
+            slot = atomicAdd(&qhist[cell], 1);
+        __syncthreads();
+        if (wv == 0) {
+            // exclusive offsets of the 512 cells: eight consecutive cells per lane
+            int h[KT_QCELLS / 64], sum = 0;
+#pragma unroll
+            for (int u = 0; u < KT_QCELLS / 64; ++u) {
+                h[u] = qhist[lane * (KT_QCELLS / 64) + u];
+                sum += h[u];
+            }
+            int inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                inc += lane >= d ? o : 0;
+            }
+            int off = inc - sum;
+#pragma unroll
+            for (int u = 0; u < KT_QCELLS / 64; ++u) {
+                qhist[lane * (KT_QCELLS / 64) + u] = off;
+                off += h[u];
+            }
+        }
+        __syncthreads();
+        if (live)
+            sq[qhist[cell] + slot] = make_float4(q0, q1, q2, __int_as_float(qi));
+        __syncthreads();
+        // sorted position threadIdx.x: the live queries fill positions 0 .. m - 1
+        live = (int)threadIdx.x < m;
+        const float4 mine = sq[live ? threadIdx.x : 0];
+        q0 = live ? mine.x : 0.f, q1 = live ? mine.y : 0.f, q2 = live ? mine.z : 0.f;
+        qi = live ? __float_as_int(mine.w) : 0;         // the row the result belongs to
+    }
     if (__ballot(live) == 0)
         return;
     const int nlive = a.n_arr ? a.n_arr[pb] : a.n;
     const bool anydup = a.uws[0] != 0;
     const int count = anydup ? a.cand_count[pb] : nlive;
     const int ntile = (count + KT_TILE - 1) / KT_TILE;
-    const float inf = __builtin_inff();
 
-    const float *qp = a.query + ((size_t)b * a.m + (live ? qi : 0)) * 3;
-    const float q0 = live ? qp[0] : 0.f, q1 = live ? qp[1] : 0.f, q2 = live ? qp[2] : 0.f;
     float rq = __builtin_fmaf(q0, q0, 0.f);
     rq = __builtin_fmaf(q1, q1, rq);
     rq = __builtin_fmaf(q2, q2, rq);
@@ -485,9 +575,20 @@ extern "C" int tpu3_knn_tiles_query_f32(tpu3_stream_t stream, int b, int m, int 
     const long blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return TPU3_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
+    // query sets of 65 .. 512 points (the patches of a Level): a workgroup per set, its queries in Morton order
+    // (TPU3_KNN_TILES_SORT=0: the waves take the queries in the order given, as before round 5)
+    static const bool sort_on = !(getenv("TPU3_KNN_TILES_SORT") && atoi(getenv("TPU3_KNN_TILES_SORT")) == 0);
+    if (sort_on && m > 64 && m <= KT_QMAX && b <= 0x7FFFFFFF) {
+        const int threads = ((m + 63) / 64) * 64;
+        if (k <= 5)
+            hipLaunchKernelGGL((kt_query_kernel<5, true>), dim3((unsigned)b), dim3(threads), 0, s, a);
+        else
+            hipLaunchKernelGGL((kt_query_kernel<8, true>), dim3((unsigned)b), dim3(threads), 0, s, a);
+        return tpu3_launch_status();
+    }
     if (k <= 5)
-        hipLaunchKernelGGL(kt_query_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kt_query_kernel<5, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(kt_query_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kt_query_kernel<8, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return tpu3_launch_status();
 }

@@ -47,13 +47,14 @@ class HipBackend(object):
     name = "hip-gfx950"
 
     COMPACT_MIN_N = 1024      # unique=True: point sets this large get a first-occurrence list
-    # ... and, for 3-d points, k <= 8 and LARGE sets, spatial tiles of it (csrc/knn_tiles.hip): a wave of queries then
-    # searches ~9 tiles of 64 instead of the whole list.  It pays from ~16 k rows (a whole cloud's previous level, as
-    # Net.forward searches it); the batched pipeline's previous sets are ONE outer patch's inner patches (3120 / 6240
-    # rows, 10 - 20 tiles of which a wave needs 6 - 9: measured 1.0 vs 0.4 - 0.65 ms per call) and stay with the
-    # brute-force kernel.  TPU3_KNN_TILES=0: tuning hook
+    # ... and, for 3-d points and k <= 8 (the inter-level search, fm_knn = 5), spatial tiles of it (csrc/knn_tiles.hip):
+    # a wave of queries then searches the few tiles of 64 near it instead of the whole list.  (r5) From 2048 rows on:
+    # since a patch's queries are taken in Morton order (a wave = a compact blob instead of a ring around the seed) the
+    # pruned search also wins on the batched pipeline's previous sets -- ONE outer patch's inner patches, 3120 / 6240
+    # rows, 10 - 20 tiles -- where it lost in round 3 (6 - 9 tiles per wave then).  TPU3_KNN_TILES=0 /
+    # TPU3_KNN_TILES_MIN_N: tuning hooks
     knn_tiles = os.environ.get("TPU3_KNN_TILES", "1") not in ("0", "")
-    KNN_TILES_MIN_N = 16384
+    KNN_TILES_MIN_N = int(os.environ.get("TPU3_KNN_TILES_MIN_N", "2048"))
 
     # Self kNN graphs can run optimistically: only the one-pass kernel, which raises a device-side event when a
     # query saw a second zero distance (rows may be duplicated: the exact path is then required).  OFF by
