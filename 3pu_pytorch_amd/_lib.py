@@ -87,6 +87,11 @@ SIGNATURES = {
                                          _vp, _i, _i, _i]),
     "tpu3_dense_edge_conv_fold_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tpu3_dense_edge_conv_pack_floats": (_sz, [_i]),
+    "tpu3_dense_edge_conv_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tpu3_dense_edge_conv_pk_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i]),
+    "tpu3_dense_edge_conv_fold_pk_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i,
+                                              _i, _vp]),
 }
 
 MFMA_F32, MFMA_F16 = 0, 1        # TPU3_MFMA_* of include/tpu3.h

@@ -75,6 +75,9 @@ struct DecArgs {
     int out_half;                    // `out` is a fp16 buffer (TPU3_STORE_F16; fp16-operand kernel only), stride in halves
     int nosplit = 0;                 // tuning hook TPU3_DEC_SPLIT=0: left-over steps whole, as before round 4
     int patches = 0;                 // lane-per-point kernel: a workgroup walks patches blockIdx.x, + gridDim.x, ...
+    // (r5) the operand tables of the lane-per-point kernel as tpu3_dense_edge_conv_pack_f32 left them (null: the
+    // workgroup builds them from the weights): DEC4_PACK_FLOATS floats + fold_n * 60
+    const float *pack = nullptr;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
@@ -98,6 +101,12 @@ __device__ __forceinline__ float dec_relu(float v)
 // instruction like v_max, and the compiler sees it.
 __device__ __forceinline__ float dec_relu_c(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 __device__ __forceinline__ float dec_max_c(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+
+// (r5) 2 * max(v, 0) as ONE FULL-RATE instruction, v_add_f32 v, v, |v|: exact (v + v for v > 0, v - v = +0 otherwise).
+// v_max / v_med3 are half-rate on gfx950, and on an MFMA result the compiler puts a canonicalising v_max in front
+// of them -- the ReLU of a hidden layer cost two half-rate instructions per value.  The factor 2 is taken out of
+// the weights that multiply the value (0.5 * W is exact, and fma(0.5 W, 2 h, acc) == fma(W, h, acc) bit for bit).
+__device__ __forceinline__ float dec_relu2(float v) { return v + __builtin_fabsf(v); }
 
 // running maximum as ONE v_max_f32 (fmaxf() canonicalises both operands first: three instructions)
 __device__ __forceinline__ float dec_max(float a, float b)
@@ -499,6 +508,18 @@ __global__ __launch_bounds__(DEC_NW * 64) void dec_fused_kernel(DecArgs a)
 // the end (max_j (c + v_j) = c + max_j v_j; the rounding of the sum differs by one ulp from seeding the chain).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DEC4_MAXW = 8;                 // waves per workgroup (at most)
+// -DDEC4_TRACE (tools/dec_trace.py builds its own copy of the library with it): wave w of workgroup g writes the
+// shader clock at mark m to trace[(4 g + w) * 16 + m]; mark 15 = HW_ID.  Not compiled into the product library.
+#ifdef DEC4_TRACE
+__device__ long long *g_dec4_trace;
+#define DEC4_MARK(m)                                                                                            \
+    do {                                                                                                        \
+        if (g_dec4_trace && (threadIdx.x & 63) == 0)                                                            \
+            g_dec4_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (m)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DEC4_MARK(m) do { } while (0)
+#endif
 // LDS tables of A operands, float4 entries [rg][kq][lane & 3] = W[4 rg + i][4 kq .. 4 kq + 3]
 constexpr int DEC4_T_W1A = 0;                // 3 x 3 x 4   W1[:, 0:12]            (h0 -> h1)
 constexpr int DEC4_T_W2 = 36;                // 3 x 6 x 4   W2[:, 0:24]            ([h1 | h0] -> h2)
@@ -509,6 +530,11 @@ constexpr int DEC4_T_Z = 324;                // 3 x 6 x 4   W0[:, 24:48]        
 constexpr int DEC4_T_END = 396;              // float4 entries; then the biases [3][12] (+ 12 pad), then the z table
 constexpr int DEC4_BIAS = DEC4_T_END * 4;    // float offset
 constexpr int DEC4_ZTAB = DEC4_BIAS + 48;    // float offset
+// packed operands (tpu3_dense_edge_conv_pack_f32): [0, DEC4_ZTAB) the tables and biases as they sit in LDS,
+// [DEC4_PACK_WP, + 7 * 64) the packed (halved) edge-layer operands register by register, then the fold table
+constexpr int DEC4_PACK_WP = DEC4_ZTAB;
+constexpr int DEC4_PACK_FOLD = DEC4_PACK_WP + 7 * 64;
+constexpr int DEC4_PACK_FLOATS = DEC4_PACK_FOLD;
 
 __device__ __forceinline__ f32x4 mfma411(float a, float b, f32x4 c)
 {
@@ -568,11 +594,34 @@ constexpr int DEC4_RAW_W0 = 0, DEC4_RAW_W1 = 576, DEC4_RAW_W2 = 1008, DEC4_RAW_B
 __device__ __forceinline__ void dec4_setup(const DecArgs &a, float *lds, float *raw, float (&wp)[7])
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int t = tid; t < DEC4_RAW_FLOATS; t += blockDim.x)
-        raw[t] = t < DEC4_RAW_W1 ? a.w0[t] : t < DEC4_RAW_W2 ? a.w1[t - DEC4_RAW_W1]
-               : t < DEC4_RAW_B ? a.w2[t - DEC4_RAW_W2]
-               : (t < DEC4_RAW_B + 12 ? a.b0 : t < DEC4_RAW_B + 24 ? a.b1 : a.b2)[(t - DEC4_RAW_B) % 12];
+    // (r5) eight loads per thread in flight: the address is selected, then ONE unconditional load (as a loop of
+    // `raw[t] = t < .. ? w0[t] : ..` every element was its own branch + load + wait: seven to nine serial global round
+    // trips, most of the 50 k cycles a workgroup spent before its first MFMA)
+    DEC4_MARK(0);
+    const float *pw0 = a.w0, *pw1 = a.w1, *pw2 = a.w2, *pb0 = a.b0, *pb1 = a.b1, *pb2 = a.b2;
+    // (the six pointers in scalar registers first: selecting among kernel-argument FIELDS per lane made the compiler
+    // fetch the pointer itself with a vector load inside a branch)
+    asm volatile("" : "+s"(pw0), "+s"(pw1), "+s"(pw2), "+s"(pb0), "+s"(pb1), "+s"(pb2));
+    for (int t0 = tid; t0 < DEC4_RAW_FLOATS; t0 += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = min(t0 + i * (int)blockDim.x, DEC4_RAW_FLOATS - 1);
+            const int tb = t - DEC4_RAW_B;
+            const float *bsrc = tb < 12 ? pb0 : tb < 24 ? pb1 : pb2;
+            const float *src = t < DEC4_RAW_W1 ? pw0 + t : t < DEC4_RAW_W2 ? pw1 + (t - DEC4_RAW_W1)
+                             : t < DEC4_RAW_B ? pw2 + (t - DEC4_RAW_W2) : bsrc + (tb < 12 ? tb : tb < 24 ? tb - 12 : tb - 24);
+            v[i] = *src;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + i * (int)blockDim.x;
+            if (t < DEC4_RAW_FLOATS)
+                raw[t] = v[i];
+        }
+    }
     __syncthreads();
+    DEC4_MARK(1);
     const float *w0 = raw + DEC4_RAW_W0, *w1 = raw + DEC4_RAW_W1, *w2 = raw + DEC4_RAW_W2;
     // table entry e = (rg, kq, i): row 4 rg + i, columns 4 kq .. 4 kq + 3 of the table's matrix slice
     for (int e = tid; e < DEC4_T_END; e += blockDim.x) {
@@ -599,7 +648,8 @@ __device__ __forceinline__ void dec4_setup(const DecArgs &a, float *lds, float *
     }
     if (tid < 48)
         lds[DEC4_BIAS + tid] = tid < 36 ? raw[DEC4_RAW_B + tid] : 0.f;
-    // packed A operands of the two edge layers: operand q < 36: (rg, k) = (q / 12, q % 12) of W1[:, 0:12];
+    // packed A operands of the two edge layers, HALVED (their inputs h0, h1 are kept as 2 * relu): operand q < 36:
+    // (rg, k) = (q / 12, q % 12) of W1[:, 0:12];
     // 36 <= q < 108: (rg, k) = ((q - 36) / 24, (q - 36) % 24) of W2[:, 0:24]; lane 4b + i of register v holds
     // operand q = 16 v + b for row 4 rg + i
 #pragma unroll
@@ -610,9 +660,53 @@ __device__ __forceinline__ void dec4_setup(const DecArgs &a, float *lds, float *
             w = w1[(4 * (q / 12) + i) * 36 + q % 12];
         else if (q < 108)
             w = w2[(4 * ((q - 36) / 24) + i) * 48 + (q - 36) % 24];
-        wp[v] = w;
+        wp[v] = 0.5f * w;       // the edge layers see 2 * relu (dec_relu2)
     }
     __syncthreads();            // `raw` may be overwritten from here on
+    DEC4_MARK(2);
+}
+
+// (FOLD) A operands of the folded prep convolutions: float4 entries
+// [chunk of 24 outputs][row group 6][kq 15][i 4] = fold_w[24 chunk + 4 rg + i][4 kq .. 4 kq + 3]
+__device__ __forceinline__ void dec4_fold_table(const DecArgs &a, f32x4 *ftab)
+{
+    const int tid = threadIdx.x;
+    // (r5: the loads of a thread in flight together, as in dec4_setup)
+    const int fe = a.fold_n * 15;
+    for (int e0 = tid; e0 < fe; e0 += 5 * blockDim.x) {
+        f32x4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = min(e0 + q * (int)blockDim.x, fe - 1);
+            const int i = e & 3, kq = (e >> 2) % 15, rgc = (e >> 2) / 15;      // rgc = 6 chunk + rg
+            v[q] = *(const f32x4 *)(a.fold_w + (size_t)(4 * rgc + i) * 60 + 4 * kq);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = e0 + q * (int)blockDim.x;
+            if (e < fe)
+                ftab[e] = v[q];
+        }
+    }
+    // (visible after the barrier behind phase A)
+}
+
+// The tables of one set of weights written out once: what dec4_setup / dec4_fold_table leave in LDS and in the wp
+// registers, in the layout DEC4_PACK_* (one workgroup of 256 threads; the launches that pass the blob copy it).
+__global__ __launch_bounds__(256) void dec4_pack_kernel(DecArgs a, float *blob)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DEC4_ZTAB + DEC4_RAW_FLOATS + 4];
+    float wp[7];
+    dec4_setup(a, lds, lds + DEC4_ZTAB, wp);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DEC4_ZTAB; e += blockDim.x)
+        blob[e] = lds[e];
+    if (tid < 64)
+#pragma unroll
+        for (int v = 0; v < 7; ++v)
+            blob[DEC4_PACK_WP + 64 * v + tid] = wp[v];
+    if (a.fold_n)
+        dec4_fold_table(a, (f32x4 *)(blob + DEC4_PACK_FOLD));
 }
 
 // U = neighbour slots per loop iteration.  U = 2 folds two slots into one v_max3 per channel (18 instead of 36
@@ -633,13 +727,50 @@ void dec_fused4_kernel(DecArgs a)
     f32x4 *ftab = (f32x4 *)(zl + (size_t)n * DEC_ZS + 4);
 
     float wp[7];
-    dec4_setup(a, lds, zl, wp);
-    if constexpr (FOLD) {
-        for (int e = tid; e < a.fold_n * 15; e += blockDim.x) {
-            const int i = e & 3, kq = (e >> 2) % 15, rgc = (e >> 2) / 15;          // rgc = 6 chunk + rg
-            ftab[e] = *(const f32x4 *)(a.fold_w + (size_t)(4 * rgc + i) * 60 + 4 * kq);
+    if (a.pack) {
+        // (r5) the tables as a per-weights blob: a straight copy, every load of a thread in flight, one barrier.
+        // Built in place (dec4_setup) the set-up is ~1500 integer / LDS instructions per wave, each of which waits its
+        // turn behind the MFMAs of the two other workgroups of the compute unit: 35 - 45 k of a wave's 180 k cycles.
+        DEC4_MARK(0);
+        const f32x4 *src = (const f32x4 *)a.pack;
+        constexpr int TE = DEC4_ZTAB / 4;                     // 408 float4: tables + biases
+        {
+            f32x4 v[2];
+            for (int e0 = tid; e0 < TE; e0 += 2 * blockDim.x) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    v[q] = src[min(e0 + q * (int)blockDim.x, TE - 1)];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (e0 + q * (int)blockDim.x < TE)
+                        tab[e0 + q * (int)blockDim.x] = v[q];
+            }
         }
+#pragma unroll
+        for (int v = 0; v < 7; ++v)
+            wp[v] = a.pack[DEC4_PACK_WP + 64 * v + lane];
+        __syncthreads();
+        DEC4_MARK(1);
+        if constexpr (FOLD) {
+            const f32x4 *fsrc = (const f32x4 *)(a.pack + DEC4_PACK_FOLD);
+            const int fe = a.fold_n * 15;
+            for (int e0 = tid; e0 < fe; e0 += 5 * blockDim.x) {
+                f32x4 v[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    v[q] = fsrc[min(e0 + q * (int)blockDim.x, fe - 1)];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    if (e0 + q * (int)blockDim.x < fe)
+                        ftab[e0 + q * (int)blockDim.x] = v[q];
+            }
+        }
+        DEC4_MARK(2);
         // (visible after the barrier behind phase A)
+    } else {
+        dec4_setup(a, lds, zl, wp);
+        if constexpr (FOLD)
+            dec4_fold_table(a, ftab);
     }
     const int nstep = (n + 63) >> 6;
     // (r4) steps left over by the round-robin deal (nstep mod 4 = 1 or 2) are split by neighbour slots over 4 or 2
@@ -676,24 +807,34 @@ void dec_fused4_kernel(DecArgs a)
     };
 
     // neighbour slots [s0, s1) of the lane's point folded into the running maxima; index and z row of the following
-    // slots are requested before an iteration's MFMAs
+    // slots are requested before an iteration's MFMAs.  h0 and h1 are kept as TWICE their ReLU (dec_relu2; the packed
+    // weights are halved), so m0 and m1 come out doubled: `finish` halves them.
     auto slots = [&](int pc, int s0, int s1, const f32x4 (&c0)[3], const f32x4 (&c1)[3], f32x4 (&m0)[3], f32x4 (&m1)[3],
                      f32x4 (&m2)[3]) __attribute__((always_inline)) {
         const size_t ibase = (prow + pc) * a.idx_stride + a.idx_off;
-        auto nbr = [&](int sl) __attribute__((always_inline)) {    // byte offset of the neighbour's z row
-            const int j = IDX64 ? (int)((const long long *)a.idx)[ibase + sl] : ((const int *)a.idx)[ibase + sl];
+        auto ldidx = [&](int sl) __attribute__((always_inline)) {  // the raw neighbour index of slot sl
+            return IDX64 ? (int)((const long long *)a.idx)[ibase + sl] : ((const int *)a.idx)[ibase + sl];
+        };
+        auto zoff = [&](int j) __attribute__((always_inline)) {    // byte offset of the neighbour's z row
             return min(max(j * (int)(DEC_ZS * sizeof(float)), 0), zmax);
         };
 #pragma unroll
         for (int rg = 0; rg < 3; ++rg)
             m0[rg] = m1[rg] = m2[rg] = (f32x4){ninf, ninf, ninf, ninf};
-        int jn[U];
+        // (r5) the pipeline of an iteration: [h0 from the z rows requested at the end of the previous one] [layer 1] [layer 2]
+        // [index loaded an iteration ago -> z rows of the next iteration requested, the index after that loaded] [maxima].
+        // (Written as "use z, request the next z" at the top of the loop, the compiler merged the request into the use --
+        // a phi of two loads is a load of the phi -- and every iteration began with an LDS round trip and ended with a
+        // global one, both waited for on the spot: a lone wave took 25 % longer than its instructions.  The empty asm
+        // with a memory clobber behind the requests keeps them where they are; requested before the MFMAs, as the source
+        // once read, the 24 registers of the rows cost a wave of occupancy.)
+        int jr[U];
         f32x4 zn[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f32x4 *zr = (const f32x4 *)(zb + nbr(min(s0 + u, s1 - 1)));
+            const f32x4 *zr = (const f32x4 *)(zb + zoff(ldidx(min(s0 + u, s1 - 1))));
             zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
-            jn[u] = nbr(min(s0 + U + u, s1 - 1));
+            jr[u] = ldidx(min(s0 + U + u, s1 - 1));
         }
 #pragma unroll 1
         for (int sl = s0; sl < s1; sl += U) {
@@ -705,15 +846,8 @@ void dec_fused4_kernel(DecArgs a)
                     const f32x4 pre = c0[rg] + zn[u][rg];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h0[u][rg][r] = dec_relu_c(pre[r]);
+                        h0[u][rg][r] = dec_relu2(pre[r]);
                 }
-            // requests for the following iteration (clamped at the end: a repeated slot is harmless)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const f32x4 *zr = (const f32x4 *)(zb + jn[u]);
-                zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
-                jn[u] = nbr(min(sl + 2 * U + u, s1 - 1));
-            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -736,7 +870,7 @@ void dec_fused4_kernel(DecArgs a)
                 for (int rg = 0; rg < 3; ++rg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        h1[u][rg][r] = dec_relu_c(h1[u][rg][r]);
+                        h1[u][rg][r] = dec_relu2(h1[u][rg][r]);
                     h2[u][rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             // layer 2: [h1 | h0]
@@ -750,6 +884,14 @@ void dec_fused4_kernel(DecArgs a)
                     h2[u][2] = mfma411_bc<36 + 2 * 24 + kk>(wp, b, h2[u][2]);
                 }
             });
+            // requests for the following iterations (clamped at the end: a repeated slot is harmless)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 *zr = (const f32x4 *)(zb + zoff(jr[u]));
+                zn[u][0] = zr[0]; zn[u][1] = zr[1]; zn[u][2] = zr[2];
+                jr[u] = ldidx(min(sl + 2 * U + u, s1 - 1));
+            }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
@@ -786,8 +928,11 @@ void dec_fused4_kernel(DecArgs a)
                 c2[rg] = *(const f32x4 *)(bias + 24 + 4 * rg);
             dec4_mm24(tabs + DEC4_T_C2, li, x, c2);
 #pragma unroll
-            for (int rg = 0; rg < 3; ++rg)
+            for (int rg = 0; rg < 3; ++rg) {
                 m2[rg] = m2[rg] + c2[rg];
+                m1[rg] = m1[rg] * 0.5f;         // maxima of 2 * relu (exact)
+                m0[rg] = m0[rg] * 0.5f;
+            }
         }
         if (rows && p < n) {
             f32x4 *orow = (f32x4 *)(O + (size_t)p * a.out_stride);
@@ -860,12 +1005,13 @@ void dec_fused4_kernel(DecArgs a)
         O = a.out + (size_t)patch * n * a.out_stride;
         prow = (size_t)patch * n;
         if (split > 1)
-            for (int e = tid; e < rem * 36 * 64; e += blockDim.x)
-                comb[e] = ninf;
+            for (int e = tid; e < rem * 36 * 16; e += blockDim.x)
+                ((f32x4 *)comb)[e] = (f32x4){ninf, ninf, ninf, ninf};
         // Which wave takes an extra step (no split: TPU3_DEC_SPLIT=0, or three left-over steps) rotates with the
         // patch: wave w of every workgroup sits on SIMD w -- with the long wave always on SIMD 0 that SIMD alone would
         // bound the compute unit.
         vw = __builtin_amdgcn_readfirstlane((wave + patch) % nwave);
+        DEC4_MARK(3);
         // ---- phase A, per point (lane = point): the z table into LDS, the x_i part of the output row straight from
         // the registers.  (Keeping the first step's rows for phase B made all 24 registers live across the slot loop
         // once the code around it grew: phase B reads its rows again.)  (r4: the slot-independent part of the last layer, c2_p = W2c x_p + b2, used
@@ -896,7 +1042,9 @@ void dec_fused4_kernel(DecArgs a)
                 }
             }
         }
+        DEC4_MARK(4);
         __syncthreads();
+        DEC4_MARK(5);
 
         // whole steps, dealt round-robin
         const int nwhole = split > 1 ? nstep - rem : nstep;
@@ -910,8 +1058,11 @@ void dec_fused4_kernel(DecArgs a)
             const int pc = min(p, n - 1);
             f32x4 c0[3], c1[3], m0[3], m1[3], m2[3];
             centre(tabs, st, pc, c0, c1);
+            DEC4_MARK(6);
             slots(pc, 0, k, c0, c1, m0, m1, m2);
+            DEC4_MARK(7);
             finish(tabs, tofs, p, pc, m0, m1, m2, true, 0, 1);
+            DEC4_MARK(8);
         }
         if (split > 1) {
             // ---- (r4) the steps left over (a 312-point patch: the fifth of five on four waves), split by SLOTS: wave
@@ -943,7 +1094,9 @@ void dec_fused4_kernel(DecArgs a)
                         dec4_lds_max(cb + (24 + 4 * rg + r) * 64, m0[rg][r]);
                     }
             }
+            DEC4_MARK(9);
             __syncthreads();
+            DEC4_MARK(10);
             const bool rows = q == split - 1;
             if (rows || (FOLD && q < a.fold_n / 24)) {
                 f32x4 m0[3], m1[3], m2[3];
@@ -958,6 +1111,15 @@ void dec_fused4_kernel(DecArgs a)
                 finish(tabs, tofs, p, pc, m0, m1, m2, rows, q, split);
             }
         }
+        DEC4_MARK(11);
+#ifdef DEC4_TRACE
+        if (g_dec4_trace && lane == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_dec4_trace[((size_t)blockIdx.x * 4 + wave) * 16 + 15] = hw;
+            g_dec4_trace[((size_t)blockIdx.x * 4 + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         // (the z table and `comb` are rewritten for the next patch)
         if (patch + (int)gridDim.x < a.patches)
             __syncthreads();
@@ -1046,6 +1208,13 @@ int dec_launch(hipStream_t s, int patches, DecArgs &a)
 
 } // namespace
 
+#ifdef DEC4_TRACE
+extern "C" int tpu3_debug_dec_trace(long long *buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec4_trace), &buf, sizeof(buf));
+}
+#endif
+
 extern "C" int tpu3_debug_dec_split(int on)
 {
     const int old = g_dec_nosplit ? 0 : 1;
@@ -1100,6 +1269,70 @@ extern "C" int tpu3_dense_edge_conv_f32(tpu3_stream_t stream, int patches, int n
     if (form == 4 && dec4_lds_bytes(n) <= 160 * 1024)
         return dec4_launch(s, patches, a);
     return dec_launch<false>(s, patches, a);
+}
+
+extern "C" size_t tpu3_dense_edge_conv_pack_floats(int fold_n)
+{
+    return (fold_n == 0 || fold_n == 24 || fold_n == 48 || fold_n == 72) ? (size_t)DEC4_PACK_FLOATS + (size_t)fold_n * 60 : 0;
+}
+
+extern "C" int tpu3_dense_edge_conv_pack_f32(tpu3_stream_t stream, const float *w0, const float *b0, const float *w1,
+                                             const float *b1, const float *w2, const float *b2, int fold_n,
+                                             const float *fold_w, float *pack)
+{
+    if (fold_n != 0 && fold_n != 24 && fold_n != 48 && fold_n != 72) return TPU3_EINVAL;
+    if (!w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !pack || (fold_n && !fold_w)) return TPU3_EINVAL;
+    if ((((uintptr_t)pack | (uintptr_t)fold_w) & 15) != 0) return TPU3_EINVAL;
+    DecArgs a{};
+    a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.fold_n = fold_n;
+    a.fold_w = fold_w;
+    hipLaunchKernelGGL(dec4_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, pack);
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_dense_edge_conv_pk_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                           const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                           const float *pack, float *out, int out_stride)
+{
+    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
+    if (patches == 0) return TPU3_OK;
+    if (!x || !idx || !pack || !out) return TPU3_EINVAL;
+    if ((((uintptr_t)out | (uintptr_t)x | (uintptr_t)pack) & 15) != 0) return TPU3_EINVAL;
+    if (patches > 2147483647 / n) return TPU3_ELIMIT;
+    if (dec4_lds_bytes(n) > 160 * 1024) return TPU3_ELIMIT;                // (callers then pass the weights)
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, nullptr, nullptr, nullptr, nullptr, nullptr,
+              nullptr, out, out_stride, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0};
+    a.pack = pack;
+    return dec4_launch((hipStream_t)stream, patches, a);
+}
+
+extern "C" int tpu3_dense_edge_conv_fold_pk_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                                const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                                const float *pack, float *out, int out_stride, int fold_n,
+                                                const float *fold_b, float *acc, int acc_stride, int seed_off,
+                                                int store_off, float *xnext)
+{
+    if (patches < 0 || n <= 0 || k <= 0 || (k % 16) != 0 || k > 64) return TPU3_EINVAL;
+    if (idx_elem_size != 4 && idx_elem_size != 8) return TPU3_EINVAL;
+    if (idx_off < 0 || idx_stride < idx_off + k || out_stride < 60 || (out_stride % 4) != 0) return TPU3_EINVAL;
+    if (fold_n != 24 && fold_n != 48 && fold_n != 72) return TPU3_EINVAL;
+    if (seed_off < 0 || store_off < 0 || (acc_stride % 4) || (seed_off % 4) || (store_off % 4)) return TPU3_EINVAL;
+    if (!fold_b && acc_stride < seed_off + fold_n) return TPU3_EINVAL;
+    if (fold_n > 24 && acc_stride < store_off + fold_n - 24) return TPU3_EINVAL;
+    if (patches == 0) return TPU3_OK;
+    if (!x || !idx || !pack || !out || !xnext) return TPU3_EINVAL;
+    if ((fold_n > 24 || !fold_b) && !acc) return TPU3_EINVAL;
+    if ((((uintptr_t)out | (uintptr_t)x | (uintptr_t)pack | (uintptr_t)fold_b | (uintptr_t)acc | (uintptr_t)xnext) & 15) != 0)
+        return TPU3_EINVAL;
+    if (patches > 2147483647 / n) return TPU3_ELIMIT;
+    if (dec4_lds_bytes(n, fold_n) > 160 * 1024) return TPU3_ELIMIT;
+    DecArgs a{n, k, x, idx, idx_elem_size == 8, idx_stride, idx_off, nullptr, nullptr, nullptr, nullptr, nullptr,
+              nullptr, out, out_stride, nullptr, fold_n, nullptr, fold_b, acc, acc_stride, seed_off, store_off, xnext, 0};
+    a.pack = pack;
+    return dec4_launch((hipStream_t)stream, patches, a);
 }
 
 extern "C" int tpu3_dense_edge_conv_fold_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,

@@ -314,6 +314,34 @@ class DenseEdgeConv(nn.Module):
                                                   want_dist=False, want_grouped=False)
         return None, full.long()[:, :, 1:]
 
+    def _operand_pack(self, fold_w=None):
+        """The fused fp32 kernel's operand tables for this block's CURRENT weights (and for `fold_w`, the folded prep
+        convolutions' columns), HipBackend.dense_edge_conv_pack, cached until a weight changes (version counters and
+        addresses, as Level._fold_plan).  The blob is built by a launch on one stream; a call on another stream orders
+        itself behind that launch.  None when the backend has no packed launch."""
+        if not hasattr(operations.BACKEND, "dense_edge_conv_pack"):
+            return None
+        ps = [t for conv in self.mlps for t in (conv.weight, conv.bias)]
+        if not ps[0].is_cuda:
+            return None
+        key = tuple(t._version for t in ps) + tuple(t.data_ptr() for t in ps) + \
+            ((fold_w.data_ptr(), fold_w._version, fold_w.size(0)) if fold_w is not None else (0, 0, 0))
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        slot = 0 if fold_w is None else fold_w.size(0)
+        here = torch.cuda.current_stream(ps[0].device)
+        hit = cache.get(slot)
+        if hit is not None and hit[0] == key:
+            if hit[2] != here.cuda_stream:
+                here.wait_event(hit[3])
+                hit[1].record_stream(here)
+            return hit[1]
+        with torch.no_grad():
+            blob = operations.BACKEND.dense_edge_conv_pack(self.mlps, fold_w)
+        done = torch.cuda.Event()
+        done.record(here)
+        cache[slot] = (key, blob, here.cuda_stream, done)
+        return blob
+
     def forward_cl(self, x, idx=None, layout=None, out=None, fold=None):
         """x (B,N,C) channel-last -> y (B,N,C + n*growth_rate), idx (B,N,k).
         `out`: optional (B,N,C + n*growth_rate) view (unit channel stride) that receives y -- the
@@ -335,15 +363,18 @@ class DenseEdgeConv(nn.Module):
                                                       want_dist=False, want_grouped=False)
             if out is None:
                 out = x.new_empty((B, N, C + n * g))
+            packable = self.mlp_precision == "f32" and (C, g, n) == (24, 12, 3) and out.dtype == torch.float32
             if (fold is not None and self.mlp_precision == "f32" and (C, g, n) == (24, 12, 3)
                     and hasattr(operations.BACKEND, "dense_edge_conv_fold")):
                 fold["done"] = operations.BACKEND.dense_edge_conv_fold(
                     x, full_idx, 1, k, self.mlps, out, fold["w"], fold.get("b"), fold.get("acc"),
-                    fold.get("seed_off", 0), fold.get("store_off", 0), fold["xnext"])
+                    fold.get("seed_off", 0), fold.get("store_off", 0), fold["xnext"],
+                    pack=self._operand_pack(fold["w"]) if packable else None)
                 if fold["done"]:
                     return out, full_idx[:, :, 1:]
             operations.BACKEND.dense_edge_conv(x, full_idx, 1, k, self.mlps, out,
-                                               mfma=L.MFMA_F16 if self.mlp_precision == "f16" else L.MFMA_F32)
+                                               mfma=L.MFMA_F16 if self.mlp_precision == "f16" else L.MFMA_F32,
+                                               pack=self._operand_pack() if packable else None)
             return out, full_idx[:, :, 1:]
         if self.mlp_precision != "f32":
             raise RuntimeError("mlp_precision=%r needs the fused DenseEdgeConv kernel, which does not cover this "

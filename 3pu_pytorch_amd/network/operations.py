@@ -292,7 +292,31 @@ class HipBackend(object):
         grad = torch.zeros((b, c, n), dtype=grad_out.dtype, device=grad_out.device)
         return sampling.gather_backward(b, c, n, npoint, grad_out, idx, grad)
 
-    def dense_edge_conv(self, x, idx, idx_off, k, mlps, out, mfma=L.MFMA_F32):
+    def dense_edge_conv_pack(self, mlps, fold_w=None):
+        """The block's operand tables (and those of the folded prep convolutions) written out once,
+        tpu3_dense_edge_conv_pack_f32: a float32 blob the *_pk_* launches copy instead of building the tables in
+        every workgroup.  The caller keeps it for as long as the weights are unchanged."""
+        w = []
+        for conv in mlps:
+            w.append(conv.weight.detach().reshape(conv.weight.size(0), -1).contiguous())
+            w.append(conv.bias.detach().contiguous())
+        for t in w:
+            L.require_device(t, "weights")
+            L.require_dtype(t, torch.float32, "weights")
+        fold_n = 0 if fold_w is None else fold_w.size(0)
+        if fold_w is not None:
+            fold_w = fold_w.contiguous()
+        nf = L.lib().tpu3_dense_edge_conv_pack_floats(fold_n)
+        if nf == 0:
+            raise RuntimeError("dense_edge_conv_pack: fold_n must be 0, 24, 48 or 72")
+        blob = torch.empty((nf,), device=w[0].device, dtype=torch.float32)
+        with torch.cuda.device(w[0].device):
+            L.check(L.lib().tpu3_dense_edge_conv_pack_f32(
+                L.stream_of(w[0]), L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
+                fold_n, L.ptr(fold_w), L.ptr(blob)), "tpu3_dense_edge_conv_pack_f32")
+        return blob
+
+    def dense_edge_conv(self, x, idx, idx_off, k, mlps, out, mfma=L.MFMA_F32, pack=None):
         """Fused DenseEdgeConv (inference): x (P,N,24) contiguous, idx (P,N,idx_stride) int64/int32,
         the k neighbours start at column idx_off; mlps = the block's three nn.Conv2d; `out` is a
         (P,N,>=60) view with unit channel stride whose channels [0,60) receive y.
@@ -315,13 +339,22 @@ class HipBackend(object):
                     L.ptr(out), out.stride(1), int(mfma), L.STORE_F16), "tpu3_dense_edge_conv_st_f32")
                 return out
             L.require_dtype(out, torch.float32, "out")
+            if pack is not None and mfma == L.MFMA_F32:
+                # packed operands (dense_edge_conv_pack): same launch, same bits, no table set-up per workgroup
+                rc = L.lib().tpu3_dense_edge_conv_pk_f32(
+                    L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
+                    L.ptr(pack), L.ptr(out), out.stride(1))
+                if rc != L.ELIMIT:                  # (patches beyond the lane-per-point kernel take the weights)
+                    L.check(rc, "tpu3_dense_edge_conv_pk_f32")
+                    return out
             L.check(L.lib().tpu3_dense_edge_conv_f32(
                 L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
                 L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), L.ptr(w[3]), L.ptr(w[4]), L.ptr(w[5]),
                 L.ptr(out), out.stride(1), int(mfma)), "tpu3_dense_edge_conv_f32")
         return out
 
-    def dense_edge_conv_fold(self, x, idx, idx_off, k, mlps, out, fold_w, fold_b, acc, seed_off, store_off, xnext):
+    def dense_edge_conv_fold(self, x, idx, idx_off, k, mlps, out, fold_w, fold_b, acc, seed_off, store_off, xnext,
+                             pack=None):
         """dense_edge_conv (fp32) + the next prep convolutions folded into the write-out, see
         tpu3_dense_edge_conv_fold_f32: fold_w (fold_n, 60), fold_b (fold_n) or None (sums continue from
         acc[..., seed_off:]), acc (P,N,S) or None, xnext (P,N,24) receives the next block's input rows.
@@ -335,6 +368,16 @@ class HipBackend(object):
         for conv in mlps:
             w.append(conv.weight.detach().reshape(conv.weight.size(0), -1).contiguous())
             w.append(conv.bias.detach().contiguous())
+        if pack is not None:        # packed operands of the block AND of fold_w (dense_edge_conv_pack(mlps, fold_w))
+            with torch.cuda.device(x.device):
+                rc = L.lib().tpu3_dense_edge_conv_fold_pk_f32(
+                    L.stream_of(x), P, N, k, L.ptr(x), L.ptr(idx), idx.element_size(), idx.size(2), idx_off,
+                    L.ptr(pack), L.ptr(out), out.stride(1), fold_w.size(0), L.ptr(fold_b), L.ptr(acc),
+                    0 if acc is None else acc.stride(1), seed_off, store_off, L.ptr(xnext))
+            if rc == L.ELIMIT:
+                return False
+            L.check(rc, "tpu3_dense_edge_conv_fold_pk_f32")
+            return True
         fold_w = fold_w.contiguous()
         with torch.cuda.device(x.device):
             rc = L.lib().tpu3_dense_edge_conv_fold_f32(

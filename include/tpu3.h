@@ -285,6 +285,27 @@ int tpu3_dense_edge_conv_fold_f32(tpu3_stream_t stream, int patches, int n, int 
                                   const float *fold_w, const float *fold_b, float *acc, int acc_stride,
                                   int seed_off, int store_off, float *xnext);
 
+/* (r5) The same two launches with the weights PACKED once per set of weights instead of re-arranged by every
+ * workgroup of every launch.  The lane-per-point kernel keeps its A operands in LDS tables and seven registers; built
+ * in place that is ~1500 integer / LDS instructions per wave which, on a compute unit whose other workgroups are
+ * inside their MFMA loops, take 35 - 45 k cycles of a wave's 180 k.  tpu3_dense_edge_conv_pack_f32 (one small launch)
+ * writes them to `pack` (tpu3_dense_edge_conv_pack_floats(fold_n) floats, 16-byte aligned; fold_n = 0 for a block
+ * without folded prep convolutions); the *_pk_* launches copy the blob and are otherwise the calls above, bit for
+ * bit (fp32 lane-per-point form only: TPU3_ELIMIT when the patch's tables do not fit LDS -- pass the weights then).
+ * The caller rebuilds the blob when a weight changes. */
+size_t tpu3_dense_edge_conv_pack_floats(int fold_n);
+int tpu3_dense_edge_conv_pack_f32(tpu3_stream_t stream, const float *w0, const float *b0, const float *w1,
+                                  const float *b1, const float *w2, const float *b2, int fold_n,
+                                  const float *fold_w, float *pack);
+int tpu3_dense_edge_conv_pk_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                const float *pack, float *out, int out_stride);
+int tpu3_dense_edge_conv_fold_pk_f32(tpu3_stream_t stream, int patches, int n, int k, const float *x,
+                                     const void *idx, int idx_elem_size, int idx_stride, int idx_off,
+                                     const float *pack, float *out, int out_stride, int fold_n,
+                                     const float *fold_b, float *acc, int acc_stride, int seed_off,
+                                     int store_off, float *xnext);
+
 /* Fused inter-level skip connection of a Level, inference (network/upsampler.py:317-347):
  *   w_k = exp(-|p_i - q_k|^2 / (h_s/2)) * exp(-|x_i - f_k|^2 / (h_f/2)),  h = mean_i min_k (dist),
  *   w_k /= sum_k (w_k + 1e-5),  x_i += scale * sum_k w_k f_k          (scale = 0.2 in the reference)

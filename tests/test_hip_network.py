@@ -830,6 +830,54 @@ def test_dense_edge_conv_split_steps_give_the_same_bits(dev, P, N, k, fold):
     assert float(a[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize("P,N,k", [(7, 312, 32), (3, 330, 16), (2, 64, 32), (1, 1000, 48)])
+@pytest.mark.parametrize("fold_n", [0, 24, 72])
+def test_dense_edge_conv_packed_operands_give_the_same_bits(dev, P, N, k, fold_n):
+    """tpu3_dense_edge_conv_pack_f32 + the *_pk_* launches (operand tables written once per set of weights, copied by
+    every workgroup) against the launches that build the tables from the weights: bit-identical rows."""
+    layers, ops = pkg("network.layers"), pkg("network.operations")
+    blk = _dec_block(layers, dev, k, 5 * P + N)
+    g = torch.Generator(device=dev).manual_seed(N + k + fold_n)
+    x = torch.randn(P, N, 24, device=dev, generator=g)
+    idx = torch.randint(0, N, (P, N, k + 1), device=dev, dtype=torch.int32, generator=g)
+    fw = torch.randn(max(fold_n, 24), 60, device=dev, generator=g) * 0.1
+    fb = torch.randn(max(fold_n, 24), device=dev, generator=g)
+
+    def run(pack):
+        out = torch.zeros((P, N, 60), device=dev)
+        if not fold_n:
+            ops.BACKEND.dense_edge_conv(x, idx, 1, k, blk.mlps, out, pack=pack)
+            return (out,)
+        acc, xnext = torch.zeros((P, N, 48), device=dev), torch.zeros((P, N, 24), device=dev)
+        assert ops.BACKEND.dense_edge_conv_fold(x, idx, 1, k, blk.mlps, out, fw, fb, acc, 0, 0, xnext, pack=pack)
+        return out, acc, xnext
+
+    with torch.no_grad():
+        pack = ops.BACKEND.dense_edge_conv_pack(blk.mlps, fw if fold_n else None)
+        a, b = run(None), run(pack)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert float(a[0].abs().max()) > 0
+
+
+def test_dense_edge_conv_module_repacks_when_a_weight_changes(dev):
+    """DenseEdgeConv keeps the packed operands of its current weights: an in-place weight update must show in the next
+    forward (version counters), and the cached blob must be reused while nothing changes."""
+    layers = pkg("network.layers")
+    blk = _dec_block(layers, dev, 16, 3)
+    x = torch.randn(2, 312, 24, device=dev)
+    with torch.no_grad():
+        y0, _ = blk.forward_cl(x)
+        p0 = blk._pack_cache[0][1]
+        y1, _ = blk.forward_cl(x)
+        assert blk._pack_cache[0][1] is p0 and torch.equal(y0, y1)
+        blk.mlps[2].bias.add_(1.0)
+        y2, _ = blk.forward_cl(x)
+        assert blk._pack_cache[0][1] is not p0
+    assert torch.allclose(y2[..., :12], y0[..., :12] + 1.0, atol=1e-5)
+    assert torch.equal(y2[..., 12:], y0[..., 12:])
+
+
 @pytest.mark.parametrize("P,N,k", [(4, 312, 32), (3, 1024, 32), (1, 3000, 16)])
 def test_dense_edge_conv_fp16_mfma_within_derived_bound(dev, P, N, k):
     """mlp_precision = "f16" (config C5: fp16 operands on the matrix cores, fp32 accumulate) on the same neighbour
