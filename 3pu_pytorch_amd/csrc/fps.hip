@@ -128,7 +128,7 @@ __global__ __launch_bounds__(W) void fps_resident_kernel(FpsArgs a)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const float d = tpu3_sqdist3(px[j] - x1, py[j] - y1, pz[j] - z1);
-            const float d2 = fminf(d, pt[j]);
+            const float d2 = tpu3_min1(d, pt[j]);
             pt[j] = d2;
             if (d2 > best) {
                 best = d2;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(W) void fps_stream_kernel(FpsArgs a)
         for (int k = t; k < n; k += W) {
             const float td = T[k];
             const float d = tpu3_sqdist3(P[k * 3 + 0] - x1, P[k * 3 + 1] - y1, P[k * 3 + 2] - z1);
-            const float d2 = fminf(d, td);
+            const float d2 = tpu3_min1(d, td);
             if (d2 != td)
                 T[k] = d2;
             if (d2 > best) {

@@ -197,7 +197,7 @@ __device__ __forceinline__ FbCand fm_apply(FbBucket<PPL> &b, uint32_t pmask, flo
         const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), i));
 #pragma unroll
         for (int p = 0; p < PPL; ++p)
-            t[p] = fminf(tpu3_sqdist3(b.v[p].x - qx, b.v[p].y - qy, b.v[p].z - qz), t[p]);
+            t[p] = tpu3_min1(tpu3_sqdist3(b.v[p].x - qx, b.v[p].y - qy, b.v[p].z - qz), t[p]);
     }
     FbCand c{-2.0f, 0.f, 0.f, 0.f, 0xFFFFFFFFu};
     second = -2.0f;
@@ -208,7 +208,7 @@ __device__ __forceinline__ FbCand fm_apply(FbBucket<PPL> &b, uint32_t pmask, flo
             second = c.t;
             c.t = t[p]; c.key = b.key[p]; c.x = b.v[p].x; c.y = b.v[p].y; c.z = b.v[p].z;
         } else {
-            second = fmaxf(second, t[p]);
+            second = tpu3_max1(second, t[p]);
         }
     }
     return c;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(1024) void rb_main_kernel(FbArgs a0)
     // publish the record; returns the row's maximum (wave-uniform)
     auto rescan = [&](auto jc) -> int {
         constexpr int j = decltype(jc)::value;
-        const float t = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, pz[j] - qz), pt[j]);
+        const float t = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, pz[j] - qz), pt[j]);
         pt[j] = t;
         const int bits = __float_as_int(t);
         const int wmax = tpu3_wave_max_i32_fast(bits);
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
             if (PROF) pc[5] += 1;
             rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                pt[j] = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
+                pt[j] = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
                 if constexpr (ZL && j % 8 == 7)
                     __builtin_amdgcn_sched_barrier(0);      // (eight LDS reads in flight, not all R: registers)
             });
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
                         const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);
                         rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            pt[j] = fminf(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
+                            pt[j] = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
                         });
                     }
                 }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 if (act) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+                        nt[j] = tpu3_min1(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
                 }
             }
             if (act) {
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(1024) void fl_main_kernel(FbArgs a0)
                 const bool go = mine != 0;
                 const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
                 mine &= mine - 1;
-                const float d = fminf(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
+                const float d = tpu3_min1(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
                 nt = go ? d : nt;
             }
             const int tb = act ? __float_as_int(nt) : (int)0x80000000;

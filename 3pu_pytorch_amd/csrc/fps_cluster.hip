@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                 if (act) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        nt[j] = fminf(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
+                        nt[j] = tpu3_min1(tpu3_sqdist3(pt[j].x - p.x, pt[j].y - p.y, pt[j].z - p.z), nt[j]);
                 }
             }
             if (act) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void fc_main_kernel(FbArgs a0, int lg, u64 *m
                     const bool go = mine != 0;
                     const float4 p = *(const float4 *)sh.pick[cur][go ? __builtin_ctzll(mine) : 0];
                     mine &= mine - 1;
-                    const float d = fminf(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
+                    const float d = tpu3_min1(tpu3_sqdist3(pt.x - p.x, pt.y - p.y, pt.z - p.z), nt);
                     nt = go ? d : nt;
                 }
                 const int tbits = act ? __float_as_int(nt) : (int)0x80000000;

@@ -22,6 +22,24 @@ __device__ __forceinline__ double tpu3_sqdist3(double dx, double dy, double dz)
     return __builtin_fma(dz, dz, __builtin_fma(dx, dx, dy * dy));
 }
 
+// min / max of two floats as ONE instruction.  fminf() / fmaxf() lower to minnum / maxnum, and with the IEEE mode bit
+// set the compiler quiets every operand it cannot prove canonical first (v_max_f32 v, v, v): a value that came out of a
+// load, a lane exchange or a bit cast costs three half-rate instructions per minimum instead of one (round 5: 260 of
+// the 335 v_max_f32 of the per-level FPS kernel were these).  v_min_f32 / v_max_f32 return the other operand for a
+// quiet NaN like fminf / fmaxf do; results for non-NaN inputs are the same bits.
+__device__ __forceinline__ float tpu3_min1(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float tpu3_max1(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Order-preserving float -> u32 map (ascending float order == ascending unsigned order),
 // -0.0 is folded onto +0.0 first.  NaNs land above +inf.
 __device__ __forceinline__ uint32_t tpu3_mono(float f)
