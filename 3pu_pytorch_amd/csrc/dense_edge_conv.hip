@@ -1146,7 +1146,10 @@ int dec4_launch(hipStream_t s, int patches, const DecArgs &a)
     // 3840-patch launch).  TPU3_DEC_NW: tuning hook.
     static const int nw_env = getenv("TPU3_DEC_NW") ? atoi(getenv("TPU3_DEC_NW")) : 4;
     const int nw = min(min(DEC4_MAXW, max(1, nw_env)), (a.n + 63) / 64);
-    const size_t lds = dec4_lds_bytes(a.n, a.fold_n);
+    // TPU3_DEC_LDS_MIN (tuning hook): a floor under the LDS request, e.g. 56000 = two workgroups per compute unit instead
+    // of three (leaves a third of the registers and wave slots to kernels of the other streams)
+    static const size_t lds_min = getenv("TPU3_DEC_LDS_MIN") ? (size_t)atol(getenv("TPU3_DEC_LDS_MIN")) : 0;
+    const size_t lds = max(dec4_lds_bytes(a.n, a.fold_n), min(lds_min, (size_t)160 * 1024));
     // two neighbour slots per loop iteration (U = 1: 4 waves per SIMD but 36 instead of 18 running-maximum instructions
     // per slot, 298.5 vs 294.9 ms per bench step in round 3, and it spills since the left-over steps are split)
     void (*kern)(DecArgs);
