@@ -78,6 +78,7 @@ SIGNATURES = {
     "tpu3_debug_knn_tiles_stats": (_i, [_vp]),
     "tpu3_debug_fps_cluster": (_i, [_i]),
     "tpu3_debug_dec_split": (_i, [_i]),
+    "tpu3_debug_skip_fused": (_i, [_i]),
     "tpu3_debug_fps_plan": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int)]),
     "tpu3_fps_cluster_faults": (ctypes.c_long, [_i]),
     "tpu3_debug_fps_cluster_absent": (_i, [_i]),

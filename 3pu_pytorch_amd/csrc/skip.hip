@@ -179,7 +179,8 @@ __device__ __forceinline__ int sk_lane_neighbour(const int (&nbr)[K], int tk)
 
 // (the bodies take their pointers as __restrict__ parameters: once inlined, the index loads are known not to be
 // clobbered by the kernel's stores and stay scalar loads)
-template <int K, bool VEC, bool TAIL, typename T>
+// (THREADS / FUSED: skip_fused_kernel -- a workgroup of THREADS owns a whole patch, the distance scratch is its LDS)
+template <int K, bool VEC, bool TAIL, typename T, int THREADS = SK_THREADS, bool FUSED = false>
 __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__restrict__ idx_p,
                                                const T *__restrict__ feat_p, float *__restrict__ dist_p,
                                                float *__restrict__ mins_p)
@@ -195,8 +196,8 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
     const T *F = feat_p + (size_t)b * n * a.feat_stride;
     const float *PX = a.prev_xyz + (size_t)pb * a.m * 3;
     const T *PF = (const T *)a.prev_feat + (size_t)pb * a.m * C;
-    float2 *DS = (float2 *)dist_p + (size_t)b * n * K;              // (spatial, feature) per neighbour
-    float2 *MN = (float2 *)mins_p + (size_t)b * n;
+    float2 *DS = (float2 *)dist_p + (FUSED ? 0 : (size_t)b * n * K);        // (spatial, feature) per neighbour
+    float2 *MN = (float2 *)mins_p + (FUSED ? 0 : (size_t)b * n);
     const int C4 = C >> 2;
     const bool v0 = lane < C4;
     // loads are unconditional from clamped slots (a select on the result, not a branch around the load)
@@ -206,7 +207,7 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
     // The point's own row streams from HBM (the longest wait of an iteration) and its neighbour list is a scalar
     // load the row addresses depend on: both are fetched ONE ITERATION AHEAD (8 registers), so an iteration waits
     // for L2 (the gathered rows) only.
-    constexpr int STEP = SK_THREADS / 64;
+    constexpr int STEP = THREADS / 64;
     int nbr[K];
     sk_f4 x0 = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
     if (i_lo + wave < i_hi) {
@@ -214,9 +215,9 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
         sk_neighbours<K>(a, idx_p, ((size_t)b * n + i) * K, nbr);
         if (VEC) {
             const T *X4 = F + (size_t)i * a.feat_stride;
-            x0 = sk_ld4<true>(X4, l0);
+            x0 = sk_ld4<!FUSED>(X4, l0);
             if (TAIL && L.small)
-                xt = sk_ld4<true>(X4, 64 + L.tj);
+                xt = sk_ld4<!FUSED>(X4, 64 + L.tj);
         }
     }
     for (int i = i_lo + wave; i < i_hi; i += STEP) {
@@ -243,9 +244,9 @@ __device__ __forceinline__ void skip_dist_body(const SkipArgs &a, const void *__
             {
                 sk_neighbours<K>(a, idx_p, ((size_t)b * n + inx) * K, nbrn);
                 const T *X4n = F + (size_t)inx * a.feat_stride;
-                x0n = sk_ld4<true>(X4n, l0);
+                x0n = sk_ld4<!FUSED>(X4n, l0);
                 if (TAIL && L.small)
-                    xtn = sk_ld4<true>(X4n, 64 + L.tj);
+                    xtn = sk_ld4<!FUSED>(X4n, 64 + L.tj);
             }
             float ts = 0.f;
             if (TAIL) {
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(SK_THREADS) void skip_dist_kernel(SkipArgs a)
     skip_dist_body<K, VEC, TAIL, T>(a, a.idx, (const T *)a.feat, a.dist, a.mins);
 }
 
-template <int K, bool VEC, bool TAIL, typename T>
+template <int K, bool VEC, bool TAIL, typename T, int THREADS = SK_THREADS, bool FUSED = false>
 __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *__restrict__ idx_p,
                                                 T *__restrict__ feat_p, const T *__restrict__ prev_p,
                                                 const float *__restrict__ dist_p, const float *__restrict__ mins_p)
@@ -338,8 +339,8 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
     const int i_lo = slice * a.slice_len, i_hi = min(n, i_lo + a.slice_len);
     T *F = feat_p + (size_t)b * n * a.feat_stride;
     const T *PF = prev_p + (size_t)pb * a.m * C;
-    const float2 *DS = (const float2 *)dist_p + (size_t)b * n * K;
-    const float2 *MN = (const float2 *)mins_p + (size_t)b * n;
+    const float2 *DS = (const float2 *)dist_p + (FUSED ? 0 : (size_t)b * n * K);
+    const float2 *MN = (const float2 *)mins_p + (FUSED ? 0 : (size_t)b * n);
     // ---- h = mean over the patch's points of the distance to the closest of the K neighbours; every wave of
     // every slice of a patch sums the same values in the same order (no barrier, no LDS) -----------------------
     float ms = 0.f, mf = 0.f;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void skip_apply_body(const SkipArgs &a, const void *_
     const int lk = min(L.tk, K - 1);                // (lanes 0 .. K-1: their own neighbour; K <= 8)
 
     // (own row and neighbour list one iteration ahead, as in skip_dist_kernel)
-    constexpr int STEP = SK_THREADS / 64;
+    constexpr int STEP = THREADS / 64;
     int nbr[K];
     sk_f4 x0 = {0.f, 0.f, 0.f, 0.f}, xt = {0.f, 0.f, 0.f, 0.f};
     if (i_lo + wave < i_hi) {
@@ -475,6 +476,26 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
     skip_apply_body<K, VEC, TAIL, T>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, a.dist, a.mins);
 }
 
+// (r5) ONE launch, a 16-wave workgroup per patch: distances and minima of all its points into LDS, a barrier, then the
+// weights and the update.  The own rows are still read twice, but the second read follows the first by half a
+// workgroup's life instead of a whole launch (1.3 GB of other rows): with ONE patch in flight per compute unit (84 MB
+// on the device) it is served by the Infinity Cache, the (2K+2)-float scratch per point never reaches memory (every
+// wave sums h from LDS) -- the same operations in the same order as the two kernels, bit for bit.  Measured on a
+// 3840-patch chunk: two kernels 1.49 ms; fused with 4 / 8 / 12 / 16 waves per workgroup (8 / 4 / 2 / 1 patches per
+// compute unit) 1.45 / 1.34 / 1.34 / 1.26 ms; 16 waves held to 64 registers (two patches per compute unit) 1.43 ms;
+// with 137 of a patch's 312 own rows kept in the workgroup's LDS for the second phase 1.27 ms (no gain: dropped).
+constexpr int SKF_THREADS = 1024;
+
+template <int K, bool VEC, bool TAIL, typename T = float>
+__global__ __launch_bounds__(SKF_THREADS) void skip_fused_kernel(SkipArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sk_sm[];
+    float *ds = sk_sm, *mn = sk_sm + (size_t)a.n * K * 2;
+    skip_dist_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (const T *)a.feat, ds, mn);
+    __syncthreads();
+    skip_apply_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, ds, mn);
+}
+
 // (r4, measured and removed -- commit cc6a076 has the kernels): a DPP ROW of 16 lanes per point, four points per wave
 // step (a lane holds 4 + 1 float4 of each row; reductions are 4 DPP steps inside the rows for four points at once, lane
 // k of a row evaluates neighbour k's spatial distance and weight, row_newbcast hands them round; loads stay coalesced,
@@ -483,6 +504,8 @@ __global__ __launch_bounds__(SK_THREADS) void skip_apply_kernel(SkipArgs a)
 // VGPRs, 4 / 3 waves per SIMD), 1.57 ms single-buffered (86 / 116 VGPRs), against 1.52 ms here.  These kernels are not
 // bound by their instruction count: what limits them is the vector-memory path (K + 1 rows of 1056 B per point and
 // kernel from L2 / HBM) and the waves available to hide it.
+
+int g_skip_fused = getenv("TPU3_SKIP_FUSED") ? atoi(getenv("TPU3_SKIP_FUSED")) != 0 : 1;
 
 template <int K>
 int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool half)
@@ -495,6 +518,21 @@ int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool hal
             hipLaunchKernelGGL((skip_dist_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
             hipLaunchKernelGGL((skip_apply_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
         }
+        return tpu3_launch_status();
+    }
+    // inference on fp32 rows (float4 lanes), the patch's scratch in LDS: the fused launch (TPU3_SKIP_FUSED=0 /
+    // tpu3_debug_skip_fused(0): the two kernels)
+    const size_t lds = (size_t)a.n * (K + 1) * 8;
+    if (g_skip_fused && vec && !a.wout && lds <= 64 * 1024) {
+        SkipArgs f = a;
+        const int patches = blocks / a.slices;
+        f.slices = 1;
+        f.slice_len = a.n;
+        f.remap_blocks = a.per_cloud ? (patches / a.per_cloud / 8) * 8 * a.per_cloud : 0;
+        if (a.c > 256)
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, true>), dim3(patches), dim3(SKF_THREADS), lds, s, f);
+        else
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, false>), dim3(patches), dim3(SKF_THREADS), lds, s, f);
         return tpu3_launch_status();
     }
     if (vec && a.c > 256) {
@@ -565,6 +603,13 @@ extern "C" size_t tpu3_interlevel_skip_workspace_bytes(int b, int n, int k)
     if (b <= 0 || n <= 0 || k <= 0)
         return 0;
     return (size_t)b * n * (2 * (size_t)k + 2) * sizeof(float);
+}
+
+extern "C" int tpu3_debug_skip_fused(int on)
+{
+    const int old = g_skip_fused;
+    g_skip_fused = on != 0;
+    return old;
 }
 
 extern "C" int tpu3_interlevel_skip_f32(tpu3_stream_t stream, int b, int n, int k, int c, const float *xyz,

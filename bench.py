@@ -218,11 +218,15 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
                     "algorithmic_bytes_per_step": byt, "traffic": tr("linear_small_kernel")})
     ms, shp, spread = kt.total("interlevel_skip")
     if shp:
-        byt = sum(b * n * (3.0 * 4 * c) for b, n, k, c in shp)           # own row read twice, written once
+        byt = sum(b * n * (2.0 * 4 * c) for b, n, k, c in shp)           # own row read once, written once
         ach = byt / (ms * 1e-3) / 1e9
-        out.append({"kernel": "skip_dist_kernel + skip_apply_kernel (inter-level skip), %d launches/step" % len(shp),
+        out.append({"kernel": "skip_fused_kernel (inter-level skip, one launch, a 16-wave workgroup per patch), %d launches/step"
+                              % len(shp),
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "basis": "3 x 4C B per point streamed (the 2K gathered neighbour rows per point come from L2)",
+                    "basis": "2 x 4C B per point: the own row read once and written once (its second read, half a workgroup's "
+                             "life after the first, comes from the Infinity Cache; the 2K gathered neighbour rows per point "
+                             "from L2).  Rounds 1-4 ran two kernels = 3 x 4C B per point: on that basis this entry would read "
+                             "%.2f" % (1.5 * ach / HBM_PEAK_GBS),
                     "ms_per_step": ms, "ms_per_step_min_max": spread, "algorithmic_bytes_per_step": byt, "traffic": tr("skip_")})
     ms, shp, spread = kt.total("fps", lambda s: s[2] >= 256)
     if shp:

@@ -506,6 +506,11 @@ int tpu3_debug_fps_plan(int b, int n, int m, int *cluster);
  * (on = 1, the default) or taken whole by one wave (on = 0, the form before round 4; also TPU3_DEC_SPLIT=0).  Both
  * give the same bits (tests/test_hip_network.py).  Returns the previous setting; host-side state only. */
 int tpu3_debug_dec_split(int on);
+/* tpu3_debug_skip_fused: the inference skip on fp32 rows runs as ONE launch with a 16-wave workgroup per patch (on = 1,
+ * the default: distances and minima in LDS, a barrier, weights and update; the second read of a patch's own rows
+ * comes from the Infinity Cache) or as the two kernels with a global scratch (on = 0; also TPU3_SKIP_FUSED=0).  Both
+ * give the same bits (tests/test_hip_network.py).  Returns the previous setting; host-side state only. */
+int tpu3_debug_skip_fused(int on);
 
 /* The multi-workgroup FPS spins on its partner workgroups with BOUNDED polls; a launch whose workgroups never all
  * became resident gives up, leaves its outputs incomplete and counts a fault.  Returns the number of faulted

@@ -1032,6 +1032,34 @@ def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
     assert (got.double() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("C,K,N,per", [(264, 5, 312, 4), (264, 5, 312, 0), (256, 5, 100, 0), (288, 8, 330, 0),
+                                       (64, 3, 17, 0), (264, 5, 1024, 2)])
+def test_interlevel_skip_one_launch_gives_the_two_kernels_bits(dev, C, K, N, per):
+    """The inference skip as ONE launch (a 16-wave workgroup per patch, distances and minima in LDS) against the two
+    kernels with a global scratch (tpu3_debug_skip_fused): the same operations in the same order -- bit-identical
+    rows, with and without the XCD-aware block mapping (`per_cloud`), with and without the packed tail."""
+    ops = pkg("network.operations")
+    lib = pkg("_lib").lib()
+    g = torch.Generator(device="cpu").manual_seed(C + K + N)
+    Bp, M = 8, 500
+    B = Bp * (per if per else 3)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat = torch.randn(B, N, C, generator=g).to(dev)
+    pxyz = torch.rand(Bp, M, 3, generator=g).to(dev)
+    pfeat = torch.randn(Bp, M, C, generator=g).to(dev)
+    owner = torch.repeat_interleave(torch.arange(Bp, dtype=torch.int32), B // Bp).to(dev)
+    idx = torch.randint(0, M, (B, N, K), generator=g).to(dev)
+    old = lib.tpu3_debug_skip_fused(1)
+    try:
+        one = ops.BACKEND.interlevel_skip(xyz, feat.clone(), pxyz, pfeat, owner, idx, per_cloud=per)
+        lib.tpu3_debug_skip_fused(0)
+        two = ops.BACKEND.interlevel_skip(xyz, feat.clone(), pxyz, pfeat, owner, idx, per_cloud=per)
+    finally:
+        lib.tpu3_debug_skip_fused(old)
+    assert torch.equal(one, two)
+    assert not torch.equal(one, feat)
+
+
 # (5, 101): 505 points, not a multiple of the 8 points of a pass, one pass per workgroup; (21, 312): 6552 points = 819
 # passes on 512 workgroups -- some walk two passes, some one (idle halves must add nothing to the weight gradients that the
 # backward kernel accumulates across its passes)
