@@ -64,6 +64,17 @@ def test_argument_validation_without_gpu():
     assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24, 1) == 0
     assert lib.tpu3_linear_small_f32(None, 0, 84, 24, None, 84, None, None, 1, None, 24, 7) == -1   # unknown mfma
     assert lib.tpu3_dense_edge_conv_f32(None, 1, 312, 32, 8, 8, 4, 33, 1, 8, 8, 8, 8, 8, 8, 8, 60, 5) == -1
+    # (r5) packed DenseEdgeConv operands
+    assert lib.tpu3_dense_edge_conv_pack_floats(0) == 2080 and lib.tpu3_dense_edge_conv_pack_floats(72) == 2080 + 72 * 60
+    assert lib.tpu3_dense_edge_conv_pack_floats(36) == 0                                         # fold_n not 0/24/48/72
+    assert lib.tpu3_dense_edge_conv_pack_f32(None, 16, 16, 16, 16, 16, 16, 36, 16, 16) == -1
+    assert lib.tpu3_dense_edge_conv_pack_f32(None, 16, 16, 16, 16, 16, 16, 24, None, 16) == -1   # fold_n without fold_w
+    assert lib.tpu3_dense_edge_conv_pack_f32(None, 16, 16, 16, 16, 16, 16, 0, None, 8) == -1     # blob not 16-byte aligned
+    assert lib.tpu3_dense_edge_conv_pk_f32(None, 1, 312, 32, 16, 16, 4, 33, 1, None, 16, 60) == -1   # no blob
+    assert lib.tpu3_dense_edge_conv_pk_f32(None, 0, 312, 32, None, None, 4, 33, 1, None, None, 60) == 0
+    assert lib.tpu3_dense_edge_conv_pk_f32(None, 1, 4000, 32, 16, 16, 4, 33, 1, 16, 16, 60) == -2    # patch beyond LDS
+    assert lib.tpu3_dense_edge_conv_fold_pk_f32(None, 1, 312, 32, 16, 16, 4, 33, 1, 16, 16, 60, 36, 16, 16, 48, 0, 0, 16) == -1
+    assert lib.tpu3_debug_skip_fused(1) in (0, 1)
     assert lib.tpu3_linear_wgrad_f32(None, 100, 80, 12, 8, 80, 8, 12, 8, 8, 1 << 20) == -2       # cin > 64
     assert lib.tpu3_linear_wgrad_f32(None, 100, 48, 12, 8, 48, 8, 12, 8, None, 0) == -1          # no workspace
     assert lib.tpu3_linear_wgrad_workspace_bytes(319488) == 1024 * 16 * 64 * 4
