@@ -1035,6 +1035,11 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
 }
 
+#ifdef KG_TRACE
+// (-DKG_TRACE, tools/knn_trace.py: per wave the shader clocks of its slab loop and the chunks it took through the network)
+__device__ long long *g_kg_trace;
+#endif
+
 template <int C, int K>
 __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) void knn_graph_slab_kernel(KnnArgs a)
 {
@@ -1104,6 +1109,10 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nch = (n + L - 1) / L;
     int lo_c = 2 * wave - 1, hi_c = 2 * wave + 2;
     int side = 0;
+#ifdef KG_TRACE
+    const long long kt0 = __builtin_readcyclecounter();
+    int kt_dist = 0, kt_net = 0;
+#endif
     for (int step = 0;; ++step) {
         int c;
         const bool own = step < 2;
@@ -1133,6 +1142,9 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         const int j = c * L;
         float d[L];
+#ifdef KG_TRACE
+        ++kt_dist;
+#endif
 #pragma unroll
         for (int u = 0; u < L; u += 16)
             kg_dist<C, 4>(tile, rps, j + u, q, rq, d + u);
@@ -1158,8 +1170,17 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         // (taking the wave's first chunk -- empty list -- through the sorting network alone was measured: no gain, the
         // second code path costs five spilled registers)
+#ifdef KG_TRACE
+        ++kt_net;
+#endif
         kg_fold_i32<L>(lst, e, e2, nw);
     }
+#ifdef KG_TRACE
+    if (g_kg_trace && lane == 0) {
+        long long *t = g_kg_trace + ((size_t)b * 8 + wave) * 4;
+        t[0] = __builtin_readcyclecounter() - kt0; t[1] = kt_dist; t[2] = kt_net; t[3] = kt0;
+    }
+#endif
     // ---- boundary collisions after truncation: as knn_graph_key_kernel, ties by the ORIGINAL index ------------
     bool redo = live && (lst[0] >> IB) <= 0;
     const int T = lst[L - 1] >> IB;
@@ -2225,3 +2246,10 @@ extern "C" int tpu3_knn_unique_prepare_f32(tpu3_stream_t stream, int b, int m, i
     }
     return r;
 }
+
+#ifdef KG_TRACE
+extern "C" int tpu3_debug_kg_trace(long long *buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kg_trace), &buf, sizeof(buf));
+}
+#endif
