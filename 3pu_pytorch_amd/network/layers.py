@@ -15,6 +15,8 @@ Same classes, constructor arguments, parameter names and shapes (so reference ch
 The NCHW `forward` keeps the reference's calling convention; `forward_cl` is the channel-last
 entry the Level uses.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -177,6 +179,11 @@ def linear_1x1(conv, x):
     return F.linear(x, w2, conv.bias)
 
 
+# packed operand blobs of the fused DenseEdgeConv kernel per module (layers.DenseEdgeConv._operand_pack); held outside
+# the modules so that copy.deepcopy(net) / torch.save(net) never meet a stream event
+_PACK_CACHES = weakref.WeakKeyDictionary()
+
+
 class DenseEdgeConv(nn.Module):
     """Dense edge convolution block (reference layers.py:6-64): feature-space kNN graph, edge
     feature [x_i, x_j - x_i], `n` 1x1 convolutions with dense concatenation, max over k."""
@@ -314,6 +321,11 @@ class DenseEdgeConv(nn.Module):
                                                   want_dist=False, want_grouped=False)
         return None, full.long()[:, :, 1:]
 
+    @property
+    def _pack_cache(self):
+        """{fold_n: (key, blob, stream, event)} of this block's packed operands (see _operand_pack)."""
+        return _PACK_CACHES.get(self, {})
+
     def _operand_pack(self, fold_w=None):
         """The fused fp32 kernel's operand tables for this block's CURRENT weights (and for `fold_w`, the folded prep
         convolutions' columns), HipBackend.dense_edge_conv_pack, cached until a weight changes (version counters and
@@ -326,7 +338,7 @@ class DenseEdgeConv(nn.Module):
             return None
         key = tuple(t._version for t in ps) + tuple(t.data_ptr() for t in ps) + \
             ((fold_w.data_ptr(), fold_w._version, fold_w.size(0)) if fold_w is not None else (0, 0, 0))
-        cache = self.__dict__.setdefault("_pack_cache", {})
+        cache = _PACK_CACHES.setdefault(self, {})      # (not an attribute: events and blobs must not be pickled / deep-copied)
         slot = 0 if fold_w is None else fold_w.size(0)
         here = torch.cuda.current_stream(ps[0].device)
         hit = cache.get(slot)

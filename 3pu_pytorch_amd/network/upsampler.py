@@ -17,6 +17,8 @@ from math import log, sqrt
 
 import os
 
+import weakref
+
 import torch
 
 from . import layers
@@ -291,6 +293,11 @@ class _SkipTrain(torch.autograd.Function):
         return g, gprev, None, None, None, None
 
 
+# fold plans per Level (Level._fold_plan): held outside the modules -- a plan carries a stream event, which neither
+# copy.deepcopy(net) nor torch.save(net) may meet
+_FOLD_CACHES = weakref.WeakKeyDictionary()
+
+
 class Level(torch.nn.Module):
     """3PU per-level network (reference :192-374)."""
 
@@ -373,7 +380,7 @@ class Level(torch.nn.Module):
         # (weights AND biases: block 0 bakes the three biases in; a bias-only in-place edit must rebuild too)
         key = tuple(t._version for p in preps for t in (p.conv.weight, p.conv.bias)) + \
             tuple(t.data_ptr() for p in preps for t in (p.conv.weight, p.conv.bias))
-        cached = getattr(self, "_fold_cache", None)
+        cached = _FOLD_CACHES.get(self)
         on_device = preps[0].conv.weight.is_cuda
         here = torch.cuda.current_stream(preps[0].conv.weight.device) if on_device else None
         if cached is not None and cached[0] == key:
@@ -405,7 +412,7 @@ class Level(torch.nn.Module):
         if on_device:
             done = torch.cuda.Event()
             done.record(here)
-        self._fold_cache = (key, plan, here.cuda_stream if on_device else None, done)
+        _FOLD_CACHES[self] = (key, plan, here.cuda_stream if on_device else None, done)
         return plan
 
     def forward_cl(self, xyz, xyz_normalized, previous=None, owner=None, groups=1, per_owner=0):

@@ -878,6 +878,24 @@ def test_dense_edge_conv_module_repacks_when_a_weight_changes(dev):
     assert torch.equal(y2[..., 12:], y0[..., 12:])
 
 
+def test_modules_with_cached_operands_can_be_copied_and_pickled(dev):
+    """The packed-operand blobs and fold plans carry stream events; they live outside the modules, so a block that has
+    run can still be deep-copied and pickled, and the copy computes the same rows from its own cache."""
+    import copy
+    import io
+    layers = pkg("network.layers")
+    blk = _dec_block(layers, dev, 16, 5)
+    x = torch.randn(2, 312, 24, device=dev)
+    with torch.no_grad():
+        y0, _ = blk.forward_cl(x)
+        twin = copy.deepcopy(blk)
+        buf = io.BytesIO()
+        torch.save(blk, buf)
+        y1, _ = twin.forward_cl(x)
+    assert torch.equal(y0, y1)
+    assert twin._pack_cache[0][1] is not blk._pack_cache[0][1]
+
+
 @pytest.mark.parametrize("P,N,k", [(4, 312, 32), (3, 1024, 32), (1, 3000, 16)])
 def test_dense_edge_conv_fp16_mfma_within_derived_bound(dev, P, N, k):
     """mlp_precision = "f16" (config C5: fp16 operands on the matrix cores, fp32 accumulate) on the same neighbour
