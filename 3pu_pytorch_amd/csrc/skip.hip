@@ -510,6 +510,26 @@ int g_skip_fused = getenv("TPU3_SKIP_FUSED") ? atoi(getenv("TPU3_SKIP_FUSED")) !
 template <int K>
 int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool half)
 {
+    // inference, float4 lanes, the patch's scratch in LDS: the one-launch form (TPU3_SKIP_FUSED=0 /
+    // tpu3_debug_skip_fused(0): the two kernels); fp32 and fp16 rows alike
+    const size_t lds = (size_t)a.n * (K + 1) * 8;
+    if (g_skip_fused && (vec || half) && !a.wout && lds <= 64 * 1024) {
+        SkipArgs f = a;
+        const int patches = blocks / a.slices;
+        f.slices = 1;
+        f.slice_len = a.n;
+        f.remap_blocks = a.per_cloud ? (patches / a.per_cloud / 8) * 8 * a.per_cloud : 0;
+        const dim3 g(patches), t(SKF_THREADS);
+        if (half && a.c > 256)
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, true, _Float16>), g, t, lds, s, f);
+        else if (half)
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, false, _Float16>), g, t, lds, s, f);
+        else if (a.c > 256)
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, true>), g, t, lds, s, f);
+        else
+            hipLaunchKernelGGL((skip_fused_kernel<K, true, false>), g, t, lds, s, f);
+        return tpu3_launch_status();
+    }
     if (half) {         // fp16 rows: the float4-per-lane forms only (the caller checked the alignment)
         if (a.c > 256) {
             hipLaunchKernelGGL((skip_dist_kernel<K, true, true, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
@@ -518,21 +538,6 @@ int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool hal
             hipLaunchKernelGGL((skip_dist_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
             hipLaunchKernelGGL((skip_apply_kernel<K, true, false, _Float16>), dim3(blocks), dim3(SK_THREADS), 0, s, a);
         }
-        return tpu3_launch_status();
-    }
-    // inference on fp32 rows (float4 lanes), the patch's scratch in LDS: the fused launch (TPU3_SKIP_FUSED=0 /
-    // tpu3_debug_skip_fused(0): the two kernels)
-    const size_t lds = (size_t)a.n * (K + 1) * 8;
-    if (g_skip_fused && vec && !a.wout && lds <= 64 * 1024) {
-        SkipArgs f = a;
-        const int patches = blocks / a.slices;
-        f.slices = 1;
-        f.slice_len = a.n;
-        f.remap_blocks = a.per_cloud ? (patches / a.per_cloud / 8) * 8 * a.per_cloud : 0;
-        if (a.c > 256)
-            hipLaunchKernelGGL((skip_fused_kernel<K, true, true>), dim3(patches), dim3(SKF_THREADS), lds, s, f);
-        else
-            hipLaunchKernelGGL((skip_fused_kernel<K, true, false>), dim3(patches), dim3(SKF_THREADS), lds, s, f);
         return tpu3_launch_status();
     }
     if (vec && a.c > 256) {

@@ -1050,9 +1050,11 @@ def test_interlevel_skip_kernel_against_formula(dev, C, K, idx_dtype):
     assert (got.double() - ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("C,K,N,per", [(264, 5, 312, 4), (264, 5, 312, 0), (256, 5, 100, 0), (288, 8, 330, 0),
-                                       (64, 3, 17, 0), (264, 5, 1024, 2)])
-def test_interlevel_skip_one_launch_gives_the_two_kernels_bits(dev, C, K, N, per):
+@pytest.mark.parametrize("C,K,N,per,rows", [(264, 5, 312, 4, torch.float32), (264, 5, 312, 0, torch.float32),
+                                            (256, 5, 100, 0, torch.float32), (288, 8, 330, 0, torch.float32),
+                                            (64, 3, 17, 0, torch.float32), (264, 5, 1024, 2, torch.float32),
+                                            (264, 5, 1024, 2, torch.float16), (256, 5, 312, 0, torch.float16)])
+def test_interlevel_skip_one_launch_gives_the_two_kernels_bits(dev, C, K, N, per, rows):
     """The inference skip as ONE launch (a 16-wave workgroup per patch, distances and minima in LDS) against the two
     kernels with a global scratch (tpu3_debug_skip_fused): the same operations in the same order -- bit-identical
     rows, with and without the XCD-aware block mapping (`per_cloud`), with and without the packed tail."""
@@ -1062,9 +1064,9 @@ def test_interlevel_skip_one_launch_gives_the_two_kernels_bits(dev, C, K, N, per
     Bp, M = 8, 500
     B = Bp * (per if per else 3)
     xyz = torch.rand(B, N, 3, generator=g).to(dev)
-    feat = torch.randn(B, N, C, generator=g).to(dev)
+    feat = torch.randn(B, N, C, generator=g).to(dev).to(rows)           # (fp16: activation storage mode "f16")
     pxyz = torch.rand(Bp, M, 3, generator=g).to(dev)
-    pfeat = torch.randn(Bp, M, C, generator=g).to(dev)
+    pfeat = torch.randn(Bp, M, C, generator=g).to(dev).to(rows)
     owner = torch.repeat_interleave(torch.arange(Bp, dtype=torch.int32), B // Bp).to(dev)
     idx = torch.randint(0, M, (B, N, K), generator=g).to(dev)
     old = lib.tpu3_debug_skip_fused(1)
