@@ -569,12 +569,53 @@ __device__ __forceinline__ void dec4_step(const f32x4 *tab, int li, int kq, floa
     acc[0] = mfma411(a0[3], i3, acc[0]); acc[1] = mfma411(a1[3], i3, acc[1]); acc[2] = mfma411(a2[3], i3, acc[2]);
 }
 
+// (r5) acc[rg] += W[4 rg .. 4 rg + 3][0 .. 4 KQ) x for NRG row groups, the A operands of k-quad kq + 1 requested from the
+// LDS table BEFORE the MFMAs of k-quad kq are issued (two register sets).  Written as "read the three operands, issue
+// their twelve MFMAs" per k-quad the compiler kept one register set and every group of MFMAs waited a full LDS round
+// trip for its operands: the folded prep convolutions ran at a fifth of the matrix rate (90 reads x ~100 cycles
+// against 360 x 8 per chunk of 24 outputs).
+// k-quad visited at position t.  The fold (KQ = 15: [max h2 | max h1 | max h0 | x_i]) keeps the order its sums have had
+// since round 3 -- group by group across the three maxima, then x -- because the 16x end-to-end fixtures were recorded
+// against those bits: another (equally valid) order rounds a prep output differently, that flips a near-tie of the next
+// block's kNN graph in some patch, and from the next level's FPS seeds on every point differs.
+template <int KQ>
+__device__ constexpr int dec4_kq_at(int t)
+{
+    return KQ == 15 ? (t < 9 ? 3 * (t % 3) + t / 3 : t) : t;
+}
+
+template <int KQ, int NRG>
+__device__ __forceinline__ void dec4_mm(const f32x4 *tab, int li, const f32x4 (&x)[KQ], f32x4 (&acc)[NRG])
+{
+    f32x4 a[2][NRG];
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg)
+        a[0][rg] = tab[(rg * KQ + dec4_kq_at<KQ>(0)) * 4 + li];
+    dec4_static_for<0, KQ>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int kq = dec4_kq_at<KQ>(t);
+        if constexpr (t + 1 < KQ) {
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg)
+                a[(t + 1) & 1][rg] = tab[(rg * KQ + dec4_kq_at<KQ>(t + 1)) * 4 + li];
+        }
+        // (the k-quad's first B operand passes through the asm: its products -- and, through the accumulators, the
+        // rest -- cannot be issued above the requests; without that the scheduler hoists them and folds the two
+        // register sets into one)
+        float b0 = x[kq][0];
+        asm volatile("" : "+v"(b0) : : "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg)
+                acc[rg] = mfma411(a[t & 1][rg][r], r == 0 ? b0 : x[kq][r], acc[rg]);
+    });
+}
+
 // 12 outputs of a 24-channel input row held in six float4 registers
 __device__ __forceinline__ void dec4_mm24(const f32x4 *tab, int li, const f32x4 (&x)[6], f32x4 (&acc)[3])
 {
-#pragma unroll
-    for (int kq = 0; kq < 6; ++kq)
-        dec4_step<6>(tab, li, kq, x[kq][0], x[kq][1], x[kq][2], x[kq][3], acc);
+    dec4_mm<6, 3>(tab, li, x, acc);
 }
 
 // running maximum in LDS (ds_max_f32; no return value)
@@ -962,22 +1003,10 @@ void dec_fused4_kernel(DecArgs a)
                 for (int rg = 0; rg < 6; ++rg)
                     acc[rg] = a.fold_b ? *(const f32x4 *)(a.fold_b + 24 * ch + 4 * rg)
                                        : *(const f32x4 *)(arow + a.seed_off + 24 * ch + 4 * rg);
-                auto step15 = [&](int kq, const f32x4 &v) __attribute__((always_inline)) {
-                    f32x4 lo3[3] = {acc[0], acc[1], acc[2]}, hi3[3] = {acc[3], acc[4], acc[5]};
-                    dec4_step<15>(ft, li, kq, v[0], v[1], v[2], v[3], lo3);
-                    dec4_step<15>(ft + 3 * 15 * 4, li, kq, v[0], v[1], v[2], v[3], hi3);
-                    acc[0] = lo3[0]; acc[1] = lo3[1]; acc[2] = lo3[2];
-                    acc[3] = hi3[0]; acc[4] = hi3[1]; acc[5] = hi3[2];
-                };
-#pragma unroll
-                for (int g3 = 0; g3 < 3; ++g3) {
-                    step15(g3, m2[g3]);
-                    step15(3 + g3, m1[g3]);
-                    step15(6 + g3, m0[g3]);
-                }
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    step15(9 + q, x[q]);
+                // the row [max h2 | max h1 | max h0 | x_i] as 15 k-quads, in the order of the weight columns
+                const f32x4 row[15] = {m2[0], m2[1], m2[2], m1[0], m1[1], m1[2], m0[0], m0[1], m0[2],
+                                       x[0], x[1], x[2], x[3], x[4], x[5]};
+                dec4_mm<15, 6>(ft, li, row, acc);
                 if (p < n) {
                     if (ch == 0) {
                         f32x4 *xn = (f32x4 *)(a.xnext + (prow + p) * DEC_C);
