@@ -637,11 +637,6 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
     int wbound = 0x7F800000;                        // +inf until the first selection has reduced the maxima
 
     // pair (i < l) number `lane` of the l-major enumeration 0:(0,1) 1:(0,2) 2:(1,2) 3:(0,3) ... (wave 0's clearance test)
-    int pair_l = (int)((1.f + sqrtf(1.f + 8.f * (float)lane)) * 0.5f);
-    pair_l -= pair_l * (pair_l - 1) / 2 > lane ? 1 : 0;
-    pair_l += (pair_l + 1) * pair_l / 2 <= lane ? 1 : 0;
-    const int pair_i = lane - pair_l * (pair_l - 1) / 2;
-
     if (tid == 0)
         a.idx[0] = 0;
     // current samples: lane i < J holds sample i; start with point 0
@@ -828,14 +823,13 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
                     {
                         const int npair = jmax * (jmax - 1) / 2;
                         for (int t0 = 0; t0 < npair; t0 += 64) {
-                            int pl = pair_l, pi = pair_i;
-                            if (t0) {
-                                const int t = t0 + lane;
-                                pl = (int)((1.f + sqrtf(1.f + 8.f * (float)t)) * 0.5f);
-                                pl -= pl * (pl - 1) / 2 > t ? 1 : 0;
-                                pl += (pl + 1) * pl / 2 <= t ? 1 : 0;
-                                pi = t - pl * (pl - 1) / 2;
-                            }
+                            // (the pair of a lane is derived here, every pass: kept from the kernel's start it was two
+                            // registers of all 16 waves for wave 0's sake, in a kernel that spills at 128)
+                            const int t = t0 + lane;
+                            int pl = (int)((1.f + sqrtf(1.f + 8.f * (float)t)) * 0.5f);
+                            pl -= pl * (pl - 1) / 2 > t ? 1 : 0;
+                            pl += (pl + 1) * pl / 2 <= t ? 1 : 0;
+                            const int pi = t - pl * (pl - 1) / 2;
                             const bool ok = pl < jmax;
                             const float4 L4 = *(const float4 *)sh.pick[par][ok ? pl : 0];
                             const float4 I4 = *(const float4 *)sh.pick[par][ok ? pi : 0];
