@@ -1040,6 +1040,11 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 __device__ long long *g_kg_trace;
 #endif
 
+// (r5, measured and dropped: two five-wave patches per workgroup -- ten waves are dealt 3 + 3 + 2 + 2 over the SIMDs
+// whatever the start, where a second five-wave workgroup only fits beside the first when the dispatcher starts it on
+// another SIMD: tools/knn_trace.py counts 1.40 patches resident per compute unit, 1.65 paired -- but 0.438 vs 0.407 ms
+// per launch: the kernel is bound by VALU issue, more resident waves only slow each other, and a ten-wave workgroup's
+// staging no longer overlaps the previous one's tail.)
 template <int C, int K>
 __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) void knn_graph_slab_kernel(KnnArgs a)
 {
@@ -1054,6 +1059,9 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ int orig[TILE];                      // original row of a sorted position
     __shared__ float crange[2 * NCH];               // t-range of each chunk: [c] = min, [NCH + c] = max
     __shared__ uint32_t wrq[NW];                    // per wave: mono(max |x_i|^2)
+#ifdef KG_TRACE
+    const long long kt_entry = __builtin_readcyclecounter();
+#endif
     if (a.uws && a.uws[0] != 0)
         return;
     const int b = blockIdx.y;
@@ -1178,8 +1186,9 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #ifdef KG_TRACE
     if (g_kg_trace && lane == 0) {
         long long *t = g_kg_trace + ((size_t)b * 8 + wave) * 4;
-        t[0] = __builtin_readcyclecounter() - kt0; t[1] = kt_dist; t[2] = kt_net; t[3] = kt0;
+        t[0] = __builtin_readcyclecounter() - kt0; t[1] = kt_dist; t[2] = kt_net; t[3] = kt0 - kt_entry;
     }
+    const long long kt_loop_end = __builtin_readcyclecounter();
 #endif
     // ---- boundary collisions after truncation: as knn_graph_key_kernel, ties by the ORIGINAL index ------------
     bool redo = live && (lst[0] >> IB) <= 0;
@@ -1258,6 +1267,17 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int i = 0; i < L; ++i)
             out[1 + i] = orig[lst[i] & ~keep];
     }
+#ifdef KG_TRACE
+    if (g_kg_trace && lane == 0) {
+        g_kg_trace[((size_t)b * 8 + 5 + (wave & 1)) * 4 + (wave >> 1)] = __builtin_readcyclecounter() - kt_loop_end;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // second block of the trace buffer: [patch][wave] -> (entry clock, exit clock, hw id, xcc id)
+        long long *t2 = g_kg_trace + (size_t)a.b * 32 + ((size_t)b * 8 + wave) * 4;
+        t2[0] = kt_entry; t2[1] = __builtin_readcyclecounter(); t2[2] = hw; t2[3] = xcc;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ tot = np.zeros((5, 3))
 for gi, x in enumerate(rows):
     reps = (B + x.size(0) - 1) // x.size(0)
     xb = x.repeat(reps, 1, 1)[:B].contiguous()
-    trace = torch.zeros((B, 8, 4), dtype=torch.int64, device=dev)
+    trace = torch.zeros((2, B, 8, 4), dtype=torch.int64, device=dev)
     for _ in range(30):
         ops.BACKEND.knn_graph(33, xb, optimistic=True)
     torch.cuda.synchronize()
@@ -60,8 +60,29 @@ for gi, x in enumerate(rows):
     ops.BACKEND.knn_graph(33, xb, optimistic=True)
     torch.cuda.synchronize()
     h.tpu3_debug_kg_trace(ctypes.c_void_p(0))
-    t = trace.cpu().numpy()[:, :5, :3].astype(np.float64)
+    both = trace.cpu().numpy()
+    full = both[0].astype(np.float64)
+    t = full[:, :5, :3]
     m = t.mean(0)
+    stage = full[:, :5, 3].mean()
+    tail = np.concatenate([full[:, 5, :3].ravel(), full[:, 6, :2].ravel()]).mean()
+    if gi == 0:
+        w = both[1][:, :5, :]                                   # (B, 5 waves, [entry, exit, hw, xcc])
+        hw, xcc = w[:, :, 2], w[:, :, 3] & 0xF
+        simd, cu, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 13) & 7
+        print("   SIMD of wave 0..4 (share of workgroups): " + "  ".join(
+            "w%d: %s" % (k, np.round(np.bincount(simd[:, k], minlength=4) / len(simd), 2)) for k in range(5)))
+        print("   waves 0 and 4 on the same SIMD: %.2f of the workgroups" % (simd[:, 0] == simd[:, 4]).mean())
+        key = (xcc[:, 0] * 8 + se[:, 0]) * 16 + cu[:, 0]
+        conc = []
+        for kk in np.unique(key)[:64]:
+            sel = key == kk
+            st, en = w[sel][:, :, 0].min(1), w[sel][:, :, 1].max(1)
+            ts = np.linspace(st.min(), en.max(), 200)
+            conc.append(np.mean([((st <= x) & (en > x)).sum() for x in ts]))
+        print("   compute units seen %d; patches resident per compute unit over its busy time: mean %.2f" % (len(np.unique(key)), np.mean(conc)))
+    if gi % 4 == 0:
+        print("   staging (entry -> slab loop) %.0f cycles, after the loop (collisions, write-out) %.0f" % (stage, tail))
     tot += m
     if gi % 4 == 0:
         print("graph %2d: per slab 0..4  cycles %s  chunks with distances %s  through the network %s   workgroup: max/mean cycles %.2f"
