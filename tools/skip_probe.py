@@ -16,6 +16,9 @@ pfeat = torch.rand((clouds, m, C), device=dev, generator=g)
 # neighbours: spatially coherent within a patch -- a window of the unique rows
 base = torch.randint(0, uniq - 400, (B, 1, 1), device=dev, generator=g)
 idx = (base + torch.randint(0, 400, (B, n, K), device=dev, generator=g)).to(torch.int64)
+if os.environ.get("COHERENT"):      # neighbours vary smoothly along the point index: points i .. i + 15 share most rows
+    ii = torch.arange(n, device=dev).view(1, n, 1)
+    idx = (base + ii // 2 + torch.arange(K, device=dev).view(1, 1, K) * 3).clamp_(max=m - 1).to(torch.int64)
 if os.environ.get("SAME_ROW"):
     idx = torch.zeros_like(idx) + torch.arange(K, device=dev).view(1, 1, K)
 owner = torch.repeat_interleave(torch.arange(clouds, dtype=torch.int32, device=dev), P)
