@@ -76,6 +76,7 @@ SIGNATURES = {
     "tpu3_debug_fps_level_stats": (_i, [_vp]),
     "tpu3_debug_fps_tile_stats": (_i, [_vp]),
     "tpu3_debug_knn_tiles_stats": (_i, [_vp]),
+    "tpu3_debug_knn_slab_launches": (ctypes.c_long, [_i]),
     "tpu3_debug_fps_cluster": (_i, [_i]),
     "tpu3_debug_dec_split": (_i, [_i]),
     "tpu3_debug_skip_fused": (_i, [_i]),

@@ -836,10 +836,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //     t_i = <x_i, v>, |v| < 1;   rows sorted by t (a binned counting sort: order inside a bin is arbitrary).
 // A wave then owns 64 consecutive rows of that order -- a SLAB of the patch -- and visits the 32-row chunks outwards
 // from its own, left and right alternately.  (t_q - t_c)^2 <= |x_q - x_c|^2 for every pair, so once every lane's
-// gap to the chunk's t-range, squared, exceeds the lane's current 32nd key (with a margin for the rounding of t
-// and of the expanded-form distance, see E1 / E2), the chunk AND every chunk beyond it on that side cannot change
-// any list: that side is closed without computing a single distance (~31 % of all chunks on the feature rows of a
-// 16x run).  A chunk that survives the bound still skips the sorting network when no lane's smallest new key
+// gap to the t-range of the chunk AND ALL CHUNKS BEYOND IT on that side (r6: a suffix-min / prefix-max table -- the
+// binned order is not monotone inside a bin, each chunk's own range is not enough), squared, exceeds the lane's
+// current 32nd key (with a margin for the rounding of t and of the expanded-form distance, see E1 / E2), none of
+// them can change any list: that side is closed without computing a single distance (~31 % of all chunks on the
+// feature rows of a 16x run).  A chunk that survives the bound still skips the sorting network when no lane's smallest new key
 // beats its 32nd (~10 %).  Keys carry the sorted POSITION in their low bits; truncation ties are only ever resolved
 // at the list's boundary, and there by (distance, ORIGINAL index) exactly like the oracle.  A skipped key has a
 // truncated distance strictly above the list's last one at that time (hence above the final one), so it can never
@@ -1057,7 +1058,8 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float4 tile[TILE * F4];              // the patch's rows in SORTED order
     __shared__ __attribute__((aligned(16))) float rps[TILE];
     __shared__ int orig[TILE];                      // original row of a sorted position
-    __shared__ float crange[2 * NCH];               // t-range of each chunk: [c] = min, [NCH + c] = max
+    __shared__ uint32_t crange[2 * NCH];            // t-range of each chunk, mono(): [c] = min, [NCH + c] = max
+    __shared__ float cbound[NW][2 * NCH];           // per wave: [c] = min t over chunks >= c, [NCH + c] = max t over chunks <= c
     __shared__ uint32_t wrq[NW];                    // per wave: mono(max |x_i|^2)
 #ifdef KG_TRACE
     const long long kt_entry = __builtin_readcyclecounter();
@@ -1094,8 +1096,8 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         lo = min(lo, (uint32_t)tpu3_dpp<0x142, 0xA>((int)lo));     // rows 1, 3 += rows 0, 2: lanes 31 / 63 hold a chunk
         hi = max(hi, (uint32_t)tpu3_dpp<0x142, 0xA>((int)hi));
         if ((lane & 31) == 31) {
-            crange[tid >> 5] = tpu3_unmono(lo);                    // (an all-pad chunk: NaN / -NaN, never closed by a bound)
-            crange[NCH + (tid >> 5)] = tpu3_unmono(hi);
+            crange[tid >> 5] = lo;                                 // (an all-pad chunk: neutral for the min / max below)
+            crange[NCH + (tid >> 5)] = hi;
         }
         const uint32_t wm = tpu3_wave_max_u32(live ? tpu3_mono(rq) : 0u);
         if (lane == 0)
@@ -1106,6 +1108,37 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int w = 1; w < nwaves; ++w)
         mm = max(mm, wrq[w]);
     const float M = tpu3_unmono(mm);                // max |x_i|^2 over the patch
+    const int nch = (n + L - 1) / L;
+    // (r6) The closing test below shuts a side at chunk c for c AND every chunk beyond it, so the range it tests must
+    // cover all of them.  The pre-pass only BINS the rows (order inside a bin = arrival order of its atomics): a chunk
+    // that lies wholly inside one bin can have a larger minimum t than a later chunk of the same bin (a dense cluster
+    // narrower than a bin; tools/knn_slab_bound_sim.py, test_knn_graph_slab_form_cluster_inside_one_bin).  So the table
+    // holds, for the right side, the minimum over chunks c .. nch-1 and, for the left side, the maximum over chunks
+    // 0 .. c: monotone whatever the order inside the bins is.  (For a chunk on the right of the wave's own the left-side
+    // term t_q - max is <= 0, the own chunks being part of the prefix, and vice versa: the max of the two below is
+    // always the bound of the side the walk is on.)  Each wave builds its own copy: no second workgroup barrier.
+    {
+        uint32_t slo = 0xFFFFFFFFu, phi = 0u;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            if (cc < nch) {
+                const uint32_t l = crange[cc], h = crange[NCH + cc];
+#ifdef KG_SLAB_OWN_TABLE        // (A/B builds only, tools/_ab: the r5 table -- each chunk's own range -- to show the test catches it)
+                slo = min(slo, cc == lane ? l : 0xFFFFFFFFu);
+                phi = max(phi, cc == lane ? h : 0u);
+#else
+                slo = min(slo, cc >= lane ? l : 0xFFFFFFFFu);
+                phi = max(phi, cc <= lane ? h : 0u);
+#endif
+            }
+        }
+        if (lane < NCH) {
+            cbound[wave][lane] = tpu3_unmono(slo);
+            cbound[wave][NCH + lane] = tpu3_unmono(phi);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float *cb = cbound[wave];
     // margins of the bound (DESIGN / docs): |t - <x, v>| <= 2^-19.4 sqrt(M) per row, the expanded-form distance is
     // within 2^-17.3 M of the true one; E1, E2 are 10x / 5x those
     const float E1 = 3.0517578125e-05f * __builtin_amdgcn_sqrtf(M), E2 = 3.0517578125e-05f * M;
@@ -1114,7 +1147,6 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int i = 0; i < L; ++i)
         lst[i] = 0x7FFFFFFF;
-    const int nch = (n + L - 1) / L;
     int lo_c = 2 * wave - 1, hi_c = 2 * wave + 2;
     int side = 0;
 #ifdef KG_TRACE
@@ -1135,7 +1167,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             side ^= 1;
             c = left ? lo_c : hi_c;
             // the bound: every row of chunk c (and beyond) is farther than the lane's 32nd key, for EVERY lane?
-            const float gap = __builtin_fmaxf(crange[c] - tq, tq - crange[NCH + c]) - E1;
+            const float gap = __builtin_fmaxf(cb[c] - tq, tq - cb[NCH + c]) - E1;
             const float tau = __int_as_float(lst[L - 1] | ~keep);      // top of the 32nd key's truncation bucket (NaN while the list is short)
             const bool out = !live || (gap > 0.f && __builtin_fmaf(gap, gap, -E2) > tau);
             const uint64_t outs = __builtin_amdgcn_ballot_w64(out);
@@ -2045,6 +2077,8 @@ namespace {
 // of their own -- a training batch (32 patches) or one cloud's 48 outer patches used to be 32 / 48 workgroups whose
 // five waves shared four SIMDs of one compute unit while most of the chip idled (82 -> 63 us per call).
 // TPU3_KG_THREADS: tuning hook.
+long g_kg_slab_launches = 0;     // tpu3_debug_knn_slab_launches: the tests assert that they exercise the slab form
+
 int kg_graph_threads(int b, int n)
 {
     static const int forced = getenv("TPU3_KG_THREADS") ? atoi(getenv("TPU3_KG_THREADS")) : 0;
@@ -2070,6 +2104,7 @@ int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a
         && threads == ((a.n + 63) / 64) * 64) {
         hipLaunchKernelGGL((knn_slab_order_kernel<24>), g, dim3(threads), 0, s, a);
         hipLaunchKernelGGL((knn_graph_slab_kernel<24, 33>), g, dim3(threads), 0, s, a);
+        ++g_kg_slab_launches;
         return tpu3_launch_status();
     }
     if (k == 33) {
@@ -2090,6 +2125,13 @@ int launch_graph_first_pass(hipStream_t s, dim3 g, int threads, const KnnArgs &a
     return tpu3_launch_status();
 }
 } // namespace
+
+extern "C" long tpu3_debug_knn_slab_launches(int reset)
+{
+    const long v = g_kg_slab_launches;
+    if (reset) g_kg_slab_launches = 0;
+    return v;
+}
 
 extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c, int k, const float *x,
                                        const tpu3_knn_layout *layout, uint8_t *dup, uint32_t *uws, int32_t *idx,

@@ -329,7 +329,7 @@ class DenseEdgeConv(nn.Module):
     def _operand_pack(self, fold_w=None):
         """The fused fp32 kernel's operand tables for this block's CURRENT weights (and for `fold_w`, the folded prep
         convolutions' columns), HipBackend.dense_edge_conv_pack, cached until a weight changes (version counters and
-        addresses, as Level._fold_plan).  The blob is built by a launch on one stream; a call on another stream orders
+        addresses, as Level._fold_plan -- an edit through `param.data` bumps neither: Net.invalidate_weight_caches()).  The blob is built by a launch on one stream; a call on another stream orders
         itself behind that launch.  None when the backend has no packed launch."""
         if not hasattr(operations.BACKEND, "dense_edge_conv_pack"):
             return None

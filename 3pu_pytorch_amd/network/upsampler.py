@@ -173,6 +173,19 @@ class Net(torch.nn.Module):
         for cell in self._small_cloud_counts.values():
             cell.zero_()
 
+    def invalidate_weight_caches(self):
+        """Drop every blob DERIVED from the weights: the packed DenseEdgeConv operand tables
+        (layers.DenseEdgeConv._operand_pack) and the folded prep convolutions (Level._fold_plan).  Both are keyed by the
+        parameters' version counters and addresses, which `optimizer.step()`, `load_state_dict` and every in-place
+        tensor method bump; an edit through `param.data` (p.data.copy_(), p.data.mul_()) bumps neither, so call this
+        after one.  (The unpacked kernels read the weights at every launch; only the cached blobs can go stale.)"""
+        for m in self.modules():
+            if isinstance(m, layers.DenseEdgeConv):
+                layers._PACK_CACHES.pop(m, None)
+            elif isinstance(m, Level):
+                _FOLD_CACHES.pop(m, None)
+        return self
+
     def set_mlp_precision(self, precision, activations=None):
         """Arithmetic of the matrix-core kernels of the per-patch feature stacks (inference):
         "f32" -- fp32 operands (default; what the parity tests pin), or "f16" -- operands rounded to fp16,
@@ -195,6 +208,7 @@ class Net(torch.nn.Module):
                 continue            # layer0 embeds the xyz coordinates themselves (3 -> 24): kept in fp32
             if isinstance(m, (layers.DenseEdgeConv, layers.Conv1d, layers.Conv2d, Level)):
                 m.mlp_precision = precision
+        self.invalidate_weight_caches()
         return self
 
     def _forward_eval(self, xyz, ratio):

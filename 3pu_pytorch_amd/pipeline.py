@@ -317,8 +317,17 @@ class GraphedUpsample(object):
     documented there), so a replayed result is never handed out unchecked.  `check=False` leaves result and check
     to the caller (it must then read BACKEND.graph_dup_events / fps_cluster_faults / net.small_cloud_events itself).
 
-    Weights are read through their storage: in-place updates are seen by the next replay; replacing a parameter
-    tensor, or changing the fold-able prep layers (the folded weights are built at capture), needs a new object."""
+    Weights: the kernels read most parameters through their storage, but the DenseEdgeConv operand tables
+    (layers.DenseEdgeConv._operand_pack) and the folded prep convolutions (Level._fold_plan) are DERIVED blobs built
+    on the host side of a call -- a replay would keep using the blobs of the capture.  So every call compares the
+    parameters' (version counter, address) key with the one recorded at capture and captures again when it changed
+    (optimizer.step(), load_state_dict, `p.copy_()`, a replaced parameter tensor, set_mlp_precision).  Edits through
+    `param.data` bump no counter (neither here nor in the eager caches): call `net.invalidate_weight_caches()` and
+    `GraphedUpsample.invalidate()` after such an edit.
+
+    A captured cluster-form final FPS (csrc/fps_cluster.hip) waits for its member workgroups to be co-resident; a
+    replay that finds the device busy with other streams' work can fault like an eager launch can, which the check
+    below turns into the eager recompute."""
 
     def __init__(self, net, shape, num_point, up_ratio, patch_num_ratio=3, device=None, final_fps=True):
         dev = torch.device(device) if device is not None else next(net.parameters()).device
@@ -330,7 +339,20 @@ class GraphedUpsample(object):
         self.static_in = torch.zeros(self.shape, dtype=torch.float32, device=dev)
         self.static_out = None
         self.graph = None
+        self.weights_key = None
+        self.captures = 0
         self.stream = torch.cuda.Stream(device=dev)
+
+    def _weights_key(self):
+        ps = list(self.net.parameters())
+        return (tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps),
+                tuple(getattr(m, "mlp_precision", None) for m in self.net.modules() if hasattr(m, "mlp_precision")))
+
+    def invalidate(self):
+        """Forget the captured graph (after a weight edit the version counters cannot see)."""
+        self.graph = None
+        self.static_out = None
+        self.weights_key = None
 
     def _body(self):
         return _upsample(self.net, self.static_in, self.num_point, self.up_ratio, self.patch_num_ratio, None,
@@ -353,6 +375,8 @@ class GraphedUpsample(object):
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.static_out = self._body()
+            self.weights_key = self._weights_key()
+            self.captures += 1
         finally:
             if saved is not None:
                 be.optimistic_graph = saved
@@ -362,19 +386,24 @@ class GraphedUpsample(object):
         if tuple(clouds.shape) != self.shape:
             raise ValueError("GraphedUpsample was built for %s, got %s" % (self.shape, tuple(clouds.shape)))
         be = operations.BACKEND
-        if check:
+
+        def clean_counters():
             if hasattr(self.net, "reset_small_cloud_events"):
                 self.net.reset_small_cloud_events()
             if hasattr(be, "graph_dup_events"):
                 be.graph_dup_events(reset=True)
+            if hasattr(be, "fps_cluster_faults"):       # (a fault left by ANY earlier call would send this one to eager)
+                be.fps_cluster_faults(reset=True)
+        if check:
+            clean_counters()
         self.static_in.copy_(clouds)
+        if self.graph is not None and self.weights_key != self._weights_key():
+            self.graph = None                           # the packed / folded weight blobs of the capture are stale
         if self.graph is None:
             self._capture()
             if check:           # (the warm-up and the capture itself ran the kernels: start from clean counters)
-                if hasattr(self.net, "reset_small_cloud_events"):
-                    self.net.reset_small_cloud_events()
-                if hasattr(be, "graph_dup_events"):
-                    be.graph_dup_events(reset=True)
+                torch.cuda.synchronize(self.static_in.device)
+                clean_counters()
         self.graph.replay()
         if check:
             torch.cuda.synchronize(self.static_in.device)

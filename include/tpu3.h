@@ -488,6 +488,11 @@ int tpu3_debug_fps_tile_stats(unsigned long long *stats);
  * words: waves, tiles searched, tiles tested query by query, tiles per point set (summed over the waves).  One-shot;
  * host-side state only. */
 int tpu3_debug_knn_tiles_stats(unsigned *words);
+/* tpu3_debug_knn_slab_launches: how many self-graph calls took the SLAB form (knn_slab_order_kernel +
+ * knn_graph_slab_kernel: k = 33, 24 channels, 64 < n <= 320, a launch large enough for one workgroup per patch) since
+ * the last reset -- the dispatcher gives small launches a wave per workgroup and the one-pass kernel, so a test of the
+ * slab form must check that it ran it (r6: the r5 slab tests did not). */
+long tpu3_debug_knn_slab_launches(int reset);
 /* tpu3_debug_fps_cluster: workgroups per point set of the tile-form FPS for the calls that follow: -1 = the default
  * policy (several compute units per set when the launch is small: 16 workgroups per set for up to 4 sets, 8 for up
  * to 8, 32 for one or two sets beyond 2 M points; b * G <= 64), 0 = single-workgroup kernels only, 2 / 4 / ... / 64 =

@@ -616,6 +616,56 @@ def test_knn_graph_one_pass_settles_boundary_collisions(orc, dev):
     assert per[0] == 0 and per[3] == 0, per              # generic rows and the line never need the exact path
 
 
+def _slab_graph(ops, dev, x, optimistic=True):
+    """knn_graph(33, x) on a launch LARGE ENOUGH for the dispatcher to pick the slab form (one workgroup per patch:
+    more than 8 waves per compute unit in the launch, csrc/knn.hip kg_graph_threads) -- the batch is padded with
+    repeats of itself -- and the proof that it did (tpu3_debug_knn_slab_launches).  Returns (idx of the first
+    len(x) patches, exact-path events of the call)."""
+    lib = pkg("_lib").lib()
+    b, n, _ = x.shape
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    need = 8 * cus // ((n + 63) // 64) + 1
+    reps = (need + b - 1) // b
+    xt = _t(np.ascontiguousarray(np.tile(x, (reps, 1, 1))), dev)
+    lib.tpu3_debug_knn_slab_launches(1)
+    ops.BACKEND.graph_dup_events(reset=True)
+    idx = ops.BACKEND.knn_graph(33, xt, optimistic=optimistic).cpu().numpy()
+    ev = ops.BACKEND.graph_dup_events(reset=True)
+    # (the exact form of a small patch may go through the de-duplication pre-pass + two-pass kernel instead)
+    assert lib.tpu3_debug_knn_slab_launches(1) >= 1 or not optimistic, "the launch did not take the slab form"
+    if ev == 0 or not optimistic:                    # (an optimistic result that raised the event is not final)
+        for r in range(1, reps):                     # every copy of a patch gets the same neighbour SETS
+            np.testing.assert_array_equal(np.sort(idx[r * b:(r + 1) * b, :, 1:], -1), np.sort(idx[:b, :, 1:], -1),
+                                          err_msg="copy %d of the batch" % r)
+    return idx[:b], ev
+
+
+def test_knn_graph_slab_form_cluster_inside_one_bin(orc, dev):
+    """(r6, advisor finding on r5) The slab form's pre-pass only BINS the rows along its direction; inside a bin the
+    order is the arrival order of the atomics.  A dense cluster narrower than a bin can therefore put a chunk of rows
+    with larger t in front of a chunk with smaller t, and a closing test on each chunk's own range skipped the second
+    one -- a wrong neighbour set with no event raised.  tests/slab_cases.py builds exactly that (the cluster's rows are
+    consecutive original rows, high-t rows first or last; a sweep of the far rows moves the bin grid so that some cases
+    have the whole cluster in one bin); every patch must come out as the oracle's set WITHOUT an exact-path event (an
+    event would hide the defect behind the recomputation).  The numpy twin (test_knn_slab_bound_cpu.py) shows the
+    per-chunk table failing on these inputs and the suffix-min / prefix-max table not; on the device a build with the
+    per-chunk table (-DKG_SLAB_OWN_TABLE, tools/_ab/slab_ab.sh) fails this test."""
+    from slab_cases import sparse_line_with_one_bin_cluster
+    ops = pkg("network.operations")
+    rng = np.random.default_rng(3)
+    for n in (312, 320, 257, 200):
+        xs = []
+        for far_lo in np.arange(40.0, 72.0, 2.0):
+            xs.append(sparse_line_with_one_bin_cluster(rng, n=n, far_lo=float(far_lo), highs_first=True))
+            xs.append(sparse_line_with_one_bin_cluster(rng, n=n, far_lo=float(far_lo), highs_first=False))
+        x = np.stack(xs)
+        ri, _ = orc.knn(33, x, x, True)
+        opt, ev = _slab_graph(ops, dev, x)
+        assert ev == 0
+        np.testing.assert_array_equal(opt[:, :, 0], ri[:, :, 0])
+        np.testing.assert_array_equal(np.sort(opt[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
+
+
 @pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 257, 312, 320])
 def test_knn_graph_slab_form_on_low_dimensional_rows(orc, dev, n):
     """The slab form of the self graph (csrc/knn.hip, knn_graph_slab_kernel: k = 33, 24 channels, one tile) orders a
@@ -624,7 +674,9 @@ def test_knn_graph_slab_form_on_low_dimensional_rows(orc, dev, n):
     linear map (what layer0 produces), the same with a relu (what the prep layers produce), rows on a LINE (the
     projected gap equals the true distance: the rounding margins E1 / E2 carry the whole proof), two far-apart
     clusters, one huge outlier row, and coordinates around 1e3 (|x|^2 ~ 1e7: large cancellation in the expanded-form
-    distance).  Every result must be the oracle's set, for every patch size between one and five waves."""
+    distance).  Every result must be the oracle's set, for every patch size between one and five waves.
+    (r6) Every launch is padded until the dispatcher really takes the slab form, and says so -- in r5 these calls
+    (1 and 8 patches) were small enough to be given the one-pass kernel, and the test tested that one."""
     ops = pkg("network.operations")
     rng = np.random.default_rng(n)
     c, k = 24, 33
@@ -645,20 +697,18 @@ def test_knn_graph_slab_form_on_low_dimensional_rows(orc, dev, n):
     x[7] = rng.standard_normal((n, c)).astype(np.float32)                 # nothing to skip
     x = np.ascontiguousarray(x)
     ri, _ = orc.knn(k, x, x, True)
-    ops.BACKEND.graph_dup_events(reset=True)
     for i in range(x.shape[0]):
-        opt = ops.BACKEND.knn_graph(k, _t(x[i:i + 1], dev), optimistic=True).cpu().numpy()
-        ev = ops.BACKEND.graph_dup_events(reset=True)
+        opt, ev = _slab_graph(ops, dev, x[i:i + 1])
         if i in (0, 1, 2, 7):
             assert ev == 0, (i, ev)
         elif ev:
             # exact ties on the line, truncated distances of 0 at coordinates of 50 .. 1e4: the kernel may
             # legitimately ask for the exact path (like the one-pass kernel it replaces)
-            opt = ops.BACKEND.knn_graph(k, _t(x[i:i + 1], dev), optimistic=False).cpu().numpy()
+            opt, _ = _slab_graph(ops, dev, x[i:i + 1], optimistic=False)
         np.testing.assert_array_equal(opt[:, :, 0], ri[i:i + 1, :, 0], err_msg="rows %d" % i)
         np.testing.assert_array_equal(np.sort(opt[:, :, 1:], -1), np.sort(ri[i:i + 1, :, 1:], -1), err_msg="rows %d" % i)
-    # all eight at once (one workgroup per patch)
-    both = ops.BACKEND.knn_graph(k, _t(x, dev), optimistic=False).cpu().numpy()
+    # all eight at once
+    both, _ = _slab_graph(ops, dev, x, optimistic=False)
     np.testing.assert_array_equal(np.sort(both[:, :, 1:], -1), np.sort(ri[:, :, 1:], -1))
 
 

@@ -588,6 +588,43 @@ def test_graphed_upsample_equals_eager(dev):
         fast(torch.zeros(1, 3, 4000, device=dev))
 
 
+def test_graphed_upsample_sees_weight_updates(dev):
+    """(r6, advisor finding on r5) The fused DenseEdgeConv kernels read a PACKED operand blob and the folded prep
+    weights, both built on the host side of a call; a hipGraph replay would keep using the blobs of the capture.
+    GraphedUpsample compares the parameters' version key on every call and captures again: after an in-place update of
+    EVERY parameter (what optimizer.step() / load_state_dict do) the replay must equal the eager call with the new
+    weights, and must differ from the result under the old ones; a stale fault count left behind by an earlier call
+    must not send a replay to the eager path."""
+    pipe, ops = pkg("pipeline"), pkg("network.operations")
+    net = _net(dev)
+    x = torch.from_numpy(np.ascontiguousarray(sphere(71, 5000).transpose(0, 2, 1))).to(dev)
+    fast = pipe.GraphedUpsample(net, (1, 3, 5000), 312, 16, 3)
+    before = fast(x, clone=True)
+    assert fast.captures == 1
+    assert torch.equal(fast(x, clone=True), before) and fast.captures == 1
+    saved = [p.detach().clone() for p in net.parameters()]
+    try:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.01)
+        after = fast(x, clone=True)
+        assert fast.captures == 2
+        assert torch.equal(after, pipe.upsample(net, x, 312, 16, 3))
+        assert not torch.equal(after, before)
+        # an edit the version counters cannot see: the documented hooks
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), saved):
+                p.data.copy_(q)
+        net.invalidate_weight_caches()
+        fast.invalidate()
+        assert torch.equal(fast(x, clone=True), before) and fast.captures == 3
+    finally:
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), saved):
+                p.copy_(q)
+        net.invalidate_weight_caches()
+
+
 def test_pipeline_recomputes_when_a_cluster_fps_launch_faults(dev):
     """The final FPS of one cloud runs on 16 workgroups that spin on each other (csrc/fps_cluster.hip).  With a member
     made absent (tpu3_debug_fps_cluster_absent: it leaves at once, as if it had never become resident) the others give
