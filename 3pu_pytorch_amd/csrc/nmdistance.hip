@@ -303,6 +303,11 @@ int nm_dir(hipStream_t s, int b, int n, int m, const float *a, const float *bb, 
 
 } // namespace
 
+// csrc/nmdist_grid.hip: the same result by a search pruned in space (large clouds)
+bool tpu3_nmdist_takes_grid(int b, int n, int m);
+int tpu3_nmdist_grid_forward(hipStream_t s, int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                             float *dist2, int32_t *idx1, int32_t *idx2);
+
 extern "C" int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
                                    const float *xyz2, float *dist1, float *dist2, int32_t *idx1,
                                    int32_t *idx2)
@@ -313,6 +318,8 @@ extern "C" int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, co
     if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return TPU3_EINVAL;
     if (b > 65535) return TPU3_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
+    if (tpu3_nmdist_takes_grid(b, n, m))
+        return tpu3_nmdist_grid_forward(s, b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2);
     int r = nm_dir(s, b, n, m, xyz1, xyz2, dist1, idx1);
     if (r) return r;
     return nm_dir(s, b, m, n, xyz2, xyz1, dist2, idx2);

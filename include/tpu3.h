@@ -104,6 +104,14 @@ int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *
                         const float *xyz2, float *dist1, float *dist2, int32_t *idx1,
                         int32_t *idx2);
 
+/* Which kernel family tpu3_nmdist_fwd_f32 uses for the calls that follow: -1 = automatic (the brute-force scan of the
+ * reference for small sets, the grid-pruned search of csrc/nmdist_grid.hip -- same distances, same indices, exact ties
+ * included -- when both sets hold >= 2048 points and n * m >= 1.6e7), 0 = always the scan, 1 = the grid form whenever
+ * both sets hold >= 128 points.  Returns the previous setting.  tpu3_debug_nmdist_grid_calls: forward calls that took
+ * the grid form since the last reset (tests assert that they exercise it). */
+int tpu3_debug_nmdist_form(int form);
+long tpu3_debug_nmdist_grid_calls(int reset);
+
 /* losses.nmdistance_backward  (losses/nmdistance.cpp:17-21,26; nmdistance_cuda.cu:154-193).
  * Adds into caller-zeroed gradxyz1 (b,n,3), gradxyz2 (b,m,3). */
 int tpu3_nmdist_bwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *xyz1,
