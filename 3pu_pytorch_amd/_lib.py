@@ -34,6 +34,7 @@ SIGNATURES = {
     "tpu3_nmdist_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_debug_nmdist_form": (_i, [_i]),
     "tpu3_debug_nmdist_grid_calls": (ctypes.c_long, [_i]),
+    "tpu3_debug_nmdist_grid_stats": (_i, [_vp]),
     "tpu3_nmdist_bwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpu3_chamfer_reduce_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "tpu3_knn_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp,

@@ -41,6 +41,7 @@ namespace {
 constexpr int NMG_TILE = 64;            // rows per tile = lanes per wave
 constexpr int NMG_SUPER = 64;           // tiles per super-tile
 constexpr int NMG_SCAN = 1024;          // cells per block of the scan
+constexpr int NMG_MAX_PARTS = 2048;     // scan blocks per set: G <= 128
 
 struct NmgArgs {
     int b, n, m;                        // batch elements, |set 0| = n (xyz1), |set 1| = m (xyz2)
@@ -56,6 +57,8 @@ struct NmgArgs {
     float4 *rows;                       // (2b, tmax * 64) x, y, z, original index (bits); pads are NaN
     float *tbox;                        // (2b, tmax, 8)   lo xyz, hi xyz, -, -
     uint32_t *sbox;                     // (2b, smax, 8)   encoded like bbox
+    unsigned long long *stats;          // development probe (tpu3_debug_nmdist_grid_stats) or null: waves, super-tiles
+                                        // and tiles that passed the wave's bound, tiles searched
 };
 
 __device__ __forceinline__ int nmg_count(const NmgArgs &a, int set) { return (set & 1) ? a.m : a.n; }
@@ -66,12 +69,13 @@ __device__ __forceinline__ const float *nmg_points(const NmgArgs &a, int set)
     return (set & 1) ? a.xyz[1] + (size_t)e * a.m * 3 : a.xyz[0] + (size_t)e * a.n * 3;
 }
 
-__device__ __forceinline__ uint32_t nmg_spread6(uint32_t v)
+__device__ __forceinline__ uint32_t nmg_spread(uint32_t v)       // bit i of a <= 10-bit value -> bit 3 i
 {
-    v &= 0x3Fu;
-    v = (v | (v << 8)) & 0x300Fu;
-    v = (v | (v << 4)) & 0x30C3u;
-    v = (v | (v << 2)) & 0x9249u;
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
 
@@ -88,7 +92,7 @@ __device__ __forceinline__ int nmg_cell(const NmgArgs &a, int e, float x, float 
         const float sc = ext > 0.f ? (float)a.G / ext : 0.f;
         float f = (p[c] - lo) * sc;
         f = fminf(fmaxf(f, 0.f), (float)(a.G - 1));
-        code |= nmg_spread6((uint32_t)(int)f) << c;
+        code |= nmg_spread((uint32_t)(int)f) << c;
     }
     return (int)code;
 }
@@ -96,6 +100,7 @@ __device__ __forceinline__ int nmg_cell(const NmgArgs &a, int e, float x, float 
 // ---- build ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nmg_bbox_kernel(NmgArgs a)
 {
+    __shared__ uint32_t red[4][6];
     const int set = blockIdx.y, e = set >> 1;
     const int cnt = nmg_count(a, set);
     const float *P = nmg_points(a, set);
@@ -109,14 +114,19 @@ __global__ __launch_bounds__(256) void nmg_bbox_kernel(NmgArgs a)
             hi[c] = fmaxf(hi[c], v);
         }
     }
+    // (one atomic per word and WORKGROUP, few workgroups: 6144 atomics on six addresses took 140 us at 80 000 points)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const uint32_t l = tpu3_wave_max_u32(~tpu3_mono(lo[c])), h = tpu3_wave_max_u32(tpu3_mono(hi[c]));
         if ((threadIdx.x & 63) == 0) {
-            atomicMax(a.bbox + (size_t)e * 8 + c, l);
-            atomicMax(a.bbox + (size_t)e * 8 + 3 + c, h);
+            red[threadIdx.x >> 6][c] = l;
+            red[threadIdx.x >> 6][3 + c] = h;
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        atomicMax(a.bbox + (size_t)e * 8 + threadIdx.x,
+                  max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x])));
 }
 
 __global__ __launch_bounds__(256) void nmg_hist_kernel(NmgArgs a)
@@ -164,13 +174,19 @@ __global__ __launch_bounds__(NMG_SCAN) void nmg_scan_kernel(NmgArgs a)
 // rows in cell order: position = (rows of earlier scan blocks) + (block-local offset of the cell) + arrival rank
 __global__ __launch_bounds__(256) void nmg_scatter_kernel(NmgArgs a)
 {
-    __shared__ int pre[256];            // exclusive prefix of part[] (parts <= 256)
+    constexpr int PPT = NMG_MAX_PARTS / 256;   // parts per thread of the prefix
+    __shared__ int pre[NMG_MAX_PARTS];  // exclusive prefix of part[]
     __shared__ int wtot[4];
     const int set = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
-        const int v = tid < a.parts ? a.part[(size_t)set * a.parts + tid] : 0;
-        int inc = v;
+        int v[PPT], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            v[u] = tid * PPT + u < a.parts ? a.part[(size_t)set * a.parts + tid * PPT + u] : 0;
+            sum += v[u];
+        }
+        int inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(inc, d, 64);
@@ -179,10 +195,14 @@ __global__ __launch_bounds__(256) void nmg_scatter_kernel(NmgArgs a)
         if (lane == 63)
             wtot[wave] = inc;
         __syncthreads();
-        int base = 0;
+        int off = inc - sum;
         for (int w = 0; w < wave; ++w)
-            base += wtot[w];
-        pre[tid] = base + inc - v;
+            off += wtot[w];
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            pre[tid * PPT + u] = off;
+            off += v[u];
+        }
         __syncthreads();
     }
     const int cnt = nmg_count(a, set);
@@ -254,13 +274,15 @@ __device__ __forceinline__ float nmg_point_box(float x, float y, float z, const 
 }
 
 // (d, index) of the lane's point against the 64 rows of one tile, folded into (best, besti) lexicographically.
-// `rows` is wave-uniform: the loads are scalar (s_load_dwordx16: no vector-memory or LDS traffic at all), a candidate
-// costs 3 subtractions and the mul / fma / fma of the reference's expression; eight candidates share one minimum tree,
-// one compare and one branch -- the lexicographic update of the eight runs only when some lane may take one of them.
-__device__ __forceinline__ void nmg_search_tile(const float4 *__restrict__ rows, float x, float y, float z,
-                                                float &best, int &besti)
+// The tile's rows sit in the wave's own 1 KiB of LDS (a wave writes and reads only its own slice, in program order: no
+// barrier); every ds_read_b128 is a broadcast.  A candidate costs 3 subtractions and the mul / fma / fma of the
+// reference's expression; eight candidates share one minimum tree, one compare and one branch -- the lexicographic
+// update of the eight runs only when some lane may take one of them.
+// (First version: the rows through SCALAR loads straight from memory -- zero vector traffic, but eight dependent
+// round trips per tile with nothing to hide them behind at 2.4 waves per SIMD: 7.6 us per tile, 671 us per 80 000^2.)
+__device__ __forceinline__ void nmg_search_tile(const float4 *rows, float x, float y, float z, float &best, int &besti)
 {
-#pragma unroll 1
+#pragma unroll 2
     for (int j = 0; j < NMG_TILE; j += 8) {
         float4 c[8];
         float d[8];
@@ -325,8 +347,20 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
     float best = inf;
     int besti = 0x7FFFFFFF;
     uint32_t U = 0x7F800000u;                                   // bits of the wave's largest best (distances are >= 0)
-    auto search = [&](int t) __attribute__((always_inline)) {
-        nmg_search_tile(CR + (size_t)t * NMG_TILE, me.x, me.y, me.z, best, besti);
+    int st_super = 0, st_tile = 0, st_search = 0;
+    __shared__ float4 stage[4][NMG_TILE];
+    float4 *mine = stage[threadIdx.x >> 6];
+    int pre_t = -1;                                             // the tile whose rows are already on their way
+    float4 pre_row = make_float4(0.f, 0.f, 0.f, 0.f);
+    // search tile t; `next` (>= 0): the tile most likely to be searched after it -- its rows are requested now
+    auto search = [&](int t, int next) __attribute__((always_inline)) {
+        ++st_search;
+        const float4 row = pre_t == t ? pre_row : CR[(size_t)t * NMG_TILE + lane];
+        pre_t = next;
+        if (next >= 0)
+            pre_row = CR[(size_t)next * NMG_TILE + lane];
+        mine[lane] = row;
+        nmg_search_tile(mine, me.x, me.y, me.z, best, besti);
         U = tpu3_wave_max_u32(live ? __float_as_uint(best) : 0u);
     };
     // ---- seed: the tile with the smallest bound (any of them), so that U is tight before the sweep ----
@@ -344,36 +378,58 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
         const float lb = tile_bound(s * NMG_SUPER + lane);
         const uint32_t key = s * NMG_SUPER + lane < tiles ? ((__float_as_uint(lb) >> 6) << 6) | (uint32_t)lane : 0xFFFFFFFFu;
         seed = s * NMG_SUPER + (int)(tpu3_wave_min_u32(key) & 63u);
-        search(seed);
+        search(seed, -1);
     }
-    // ---- sweep: super-tiles -> tiles -> lanes ----
-    for (int s0 = 0; s0 < supers; s0 += 64) {
-        const float lbs = super_bound(s0 + lane);
-        // (the index tests matter: with U = Inf -- a lane whose distances are all NaN or Inf -- nothing is "above")
-        uint64_t smask = __builtin_amdgcn_ballot_w64(s0 + lane < supers && !(lbs > __uint_as_float(U)));
-        while (smask) {
-            const int sb = __builtin_ctzll(smask);
-            smask &= smask - 1;
-            const int s = s0 + sb;
-            const float lbt = tile_bound(s * NMG_SUPER + lane);
-            uint64_t tmask = __builtin_amdgcn_ballot_w64(s * NMG_SUPER + lane < tiles && !(lbt > __uint_as_float(U)));
-            while (tmask) {
-                const int tb = __builtin_ctzll(tmask);
-                tmask &= tmask - 1;
-                const int t = s * NMG_SUPER + tb;
-                if (t == seed)
-                    continue;
-                // U has shrunk since the ballot?  then the tile's own bound decides again, for the whole wave
-                const float lbw = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lbt), tb));
-                if (lbw > __uint_as_float(U))
-                    continue;
-                const float *b = CB + (size_t)t * 8;
-                NmgBox bx;
-                bx.lx = b[0]; bx.ly = b[1]; bx.lz = b[2]; bx.hx = b[3]; bx.hy = b[4]; bx.hz = b[5];
-                const float lb = nmg_point_box(me.x, me.y, me.z, bx);
-                if (!__builtin_amdgcn_ballot_w64(live && !(lb > best)))
-                    continue;
-                search(t);
+    // ---- sweep: super-tiles -> tiles -> lanes, in two passes ----
+    // pass 0: the tiles whose box OVERLAPS the wave's box (bound exactly 0) -- after it every lane has seen its own
+    // surroundings and its best is close to final; pass 1: the others, against a U that is tight by then.  (One pass in
+    // index order searched 59 tiles per wave at 1.28 M points: the early tiles of the order are judged against the
+    // seed tile's distances only.)  A NaN bound belongs to pass 1 and is never "above".
+    auto lane_value = [](float v, int l) __attribute__((always_inline)) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int s0 = 0; s0 < supers; s0 += 64) {
+            const float lbs = super_bound(s0 + lane);
+            // (the index tests matter: with U = Inf -- a lane whose distances are all NaN or Inf -- nothing is "above")
+            const bool s_now = pass == 0 ? lbs <= 0.f : !(lbs > __uint_as_float(U));
+            uint64_t smask = __builtin_amdgcn_ballot_w64(s0 + lane < supers && s_now);
+            while (smask) {
+                const int sb = __builtin_ctzll(smask);
+                smask &= smask - 1;
+                const int s = s0 + sb;
+                ++st_super;
+                // the lane's tile of this super-tile: its box stays in registers, the per-tile tests below read it
+                // from the lane (v_readlane) instead of from memory
+                const int tl = s * NMG_SUPER + lane;
+                NmgBox tbx = {inf, inf, inf, -inf, -inf, -inf};
+                if (tl < tiles) {
+                    const float4 lo4 = *(const float4 *)(CB + (size_t)tl * 8);
+                    const float2 hi2 = *(const float2 *)(CB + (size_t)tl * 8 + 4);
+                    tbx.lx = lo4.x; tbx.ly = lo4.y; tbx.lz = lo4.z; tbx.hx = lo4.w; tbx.hy = hi2.x; tbx.hz = hi2.y;
+                }
+                const float lbt = nmg_box_box(qb, tbx);
+                const bool t_now = pass == 0 ? lbt <= 0.f : (!(lbt <= 0.f) && !(lbt > __uint_as_float(U)));
+                uint64_t tmask = __builtin_amdgcn_ballot_w64(tl < tiles && tl != seed && t_now);
+                while (tmask) {
+                    const int tb = __builtin_ctzll(tmask);
+                    tmask &= tmask - 1;
+                    const int t = s * NMG_SUPER + tb;
+                    // U has shrunk since the ballot?  then the tile's own bound decides again, for the whole wave
+                    if (lane_value(lbt, tb) > __uint_as_float(U))
+                        continue;
+                    ++st_tile;
+                    NmgBox bx;
+                    bx.lx = lane_value(tbx.lx, tb); bx.ly = lane_value(tbx.ly, tb); bx.lz = lane_value(tbx.lz, tb);
+                    bx.hx = lane_value(tbx.hx, tb); bx.hy = lane_value(tbx.hy, tb); bx.hz = lane_value(tbx.hz, tb);
+                    const float lb = nmg_point_box(me.x, me.y, me.z, bx);
+                    if (!__builtin_amdgcn_ballot_w64(live && !(lb > best)))
+                        continue;
+                    // the next surviving tile of this super-tile is the likely successor: its rows are requested now
+                    search(t, tmask ? s * NMG_SUPER + __builtin_ctzll(tmask) : -1);
+                }
             }
         }
     }
@@ -386,6 +442,12 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
             besti = 0;
         }
     }
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats + 0, 1ull);
+        atomicAdd(a.stats + 1, (unsigned long long)st_super);
+        atomicAdd(a.stats + 2, (unsigned long long)st_tile);
+        atomicAdd(a.stats + 3, (unsigned long long)st_search);
+    }
     if (live) {
         const int j = __float_as_int(me.w);
         a.dist[dir][(size_t)e * nq + j] = best;
@@ -393,6 +455,7 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
     }
 }
 
+unsigned long long *g_nmdist_stats = nullptr;
 int g_nmdist_form = -1;                 // tpu3_debug_nmdist_form: -1 automatic, 0 scan, 1 grid
 long g_nmdist_grid_calls = 0;
 
@@ -406,6 +469,12 @@ extern "C" int tpu3_debug_nmdist_form(int form)
     if (form >= -1 && form <= 1)
         g_nmdist_form = form;
     return old;
+}
+
+extern "C" int tpu3_debug_nmdist_grid_stats(unsigned long long *stats)
+{
+    g_nmdist_stats = stats;
+    return TPU3_OK;
 }
 
 extern "C" long tpu3_debug_nmdist_grid_calls(int reset)
@@ -436,7 +505,8 @@ int tpu3_nmdist_grid_forward(hipStream_t s, int b, int n, int m, const float *xy
     NmgArgs a;
     a.b = b; a.n = n; a.m = m;
     a.pmax = max(n, m);
-    a.G = a.pmax >= 32768 ? 64 : (a.pmax >= 4096 ? 32 : 16);
+    // cells per axis: ~n / 24 occupied cells on a surface-like cloud (3 G^2 of the G^3), i.e. a handful of rows per cell
+    a.G = a.pmax >= 400000 ? 128 : (a.pmax >= 32768 ? 64 : (a.pmax >= 4096 ? 32 : 16));
     a.cells = a.G * a.G * a.G;
     a.parts = a.cells / NMG_SCAN;
     a.tmax = (a.pmax + NMG_TILE - 1) / NMG_TILE;
@@ -467,8 +537,9 @@ int tpu3_nmdist_grid_forward(hipStream_t s, int b, int n, int m, const float *xy
     a.cellrank = (int2 *)(ws + o_cr);
     a.rows = (float4 *)(ws + o_rows);
     a.tbox = (float *)(ws + o_tbox);
+    a.stats = g_nmdist_stats;
     const unsigned pblocks = (unsigned)min((a.pmax + 255) / 256, 2048);
-    hipLaunchKernelGGL(nmg_bbox_kernel, dim3(min(pblocks, 256u), (unsigned)sets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nmg_bbox_kernel, dim3(min(pblocks, 64u), (unsigned)sets), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nmg_hist_kernel, dim3(pblocks, (unsigned)sets), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nmg_scan_kernel, dim3((unsigned)a.parts, (unsigned)sets), dim3(NMG_SCAN), 0, s, a);
     hipLaunchKernelGGL(nmg_scatter_kernel, dim3(pblocks, (unsigned)sets), dim3(256), 0, s, a);

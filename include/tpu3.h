@@ -110,6 +110,9 @@ int tpu3_nmdist_fwd_f32(tpu3_stream_t stream, int b, int n, int m, const float *
  * both sets hold >= 128 points.  Returns the previous setting.  tpu3_debug_nmdist_grid_calls: forward calls that took
  * the grid form since the last reset (tests assert that they exercise it). */
 int tpu3_debug_nmdist_form(int form);
+/* tpu3_debug_nmdist_grid_stats: grid-form calls that follow ADD to four device u64 words: query waves, super-tiles and
+ * tiles that passed a wave's bound, tiles searched (NULL switches the probe off; tools/chamfer_probe.py). */
+int tpu3_debug_nmdist_grid_stats(unsigned long long *stats);
 long tpu3_debug_nmdist_grid_calls(int reset);
 
 /* losses.nmdistance_backward  (losses/nmdistance.cpp:17-21,26; nmdistance_cuda.cu:154-193).

@@ -58,6 +58,16 @@ for B, n, m in ((32, 624, 624), (32, 2496, 2496), (32, 4992, 4992), (1, 5000, 50
             with torch.no_grad():
                 t = timeit(lambda: ml.nndistance(a, b))
         row += "   %s %9.3f ms (%6.1f TFLOP/s on the 16 n m model = %5.2f of 157.3)" % (name, t, flop / t / 1e9, flop / t / 1e9 / 157.3)
+    if n >= 2048:
+        st = torch.zeros(4, dtype=torch.int64, device=dev)
+        lib.tpu3_debug_nmdist_form(1)
+        lib.tpu3_debug_nmdist_grid_stats(st.data_ptr())
+        with torch.no_grad():
+            ml.nndistance(a, b)
+        torch.cuda.synchronize()
+        lib.tpu3_debug_nmdist_grid_stats(None)
+        w, ss, tt, sr = [int(v) for v in st.cpu()]
+        row += "   [per query wave: %.1f super-tiles, %.1f tiles pass the wave bound, %.1f searched]" % (ss / w, tt / w, sr / w)
     lib.tpu3_debug_nmdist_form(-1)
     lib.tpu3_debug_nmdist_grid_calls(1)
 
