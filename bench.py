@@ -19,7 +19,9 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
   roofline          the kernel that BOUNDS the step: the largest entry of `rooflines_other` by ms_per_step (round 4:
                     dec_fused4_kernel, fp32 MFMA) with per-launch averages and the PMC traffic per launch
   roofline_step     the whole step against the chip: executed MFMA FLOP and counter bytes / ms_per_step
-  rooflines_other   every hand-written kernel of a step, timed with events on its launch stream: MFMA kernels on
+  rooflines_other   (r6: followed by the point-set kernels OUTSIDE the step -- nm-distance forward in both forms / backward,
+                    ball query, gather forward / backward -- as `ms_per_call` entries with `ms_per_step` null)
+                    every hand-written kernel of a step, timed with events on its launch stream: MFMA kernels on
                     EXECUTED matrix-core FLOPs, the kNN graph on the (2C+3) VALU model, HBM kernels on algorithmic
                     bytes; the final FPS as a LATENCY entry (rounds, us_per_round, x_over_floor -- it runs hidden on
                     a side stream and bounds nothing)
@@ -436,6 +438,133 @@ def extras_block(args, ops, pipe, ups, net, clouds, dev, N, npnt, r, nets=None, 
     return ex
 
 
+def point_kernel_rooflines(dev, reps=7):
+    """(r6) The point-set kernels of the C ABI that are NOT launched by an inference step -- nm-distance forward /
+    backward (the metric's Chamfer and the training loss), ball query, gather forward / backward -- each at the sizes
+    SURVEY 8(a) names, timed with HIP events on the launch stream (median of `reps` calls after a warm-up) and priced
+    with SURVEY 8(d)'s formulas: nm-distance forward against the 157.3 TF fp32 vector peak on 2*B*n*m*8 FLOP (for the
+    grid-pruned form also the EXECUTED pair evaluations from the kernel's own counters: it is a work-skipping exact
+    search, so its fraction of the scan's model may exceed 1), the others against 8 TB/s on their algorithmic bytes.
+    Several of these are a few microseconds long: launch-bound, and reported as such."""
+    import ctypes
+    sampling, losses, tlib = pkg("sampling"), pkg("losses"), pkg("_lib").lib()
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def sphere(b, n, scale=1.0):
+        x = torch.randn((b, n, 3), device=dev, generator=g)
+        return (x / x.norm(dim=2, keepdim=True) * scale).contiguous()
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts)), [float(min(ts)), float(max(ts))]
+
+    out = []
+    note = "not part of an inference step: ms_per_call of one C-ABI call on an otherwise idle device"
+    # ---- nm-distance forward: both forms at every size --------------------------------------------------------------
+    for b, n, m in ((32, 624, 624), (32, 4992, 4992), (1, 80000, 80000)):
+        x1, x2 = sphere(b, n), sphere(b, m, 1.01)
+        d1, d2 = torch.empty((b, n), device=dev), torch.empty((b, m), device=dev)
+        i1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+        i2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+        flop = 2.0 * b * n * m * 8
+        auto_grid = None
+        for form in (-1, 0, 1):
+            tlib.tpu3_debug_nmdist_form(form)
+            tlib.tpu3_debug_nmdist_grid_calls(1)
+            try:
+                ms, mm = timed(lambda: losses.nmdistance_forward(x1, x2, d1, d2, i1, i2))
+                took_grid = tlib.tpu3_debug_nmdist_grid_calls(1) > 0
+                if form == -1:
+                    auto_grid = took_grid
+                    continue
+                if form == 1 and not took_grid:
+                    continue
+                ent = {"kernel": ("nmg_query_kernel + 5 build kernels (csrc/nmdist_grid.hip: grid-pruned exact search)"
+                                  if took_grid else "nmdist_fwd_kernel / nmdist_fwd_split_kernel (csrc/nmdistance.hip: the reference's scan)"),
+                       "call": "tpu3_nmdist_fwd_f32(b=%d, n=%d, m=%d), both directions" % (b, n, m),
+                       "form": "grid" if took_grid else "scan", "automatic_choice": auto_grid == took_grid,
+                       "ms_per_call": ms, "ms_per_call_min_max": mm, "ms_per_step": None, "scope": note,
+                       "bound": "valu", "unit": "TFLOP/s", "peak": FP32_PEAK_TF,
+                       "model_flop_per_call": flop, "achieved": flop / (ms * 1e-3) / 1e12,
+                       "frac": flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                       "algorithmic_bytes_per_call": 20.0 * b * (n + m),
+                       "basis": "SURVEY 8(d): 2*B*n*m*8 FLOP (3 sub, mul, 2 fma, compare per pair and direction) / call time"}
+                if took_grid:
+                    st = torch.zeros(4, dtype=torch.int64, device=dev)
+                    tlib.tpu3_debug_nmdist_grid_stats(ctypes.c_void_p(st.data_ptr()))
+                    losses.nmdistance_forward(x1, x2, d1, d2, i1, i2)
+                    torch.cuda.synchronize()
+                    tlib.tpu3_debug_nmdist_grid_stats(None)
+                    waves, _, passed, searched = [int(v) for v in st.cpu()]
+                    ex = searched * 64.0 * 64.0 * 8
+                    ent.update({"tiles_searched_per_query_wave": searched / max(waves, 1),
+                                "tiles_tested_per_query_wave": passed / max(waves, 1),
+                                "executed_flop_per_call": ex, "executed_frac": ex / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                                "frac_note": "`frac` prices the call on the SCAN's model (what the reference executes); "
+                                             "the search evaluates %.2f %% of those pairs -- same distances and indices"
+                                             % (100.0 * ex / flop)})
+                out.append(ent)
+            finally:
+                tlib.tpu3_debug_nmdist_form(-1)
+    # ---- nm-distance backward ----------------------------------------------------------------------------------------
+    for b, n, m in ((32, 624, 624), (1, 80000, 80000)):
+        x1, x2 = sphere(b, n), sphere(b, m, 1.01)
+        d1, d2 = torch.empty((b, n), device=dev), torch.empty((b, m), device=dev)
+        i1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+        i2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+        losses.nmdistance_forward(x1, x2, d1, d2, i1, i2)
+        g1, g2 = torch.ones_like(d1), torch.ones_like(d2)
+        gx1, gx2 = torch.zeros_like(x1), torch.zeros_like(x2)
+        ms, mm = timed(lambda: losses.nmdistance_backward(x1, x2, gx1, gx2, g1, g2, i1, i2))
+        byts = float(b) * (n + m) * (12 + 12 + 4 + 4 + 24)
+        out.append({"kernel": "nmdist_bwd_kernel x 2 (csrc/nmdistance.hip)", "call": "tpu3_nmdist_bwd_f32(b=%d, n=%d, m=%d)" % (b, n, m),
+                    "ms_per_call": ms, "ms_per_call_min_max": mm, "ms_per_step": None, "scope": note, "bound": "hbm",
+                    "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_call": byts,
+                    "achieved": byts / (ms * 1e-3) / 1e9, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "basis": "SURVEY 8(d): B*(n+m)*(12+12+4+4 + 24 atomic) B / call time (fp32 atomics into L2; two launches)"})
+    # ---- ball query (exported by the reference, called by nothing in it: sampling.cpp:59-81) --------------------------------
+    b, m, n, ns = 48, 312, 5000, 32
+    xyz, q = sphere(b, n), sphere(b, m)
+    ms, mm = timed(lambda: sampling.ball_query(q, xyz, 0.1, ns))
+    byts = float(b) * (12 * n + 12 * m + 4 * m * ns)
+    out.append({"kernel": "ball_query_kernel (csrc/ball_query.hip)", "call": "tpu3_ball_query(b=%d, m=%d, n=%d, r=0.1, nsample=%d)" % (b, m, n, ns),
+                "ms_per_call": ms, "ms_per_call_min_max": mm, "ms_per_step": None, "scope": note, "bound": "hbm", "unit": "GB/s",
+                "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_call": byts, "achieved": byts / (ms * 1e-3) / 1e9,
+                "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "basis": "SURVEY 8(d): B*(12N + 12M + 4*M*nsample) B / call time (incl. the result tensor's allocation; "
+                         "the kernel itself scans N candidates per query: %.1f G pair tests" % (b * m * n / 1e9)})
+    # ---- gather forward / backward (sampling.cpp:37-53) -------------------------------------------------------------
+    for b, c, n, m in ((1, 3, 239616, 80000), (48, 3, 24960, 4992)):
+        pts = torch.randn((b, c, n), device=dev, generator=g)
+        idx = torch.randint(0, n, (b, m), device=dev, generator=g, dtype=torch.int32)
+        outp = torch.empty((b, c, m), device=dev)
+        ms, mm = timed(lambda: sampling.gather_forward(b, c, n, m, pts, idx, outp))
+        byts = float(b) * c * (4 * m + 4 * m) + 4.0 * b * m
+        out.append({"kernel": "gather_fwd_kernel (csrc/gather.hip)", "call": "tpu3_gather_fwd(b=%d, c=%d, n=%d, npoints=%d)" % (b, c, n, m),
+                    "ms_per_call": ms, "ms_per_call_min_max": mm, "ms_per_step": None, "scope": note, "bound": "hbm", "unit": "GB/s",
+                    "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_call": byts, "achieved": byts / (ms * 1e-3) / 1e9,
+                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "basis": "SURVEY 8(d): B*C*(4m read-gather + 4m write) + 4*B*m B / call time"})
+        go = torch.randn((b, c, m), device=dev, generator=g)
+        gp = torch.zeros((b, c, n), device=dev)
+        ms, mm = timed(lambda: sampling.gather_backward(b, c, n, m, go, idx, gp))
+        out.append({"kernel": "gather_bwd_kernel (csrc/gather.hip)", "call": "tpu3_gather_bwd(b=%d, c=%d, n=%d, npoints=%d)" % (b, c, n, m),
+                    "ms_per_call": ms, "ms_per_call_min_max": mm, "ms_per_step": None, "scope": note, "bound": "hbm", "unit": "GB/s",
+                    "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_call": byts, "achieved": byts / (ms * 1e-3) / 1e9,
+                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "basis": "SURVEY 8(d): the forward's bytes, the writes as fp32 atomics into the zeroed gradient / call time"})
+    return out
+
+
 def train_rooflines(ops, ups, dev, ratio=16, reps=3):
     """Config C3 (BASELINE: one training step, batch 32 patches of 312 points, up_ratio 16, Chamfer fwd + bwd): an
     EAGER step with events around the hand-written training kernels (a hipGraph replay cannot be bracketed per
@@ -815,6 +944,13 @@ def main():
             except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
                 fps_entry["rounds"] = "failed: %s" % (str(e).splitlines()[0][:120])
         line["rooflines_other"] = others + [fps_entry]
+        if not args.no_extras and not args.diag_skip_final_fps and not patch_mode:
+            # (r6) the point-set kernels of the C ABI outside the inference step: nm-distance fwd / bwd, ball query, gather
+            try:
+                line["rooflines_other"] += point_kernel_rooflines(dev)
+            except Exception as e:                                           # noqa: BLE001 (reported, not hidden)
+                line["rooflines_other"].append({"kernel": "point kernels (nm-distance, ball query, gather)",
+                                                "failed": str(e).splitlines()[0][:160]})
         # --- `roofline`: the kernel that bounds the step = the largest entry by ms_per_step that has a hardware bound
         bounded = [o for o in others if o.get("frac") is not None]
         if bounded:

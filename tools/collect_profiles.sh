@@ -25,7 +25,22 @@ pass WRITE_SIZE WRITE_SIZE
 pass SQ_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA
 pass SQ_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY
 pass GRBM GRBM_GUI_ACTIVE GRBM_COUNT
+# (r6) the point-set kernels outside the step -- nm-distance fwd (scan and grid form) / bwd, ball query, gather: kernel
+# stats and three PMC passes of tools/losses_probe.py
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof/l -- python /root/repo/tools/losses_probe.py > /dev/null 2>&1)
+cp $(find gpurun_out/prof/l -name '*kernel_stats.csv' | head -1) $O/kernel_stats_losses.csv
+lpass() { # $1 = tag, rest = counters
+  tag=$1; shift
+  (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /root/repo/gpurun_out/prof/l$tag -- python /root/repo/tools/losses_probe.py --reps 3 > /dev/null 2>&1)
+  f=$(find gpurun_out/prof/l$tag -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python tools/pmc_by_kernel.py $f > $O/pmc_${tag}_losses_by_kernel.txt
+  rm -rf gpurun_out/prof/l$tag
+}
+lpass SQ_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU
+lpass FETCH_SIZE FETCH_SIZE
+lpass WRITE_SIZE WRITE_SIZE
 tail -1 $O/bench_default.json | cut -c1-300
 python tools/kstats.py $O/kernel_stats_single_stream.csv 5 16
+python tools/kstats.py $O/kernel_stats_losses.csv 20 30
 grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|knn_slab\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
 rm -rf gpurun_out/prof
