@@ -206,3 +206,170 @@ def run_chain(ops, net, g, ids, dev, mode):
     finally:
         net.trace = saved
     return chain, levels, out.detach().cpu().numpy()
+
+
+# ---- compact record of ALL outer patches (tests/golden/c2_chain_all*.npz, oracle/make_golden.py make_chain_all_golden) ---------
+# The k = 33 feature graphs and the k = 5 inter-level sets are not stored in full (170 MB for 48 patches) but as a 16-bit
+# hash of every row's set plus the explicit set of every TIGHT row -- a row whose last member and first non-member are
+# closer than tight_tau * max |x|^2 in the reference's own distances, i.e. a row in which another correct fp32
+# evaluation may legitimately choose differently.  Replay = the build's own choice, checked row by row against the
+# reference's hash; a differing row takes the reference's set if it is a tight one and is reported as UNEXPLAINED
+# otherwise (a flip at a clear margin is a finding, not rounding noise).
+SET_HASH_MUL = 40503
+
+
+def set_hash16(idx):
+    """torch (..., k) index sets -> (...,) int64 in [0, 65536): the twin of oracle/make_golden.py set_hash16"""
+    return ((idx.long() + 1) * SET_HASH_MUL).sum(-1) & 0xFFFF
+
+
+class ChainAll(Chain):
+    def __init__(self, ops, g, ids, dev, mode):
+        super(ChainAll, self).__init__(ops, g, ids, dev, mode)
+        self.unexplained = []           # (name, outer patch, inner patch, row): differing rows that are not tight
+        self.forced = {}                # name -> rows that took the reference's set
+        self.hashes = {}                # record mode: name -> [per outer patch (P, 312) hashes]
+        self._tight = {}
+
+    # ---- the record ----------------------------------------------------------------------------------------------
+    def _offset(self, q, l, b, graphs):
+        """start of (level l, block b)'s P_l * 312 hashes in p<q>_gh (graphs) / of level l's in p<q>_fh"""
+        off = 0
+        for ll in ((1, 2, 3, 4) if graphs else (2, 3, 4)):
+            per = self.live(ll, q) * 312
+            if ll == l:
+                return off + ((b - 1) * per if graphs else 0)
+            off += (4 if graphs else 1) * per
+        raise KeyError(l)
+
+    def ref_hashes(self, l, b=None):
+        """(B * P_MAX[l], 312) int64: the reference's set hashes, dead inner-patch slots repeat the last live patch"""
+        rows = []
+        for q in self.ids:
+            live = self.live(l, q)
+            if b is None:
+                flat = np.asarray(self.g["p%d_fh" % q])
+                o = self._offset(q, l, 1, False)
+            else:
+                flat = np.asarray(self.g["p%d_gh" % q])
+                o = self._offset(q, l, b, True)
+            a = flat[o:o + live * 312].reshape(live, 312).astype(np.int64)
+            pad = P_MAX[l] - live
+            if pad:
+                a = np.concatenate([a, np.repeat(a[-1:], pad, axis=0)], axis=0)
+            rows.append(a)
+        return torch.from_numpy(np.concatenate(rows, axis=0)).to(self.dev)
+
+    def tight_sets(self, q, l, b=None):
+        """{(inner patch, row): sorted member array} of the tight rows of (outer patch q, level l[, block b])"""
+        key = (q, l, b)
+        if key not in self._tight:
+            if b is None:
+                t, r = np.asarray(self.g["p%d_ft" % q]), np.asarray(self.g["p%d_fr" % q])
+                sel = np.nonzero(t[:, 0] == l)[0]
+                self._tight[key] = {(int(t[i, 1]), int(t[i, 2])): r[i].astype(np.int64) for i in sel}
+            else:
+                t, r = np.asarray(self.g["p%d_gt" % q]), np.asarray(self.g["p%d_gr" % q])
+                sel = np.nonzero((t[:, 0] == l) & (t[:, 1] == b))[0]
+                self._tight[key] = {(int(t[i, 2]), int(t[i, 3])): r[i].astype(np.int64) for i in sel}
+        return self._tight[key]
+
+    def _settle(self, name, l, b, sets):
+        """sets (B * P_MAX[l], 312, k) the build's own member sets -> list of (batch row, point row, reference set) to
+        force; record mode: keeps the hashes instead."""
+        mine = set_hash16(sets)
+        if self.mode != "replay":
+            h = mine.cpu().numpy()
+            self.hashes[name] = [h[i * P_MAX[l]:(i + 1) * P_MAX[l]] for i in range(self.B)]
+            return []
+        diff = torch.nonzero(mine != self.ref_hashes(l, b)).cpu().numpy()
+        todo = []
+        for r, row in diff:
+            i, p = int(r) // P_MAX[l], int(r) % P_MAX[l]
+            q = self.ids[i]
+            p_live = min(p, self.live(l, q) - 1)
+            ref = self.tight_sets(q, l, b).get((p_live, int(row)))
+            if ref is None:
+                self.unexplained.append((name, q, p_live, int(row)))
+            else:
+                todo.append((int(r), int(row), ref))
+        self.forced[name] = self.forced.get(name, 0) + len(todo)
+        return todo
+
+    # ---- the seams ------------------------------------------------------------------------------------------------
+    def knn_graph(self, k, x, layout=None, optimistic=None):
+        assert k == 33
+        l, b = 1 + self.graph_calls // 4, self.graph_calls % 4 + 1
+        self.graph_calls += 1
+        name = "l%d_graph%d" % (l, b)
+        out = self.real_graph(k, x, layout)
+        assert out.shape[0] == self.B * P_MAX[l], (name, out.shape)
+        for r, row, ref in self._settle(name, l, b, out[:, :, 1:]):
+            out[r, row, 1:] = torch.from_numpy(ref).to(out.device, out.dtype)
+        return out
+
+    def knn_query(self, k, query, points, unique=True, layout=None, want_dist=True, want_grouped=True, unique_cache=None):
+        kw = {} if unique_cache is None else {"unique_cache": unique_cache}
+        if k == 33 and unique:                                   # the CPU stand-in's feature graphs
+            l, b = 1 + self.graph_calls // 4, self.graph_calls % 4 + 1
+            self.graph_calls += 1
+            name = "l%d_graph%d" % (l, b)
+            idx, dist, grouped = self.real_knn_query(k, query, points, unique, layout, want_dist, want_grouped, **kw)
+            for r, row, ref in self._settle(name, l, b, idx[:, :, 1:]):
+                idx[r, row, 1:] = torch.from_numpy(ref).to(idx.device, idx.dtype)
+                if grouped is not None:
+                    grouped[r, row] = points[r, idx[r, row]]
+            return idx, dist, grouped
+        if k == 5 and unique:                                    # inter-level neighbours
+            l = self.graph_calls // 4
+            name = "l%d_fm" % l
+            idx, dist, grouped = self.real_knn_query(k, query, points, unique, layout, want_dist, want_grouped, **kw)
+            todo = self._settle(name, l, None, idx)
+            if todo:
+                owner = layout["pts_of"].long() if layout and layout.get("pts_of") is not None else \
+                    torch.arange(points.size(0), device=points.device)
+                for r, row, ref in todo:
+                    idx[r, row] = torch.from_numpy(ref).to(idx.device, idx.dtype)
+                    if grouped is not None:
+                        grouped[r, row] = points[owner[r], idx[r, row].long()]
+            return idx, dist, grouped
+        return super(ChainAll, self).knn_query(k, query, points, unique, layout, want_dist, want_grouped, unique_cache)
+
+
+def first_flip_all(chain, g, i, q):
+    """first_flip for a ChainAll run in record mode: graphs and inter-level sets are compared by their row hashes"""
+    for name in ORDER:
+        l = int(name[1])
+        kind = name.split("_")[1]
+        if kind.startswith("graph") or kind == "fm":
+            b = int(kind[5]) if kind.startswith("graph") else None
+            one = ChainAll(chain.ops, g, [q], torch.device("cpu"), "replay")
+            ref = one.ref_hashes(l, b).numpy()[:one.live(l, q)]
+            same = np.array_equal(np.asarray(chain.hashes[name][i])[:ref.shape[0]], ref)
+        else:
+            ref = np.asarray(g["p%d_%s" % (q, name)])
+            mine = np.asarray(chain.seen[name][i])
+            if kind == "mask":
+                same = np.array_equal(mine.reshape(-1), ref.reshape(-1))
+            elif kind in ("seeds", "fps"):
+                same = np.array_equal(mine.reshape(-1)[:ref.size].astype(np.int64), ref.reshape(-1).astype(np.int64))
+            else:                                                # pidx: the order inside an inner patch matters
+                a = mine.reshape((-1,) + ref.shape[1:])[:ref.shape[0]].astype(np.int64)
+                same = np.array_equal(a, ref.astype(np.int64))
+        if not same:
+            return name
+    return None
+
+
+def run_chain_all(ops, net, g, ids, dev, mode):
+    """run_chain on the compact record: -> (chain, per-level clouds, x16)"""
+    x = torch.from_numpy(np.stack([g["p%d_in" % q] for q in ids])).to(dev)
+    chain = ChainAll(ops, g, ids, dev, mode)
+    saved, net.trace = net.trace, []
+    try:
+        with chain, torch.no_grad():
+            out = net(x, ratio=16)
+        levels = [rec["cloud"].detach().cpu().numpy() for rec in net.trace]
+    finally:
+        net.trace = saved
+    return chain, levels, out.detach().cpu().numpy()
