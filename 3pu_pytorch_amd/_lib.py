@@ -75,6 +75,12 @@ SIGNATURES = {
     "tpu3_knn_graph_self_optimistic_f32": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.POINTER(KnnLayout), _vp, _vp]),
     "tpu3_knn_graph_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(KnnLayout), _vp, _vp, _vp]),
     "tpu3_normalize_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_normalize_cl_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_repatch_filter_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tpu3_repatch_seeds_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "tpu3_gather_xyz_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i]),
+    "tpu3_denormalize_f32": (_i, [_vp, ctypes.c_long, _i, _vp, _vp, _vp, _vp]),
+    "tpu3_fill_f32_i32": (_i, [_vp, _vp, ctypes.c_long, _f, _vp, ctypes.c_long, _i]),
     "tpu3_debug_fps_bucket_events": (_i, [_vp, _vp]),
     "tpu3_debug_fps_level_stats": (_i, [_vp]),
     "tpu3_debug_fps_tile_stats": (_i, [_vp]),

@@ -31,6 +31,8 @@ __device__ __forceinline__ float block_max(float v, float *red)
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// CL: channel-last rows (b, n, 3) in and out instead of the reference's (b, 3, n); same operations in the same order
+template <bool CL>
 __global__ __launch_bounds__(NZ_THREADS) void normalize_kernel(int n_pad, const int32_t *__restrict__ n_arr,
                                                                const float *__restrict__ pc,
                                                                float *__restrict__ out,
@@ -40,8 +42,9 @@ __global__ __launch_bounds__(NZ_THREADS) void normalize_kernel(int n_pad, const 
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int n = n_arr ? n_arr[b] : n_pad;
-    const float *X = pc + (size_t)b * 3 * n_pad, *Y = X + n_pad, *Z = Y + n_pad;
-    float *OX = out + (size_t)b * 3 * n_pad, *OY = OX + n_pad, *OZ = OY + n_pad;
+    constexpr int S = CL ? 3 : 1;                   // distance between consecutive points of one channel
+    const float *X = pc + (size_t)b * 3 * n_pad, *Y = X + (CL ? 1 : n_pad), *Z = Y + (CL ? 1 : n_pad);
+    float *OX = out + (size_t)b * 3 * n_pad, *OY = OX + (CL ? 1 : n_pad), *OZ = OY + (CL ? 1 : n_pad);
     const bool resident = n <= NZ_THREADS * NZ_PPT;
     float x[NZ_PPT], y[NZ_PPT], z[NZ_PPT];
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -50,18 +53,18 @@ __global__ __launch_bounds__(NZ_THREADS) void normalize_kernel(int n_pad, const 
         for (int j = 0; j < NZ_PPT; ++j) {
             const int k = threadIdx.x + j * NZ_THREADS;
             const bool live = k < n;
-            x[j] = live ? X[k] : 0.f;
-            y[j] = live ? Y[k] : 0.f;
-            z[j] = live ? Z[k] : 0.f;
+            x[j] = live ? X[k * S] : 0.f;
+            y[j] = live ? Y[k * S] : 0.f;
+            z[j] = live ? Z[k * S] : 0.f;
             sx += x[j];
             sy += y[j];
             sz += z[j];
         }
     } else {
         for (int k = threadIdx.x; k < n; k += NZ_THREADS) {
-            sx += X[k];
-            sy += Y[k];
-            sz += Z[k];
+            sx += X[k * S];
+            sy += Y[k * S];
+            sz += Z[k * S];
         }
     }
     const float cx = block_sum(sx, red) / (float)n;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(NZ_THREADS) void normalize_kernel(int n_pad, const 
         }
     } else {
         for (int k = threadIdx.x; k < n; k += NZ_THREADS) {
-            const float dx = X[k] - cx, dy = Y[k] - cy, dz = Z[k] - cz;
+            const float dx = X[k * S] - cx, dy = Y[k * S] - cy, dz = Z[k * S] - cz;
             r2 = fmaxf(r2, (dx * dx + dy * dy) + dz * dz);
         }
     }
@@ -90,16 +93,16 @@ __global__ __launch_bounds__(NZ_THREADS) void normalize_kernel(int n_pad, const 
         for (int j = 0; j < NZ_PPT; ++j) {
             const int k = threadIdx.x + j * NZ_THREADS;
             if (k < n) {
-                OX[k] = x[j] / r;
-                OY[k] = y[j] / r;
-                OZ[k] = z[j] / r;
+                OX[k * S] = x[j] / r;
+                OY[k * S] = y[j] / r;
+                OZ[k * S] = z[j] / r;
             }
         }
     } else {
         for (int k = threadIdx.x; k < n; k += NZ_THREADS) {
-            OX[k] = (X[k] - cx) / r;
-            OY[k] = (Y[k] - cy) / r;
-            OZ[k] = (Z[k] - cz) / r;
+            OX[k * S] = (X[k * S] - cx) / r;
+            OY[k * S] = (Y[k * S] - cy) / r;
+            OZ[k * S] = (Z[k * S] - cz) / r;
         }
     }
     if (threadIdx.x == 0) {
@@ -118,7 +121,18 @@ extern "C" int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int3
     if (b < 0 || n < 0) return TPU3_EINVAL;
     if (b == 0 || n == 0) return TPU3_OK;
     if (!pc || !out || !centroid || !radius) return TPU3_EINVAL;
-    hipLaunchKernelGGL(normalize_kernel, dim3(b), dim3(NZ_THREADS), 0, (hipStream_t)stream, n, n_arr, pc,
+    hipLaunchKernelGGL(normalize_kernel<false>, dim3(b), dim3(NZ_THREADS), 0, (hipStream_t)stream, n, n_arr, pc,
+                       out, centroid, radius);
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_normalize_cl_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr,
+                                     const float *pc, float *out, float *centroid, float *radius)
+{
+    if (b < 0 || n < 0) return TPU3_EINVAL;
+    if (b == 0 || n == 0) return TPU3_OK;
+    if (!pc || !out || !centroid || !radius) return TPU3_EINVAL;
+    hipLaunchKernelGGL(normalize_kernel<true>, dim3(b), dim3(NZ_THREADS), 0, (hipStream_t)stream, n, n_arr, pc,
                        out, centroid, radius);
     return tpu3_launch_status();
 }

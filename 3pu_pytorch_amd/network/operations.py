@@ -260,10 +260,20 @@ class HipBackend(object):
         drop-in `sampling.furthest_sampling` entry point, ragged ones through the C ABI."""
         b, n, _ = xyz.shape
         idx = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
-        temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
         lib = L.lib() if xyz.is_cuda else None
         need = lib.tpu3_fps_workspace_bytes(b, n) if lib is not None else 0
-        if n_arr is None and m_arr is None and need == 0:
+        dense = n_arr is None and m_arr is None and need == 0
+        if lib is not None:
+            # temp = 1e10 (the reference's protocol, operations.py:289) and, for ragged calls, idx = 0: ONE launch
+            temp = torch.empty((b, n), dtype=torch.float32, device=xyz.device)
+            with torch.cuda.device(xyz.device):
+                L.check(lib.tpu3_fill_f32_i32(L.stream_of(xyz), L.ptr(temp), temp.numel(), 1e10,
+                                              None if dense else L.ptr(idx), 0 if dense else idx.numel(), 0),
+                        "tpu3_fill_f32_i32")
+        else:
+            temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
+            idx.zero_()
+        if dense:
             sampling.furthest_sampling(b, n, npoint, xyz, temp, idx)
             return idx
         L.require_device(xyz, "xyz")
@@ -272,7 +282,6 @@ class HipBackend(object):
             if t is not None:
                 L.require_device(t, nm)
                 L.require_dtype(t, torch.int32, nm)
-        idx.zero_()
         # large point sets: scratch for the bucketed kernel comes from torch's caching allocator
         ws = torch.empty((need,), dtype=torch.uint8, device=xyz.device) if need else None
         with torch.cuda.device(xyz.device):
@@ -672,6 +681,66 @@ class HipBackend(object):
             L.check(L.lib().tpu3_normalize_f32(L.stream_of(pc), b, n, L.ptr(n_arr), L.ptr(pc), L.ptr(out),
                                                L.ptr(centroid), L.ptr(radius)), "tpu3_normalize_f32")
         return out, centroid, radius
+
+
+    # ---- (r6) the small steps between the eval path's kernels, one launch each (csrc/glue.hip) --------------------
+    def normalize_cl(self, pc, n_arr=None):
+        """pc (B,N,3) f32 contiguous channel-last -> (out (B,N,3), centroid (B,3), radius (B)): normalize() without
+        the two transposes around it; same operations in the same order."""
+        L.require_device(pc, "pc")
+        L.require_dtype(pc, torch.float32, "pc")
+        b, n, _ = pc.shape
+        out = torch.empty_like(pc)
+        centroid = torch.empty((b, 3), dtype=torch.float32, device=pc.device)
+        radius = torch.empty((b,), dtype=torch.float32, device=pc.device)
+        with torch.cuda.device(pc.device):
+            L.check(L.lib().tpu3_normalize_cl_f32(L.stream_of(pc), b, n, L.ptr(n_arr), L.ptr(pc), L.ptr(out),
+                                                  L.ptr(centroid), L.ptr(radius)), "tpu3_normalize_cl_f32")
+        return out, centroid, radius
+
+    def repatch_filter(self, closest, xyz, k, r, small_cell=None):
+        """The outlier filter of the eval-mode patch extraction (reference upsampler.py:63-77) in one launch.
+        closest (B,N,2) f32: kNN(k=2) distances (column 1 = the closest OTHER point); xyz (B,N,3).
+        -> xyz_f (B,N,3) kept points first, count (B,) int32, patch_num, patch_num*k, patch_num*k*r (B,) int32;
+        small_cell: optional 0-d int64 device tensor that counts clouds with fewer kept points than k."""
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        xyz_f = torch.empty_like(xyz)
+        out = torch.empty((4, B), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().tpu3_repatch_filter_f32(
+                L.stream_of(xyz), B, N, k, r, closest.data_ptr() + 4, closest.stride(1), L.ptr(xyz), L.ptr(xyz_f),
+                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), L.ptr(small_cell)),
+                "tpu3_repatch_filter_f32")
+        return xyz_f, out[0], out[1], out[2], out[3]
+
+    def repatch_seeds(self, seed_idx, patch_num, xyz_f):
+        """seeds (B,P,3) = xyz_f[seed_idx[min(j, patch_num - 1)]] (upsampler.py:78-79 with padded patch slots)."""
+        B, P = seed_idx.shape
+        seeds = torch.empty((B, P, 3), dtype=torch.float32, device=xyz_f.device)
+        with torch.cuda.device(xyz_f.device):
+            L.check(L.lib().tpu3_repatch_seeds_f32(L.stream_of(xyz_f), B, xyz_f.size(1), P, L.ptr(seed_idx),
+                                                   L.ptr(patch_num), L.ptr(xyz_f), L.ptr(seeds)), "tpu3_repatch_seeds_f32")
+        return seeds
+
+    def gather_xyz(self, x, idx, nchw_out=False):
+        """x (B,N,3) f32 contiguous, idx (B,M) int32 -> rows (B,M,3), or (B,3,M) with nchw_out."""
+        B, N, _ = x.shape
+        M = idx.size(1)
+        out = torch.empty((B, 3, M) if nchw_out else (B, M, 3), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_gather_xyz_f32(L.stream_of(x), B, N, M, L.ptr(x), L.ptr(idx), L.ptr(out),
+                                                1 if nchw_out else 0), "tpu3_gather_xyz_f32")
+        return out
+
+    def denormalize(self, x, radius, centroid):
+        """x (P,R,3) f32 contiguous, radius (P,), centroid (P,3) -> x * radius + centroid (two rounded operations)."""
+        P, R, _ = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().tpu3_denormalize_f32(L.stream_of(x), P, R, L.ptr(x), L.ptr(radius), L.ptr(centroid),
+                                                 L.ptr(out)), "tpu3_denormalize_f32")
+        return out
 
 
 BACKEND = HipBackend()

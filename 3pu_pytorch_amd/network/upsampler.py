@@ -117,28 +117,62 @@ class Net(torch.nn.Module):
     def _repatch(self, xyz_cl, k):
         """Eval-mode patch extraction (reference :59-86) for a batch of clouds at once.
         xyz_cl (B,N,3) -> patches (B,P,k,3) with P = int(N/k*5), live patch count (B,) int32
-        (patches beyond a cloud's count repeat its last live patch and are never merged)."""
+        (patches beyond a cloud's count repeat its last live patch and are never merged), and -- on the device path --
+        (patch_num * k, patch_num * k * step_ratio), the two ragged counts the level needs, else None.
+        On a device the steps between the three kernels (kNN k = 2, FPS, kNN k) are two launches of csrc/glue.hip
+        (r6: they were 22 ATen launches per level -- mean, compare, sum, a stable radix sort, gathers, index
+        arithmetic -- each a dispatch gap in the one-cloud latency)."""
         B, N, _ = xyz_cl.shape
         dev = xyz_cl.device
+        be = operations.BACKEND
         # distance to the closest neighbour; points far from everything are outliers (:63-73)
         _, closest_d, _ = operations.knn_query(2, xyz_cl, xyz_cl, unique=False, want_grouped=False)
-        closest_d = closest_d[:, :, 1]
-        mask = closest_d < (5 * torch.mean(closest_d, dim=1, keepdim=True))
-        count = mask.sum(dim=1).to(torch.int32)
-        order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)   # masked_select order
-        xyz_f = torch.gather(xyz_cl, 1, order.unsqueeze(-1).expand(-1, -1, 3))
         # patch_num = int(num_point / k * 5) per cloud, in double like Python (:76)
         P = int(N / k * 5)
-        patch_num = torch.floor(count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
-        self._note_small_clouds((count < k).sum())
         kk = min(k, N)
-        seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
-        slot = torch.minimum(_arange_like(P, xyz_cl).view(1, P), (patch_num - 1).view(B, 1).long())
-        seed_idx = torch.gather(seed_idx.long(), 1, slot)
-        seeds = torch.gather(xyz_f, 1, seed_idx.unsqueeze(-1).expand(-1, -1, 3))
+        if xyz_cl.is_cuda and hasattr(be, "repatch_filter") and closest_d.is_contiguous() and closest_d.size(-1) == 2:
+            xyz_f, count, patch_num, old_count, m_count = be.repatch_filter(
+                closest_d, xyz_cl.contiguous(), k, self.step_ratio, self._small_cloud_cell(dev))
+            seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
+            seeds = be.repatch_seeds(seed_idx, patch_num, xyz_f)
+            counts = (old_count, m_count)
+        else:
+            closest_d = closest_d[:, :, 1]
+            mask = closest_d < (5 * torch.mean(closest_d, dim=1, keepdim=True))
+            count = mask.sum(dim=1).to(torch.int32)
+            order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)   # masked_select order
+            xyz_f = torch.gather(xyz_cl, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+            patch_num = torch.floor(count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
+            self._note_small_clouds((count < k).sum())
+            seed_idx = operations.fps(xyz_f, P, n_arr=count, m_arr=patch_num)
+            slot = torch.minimum(_arange_like(P, xyz_cl).view(1, P), (patch_num - 1).view(B, 1).long())
+            seed_idx = torch.gather(seed_idx.long(), 1, slot)
+            seeds = torch.gather(xyz_f, 1, seed_idx.unsqueeze(-1).expand(-1, -1, 3))
+            counts = None
         _, _, patches = operations.knn_query(kk, seeds, xyz_f, unique=False,
                                              layout=dict(n_arr=count), want_dist=False)
-        return patches, patch_num
+        return patches, patch_num, counts
+
+    def _small_cloud_cell(self, dev):
+        """The int64 event word of the current (device, stream), created on first use (see _note_small_clouds)."""
+        key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        cell = self._small_cloud_counts.get(key)
+        if cell is None:
+            cell = self._small_cloud_counts[key] = torch.zeros((), dtype=torch.int64, device=dev)
+        return cell
+
+    def _index_rows(self, B, P, dev):
+        """(arange(B), repeat_interleave(arange(B), P)) as int32 device tensors, cached per shape: the owner tables of a
+        level's launches are constants of the call shape (two launches per level otherwise)."""
+        cache = self.__dict__.setdefault("_owner_tables", {})
+        key = (B, P, dev.type, dev.index)
+        hit = cache.get(key)
+        if hit is None:
+            each = torch.arange(B, dtype=torch.int32, device=dev)
+            hit = cache[key] = (each, torch.repeat_interleave(each, P) if P > 1 else each)
+            if len(cache) > 64:
+                cache.pop(next(iter(cache)))
+        return hit
 
     def _note_small_clouds(self, n):
         """n: 0-d device tensor.  Added to the scalar of the current (device, stream): kernels of different
@@ -212,17 +246,23 @@ class Net(torch.nn.Module):
         return self
 
     def _forward_eval(self, xyz, ratio):
-        B, _, num_point = xyz.size()
-        dev = xyz.device
+        return self.forward_eval_cl(xyz.transpose(2, 1).contiguous(), ratio).transpose(2, 1).contiguous()
+
+    def forward_eval_cl(self, xyz_cl, ratio=None):
+        """The eval path on channel-last clouds: (B,N,3) -> (B,N*ratio,3).  `forward` (the reference's Bx3xN interface)
+        wraps it in two transposes; pipeline.upsample_patches calls it directly."""
+        ratio = ratio or self.max_up_ratio
+        B, num_point, _ = xyz_cl.size()
+        dev = xyz_cl.device
+        be = operations.BACKEND
         num_levels = int(log(ratio, self.step_ratio))
         max_num_point = min(num_point, self.max_num_point)
-        xyz_cl = xyz.transpose(2, 1).contiguous()                     # (B,N,3)
         for l in range(1, num_levels + 1):
             curr_ratio = self.step_ratio ** l
             level = self.levels['level_%d' % l]
             if l == 1:
                 # every input patch is its own reference call: its own unique-max group
-                each = torch.arange(B, dtype=torch.int32, device=dev)
+                each, _ = self._index_rows(B, 1, dev)
                 old_xyz, old_count = xyz_cl, None
                 if self.trace is not None:
                     self.trace.append(dict(patch_xyz=xyz_cl.transpose(2, 1)))
@@ -231,39 +271,53 @@ class Net(torch.nn.Module):
                     self.trace[-1]["out_norm"] = xyz_cl.transpose(2, 1)
                     self.trace[-1]["cloud"] = xyz_cl
                 continue
+            counts = None
             if xyz_cl.size(1) > max_num_point:
-                patches, patch_num = self._repatch(xyz_cl, max_num_point)      # (B,P,k,3)
+                patches, patch_num, counts = self._repatch(xyz_cl, max_num_point)      # (B,P,k,3)
             else:
                 patches = xyz_cl.unsqueeze(1)
                 patch_num = torch.ones((B,), dtype=torch.int32, device=dev)
             P, k = patches.size(1), patches.size(2)
             patch_cl = patches.reshape(B * P, k, 3)
-            norm, centroid, radius = operations.normalize_point_batch(
-                patch_cl.transpose(2, 1).contiguous(), NCHW=True)
-            norm_cl = norm.transpose(2, 1).contiguous()
-            owner = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), P)
+            on_device = patch_cl.is_cuda and hasattr(be, "normalize_cl")
+            if on_device:
+                norm_cl, centroid, radius = be.normalize_cl(patch_cl.contiguous())      # (BP,k,3), (BP,3), (BP,)
+            else:
+                norm, centroid, radius = operations.normalize_point_batch(
+                    patch_cl.transpose(2, 1).contiguous(), NCHW=True)
+                norm_cl = norm.transpose(2, 1).contiguous()
+            _, owner = self._index_rows(B, P, dev)
             up_cl, feat = level.forward_cl(
                 patch_cl, norm_cl, (old_xyz, old_feat, old_count), owner=owner, groups=B, per_owner=P)
             if self.trace is not None:
                 self.trace.append(dict(patch_xyz=patch_cl.transpose(2, 1), out_norm=up_cl.transpose(2, 1),
                                        patch_num=patch_num))
-            up_cl = up_cl * radius.view(-1, 1, 1) + centroid.view(-1, 1, 3)
+            if on_device:
+                up_cl = be.denormalize(up_cl.contiguous(), radius, centroid)
+            else:
+                up_cl = up_cl * radius.view(-1, 1, 1) + centroid.view(-1, 1, 3)
             r = up_cl.size(1) // k
             # merge the patches of each cloud (reference :149-155): patch-major concatenation
             merged = up_cl.reshape(B, P * k * r, 3)
             old_xyz = patch_cl.reshape(B, P * k, 3)
             old_feat = feat.reshape(B, P * k, feat.size(-1))
-            old_count = (patch_num * k).contiguous()
+            if counts is not None and r == self.step_ratio:
+                old_count, m_count = counts
+            else:
+                old_count = (patch_num * k).contiguous()
+                m_count = (patch_num * (k * r)).contiguous()
             xyz_cl = merged
             if P > 1:
                 # resample to num_point * curr_ratio points (reference :156-159)
                 num_output_point = num_point * curr_ratio
-                m_count = (patch_num * (k * r)).contiguous()
                 idx = operations.fps(merged, num_output_point, n_arr=m_count, m_arr=None)
-                xyz_cl = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+                if merged.is_cuda and hasattr(be, "gather_xyz"):
+                    xyz_cl = be.gather_xyz(merged, idx)
+                else:
+                    xyz_cl = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
             if self.trace is not None:
                 self.trace[-1]["cloud"] = xyz_cl            # (B, num_point * curr_ratio, 3): what the next level sees
-        return xyz_cl.transpose(2, 1).contiguous()
+        return xyz_cl
 
     def forward(self, xyz, ratio=None, gt=None, **kwargs):
         """
@@ -532,7 +586,7 @@ class Level(torch.nn.Module):
                     layout = dict(pts_of=owner_, n_arr=prev_count)
                 else:
                     layout = dict(pts_of=owner, n_arr=prev_count, grp=owner, groups=groups)
-                pts_of = layout["pts_of"].long()
+                pts_of = layout["pts_of"]             # (converted to int64 only where the unfused path indexes with it)
             else:
                 pts_of = None
             covered = x.is_cuda and x.is_contiguous() and self.fm_knn <= 8 and x.size(-1) <= 320
@@ -558,7 +612,7 @@ class Level(torch.nn.Module):
                     xyz.contiguous(), x, prev_xyz.contiguous(), prev_feat.contiguous(),
                     None if pts_of is None else layout["pts_of"], knn_idx, per_cloud=per_owner)
                 return self._regress(x, xyz_normalized, B, N)
-            bsel = (torch.arange(B, device=xyz.device) if pts_of is None else pts_of).view(-1, 1, 1)
+            bsel = (torch.arange(B, device=xyz.device) if pts_of is None else pts_of.long()).view(-1, 1, 1)
             knn_feats = prev_feat[bsel, knn_idx]                              # (B,N,K,C)
             s_weight = self.exponential_distance_cl(xyz, knn_points)
             f_weight = self.exponential_distance_cl(x, knn_feats)

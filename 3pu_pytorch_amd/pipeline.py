@@ -48,9 +48,12 @@ def extract_outer_patches(clouds, num_point, patch_num_ratio=3):
     P = num_outer_patches(N, num_point, patch_num_ratio)
     cl = clouds.transpose(2, 1).contiguous()
     seed_idx = operations.fps(cl, P)
-    seeds = torch.gather(cl, 1, seed_idx.long().unsqueeze(-1).expand(-1, -1, 3))
-    each = torch.arange(C, dtype=torch.int32, device=clouds.device)
-    layout = dict(grp=each, groups=C) if C > 1 else None
+    be = operations.BACKEND
+    if cl.is_cuda and hasattr(be, "gather_xyz"):
+        seeds = be.gather_xyz(cl, seed_idx)
+    else:
+        seeds = torch.gather(cl, 1, seed_idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    layout = dict(grp=torch.arange(C, dtype=torch.int32, device=clouds.device), groups=C) if C > 1 else None
     idx, _, patches = operations.knn_query(num_point, seeds, cl, unique=True, layout=layout,
                                            want_dist=False)
     return seed_idx, patches, idx
@@ -62,6 +65,23 @@ def upsample_patches(net, patches_cl, up_ratio, levels_out=None):
     (Q, num_point*up_ratio, 3) de-normalised, and the normalised input patches (Q,3,num_point).
     levels_out: optional list; receives the cloud every patch holds after each level, de-normalised like the final
     output, (Q, 3, num_point * step^l) per level (parity diagnostics: tests/test_c2_parity.py)."""
+    be = operations.BACKEND
+    if (patches_cl.is_cuda and hasattr(be, "normalize_cl") and hasattr(net, "forward_eval_cl") and not net.training
+            and patches_cl.dtype == torch.float32):
+        # (r6) channel-last end to end: normalise, the net's eval path and the de-normalisation are three calls with
+        # no transpose / multiply / add launches in between (they were nine ATen launches per call)
+        norm_cl, centroid, radius = be.normalize_cl(patches_cl.contiguous())           # (Q,n,3), (Q,3), (Q,)
+        if levels_out is not None:
+            saved, net.trace = net.trace, []
+        try:
+            up_cl = net.forward_eval_cl(norm_cl, up_ratio)
+            if levels_out is not None:
+                for rec in net.trace:
+                    levels_out.append(be.denormalize(rec["cloud"].contiguous(), radius, centroid).transpose(2, 1))
+        finally:
+            if levels_out is not None:
+                net.trace = saved
+        return be.denormalize(up_cl, radius, centroid), norm_cl.transpose(2, 1)
     patch = patches_cl.transpose(2, 1).contiguous()
     patch, centroid, radius = operations.normalize_point_batch(patch, NCHW=True)
     if levels_out is not None:
@@ -224,6 +244,8 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         if timing is not None:
             ev[1].record()
             timing.append(ev)
+        if merged.is_cuda and hasattr(operations.BACKEND, "gather_xyz"):
+            return operations.BACKEND.gather_xyz(merged.contiguous(), idx, nchw_out=True)   # (C,3,M) in one launch
         out = torch.gather(merged, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
         return out.transpose(2, 1).contiguous()
 

@@ -439,6 +439,36 @@ int tpu3_linear_dgrad_f32(tpu3_stream_t stream, long m, int cin, int cout, const
  * pc (b,3,n) f32 -> out (b,3,n), centroid (b,3), radius (b) ; ragged n_arr optional. */
 int tpu3_normalize_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc,
                        float *out, float *centroid, float *radius);
+/* The same normalisation on channel-last rows: pc, out (b, n, 3); centroid (b, 3), radius (b).  Same operations in the
+ * same order as tpu3_normalize_f32 (the eval path keeps its clouds channel-last: no transposes around the call). */
+int tpu3_normalize_cl_f32(tpu3_stream_t stream, int b, int n, const int32_t *n_arr, const float *pc, float *out,
+                          float *centroid, float *radius);
+
+/* ---- (r6) the small steps between the eval path's kernels, one launch each (csrc/glue.hip) ----------------------------
+ * tpu3_repatch_filter_f32: the outlier filter of the eval-mode patch extraction (network/upsampler.py:63-77) for b
+ *   clouds of n points: dist = each point's distance to its closest neighbour (element i of cloud e at
+ *   dist[(e * n + i) * dstride]); keeps d < 5 * mean(d); xyz_f (b, n, 3) receives the kept points first, in their
+ *   order (masked_select), the dropped ones behind them; count (b) = N', patch_num (b) = max(1, int(N' / k * 5)),
+ *   old_count = patch_num * k, m_count = patch_num * k * r (either may be NULL); *small_events (may be NULL) is
+ *   incremented once per cloud with N' < k.
+ * tpu3_repatch_seeds_f32: seeds (b, p, 3) = xyz_f[seed_idx[min(j, patch_num - 1)]] (upsampler.py:78-79 for padded patch
+ *   slots: a slot beyond a cloud's patch count repeats its last live patch).
+ * tpu3_gather_xyz_f32: out[e, j, :] = x[e, idx[e, j], :] for 3-channel rows and int32 indices; nchw_out != 0 writes
+ *   (b, 3, m) instead of (b, m, 3)  (upsampler.py:158, main.py:380).
+ * tpu3_denormalize_f32: out = x * radius[patch] + centroid[patch] on (patches, rows_per_patch, 3) rows, a multiplication
+ *   and an addition, each rounded (upsampler.py:147, main.py:242).
+ * tpu3_fill_f32_i32: a[0 .. na) = va and c[0 .. nc) = vc in one launch (FPS: temp = 1e10, idx = 0). */
+int tpu3_repatch_filter_f32(tpu3_stream_t stream, int b, int n, int k, int r, const float *dist, int dstride,
+                            const float *xyz, float *xyz_f, int32_t *count, int32_t *patch_num, int32_t *old_count,
+                            int32_t *m_count, unsigned long long *small_events);
+int tpu3_repatch_seeds_f32(tpu3_stream_t stream, int b, int n, int p, const int32_t *seed_idx, const int32_t *patch_num,
+                           const float *xyz_f, float *seeds);
+int tpu3_gather_xyz_f32(tpu3_stream_t stream, int b, int n, int m, const float *x, const int32_t *idx, float *out,
+                        int nchw_out);
+int tpu3_denormalize_f32(tpu3_stream_t stream, long patches, int rows_per_patch, const float *x, const float *radius,
+                         const float *centroid, float *out);
+int tpu3_fill_f32_i32(tpu3_stream_t stream, float *a, long na, float va, int32_t *c, long nc, int32_t vc);
+
 
 /* DenseEdgeConv block for TRAINING (network/layers.py:44-64 under autograd, model.py:53-66) for the reference's
  * shape: 24 input channels, growth 12, three layers, k = 32 neighbours (else TPU3_ELIMIT: callers then use their

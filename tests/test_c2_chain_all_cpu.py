@@ -17,17 +17,21 @@ from conftest import golden, pkg
 from oracle.backend import OracleBackend
 
 TOL = 1e-5
-SAMPLES = {"c2_chain_all.npz": [0, 6, 16, 23, 31, 47], "c2_chain_all_seed1.npz": [0, 5, 11]}
+SAMPLES = {"c2_chain_all.npz": [0, 6, 16, 23, 31, 47], "c2_chain_all_seed1.npz": [0, 5, 11],
+           "c2_chain_all_trained.npz": [0, 13, 29, 40]}      # (trained weights: tests/golden/net16_trained.npz)
 
 
 @pytest.fixture()
 def modules(orc, monkeypatch):
     ops, ups = pkg("network.operations"), pkg("network.upsampler")
     monkeypatch.setattr(ops, "BACKEND", OracleBackend())
-    net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
-    state = golden("net16_state.npz")
-    net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"}, strict=True)
-    return ops, net.eval()
+
+    def net_for(g):
+        net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+        state = golden(str(g["weights"]) if "weights" in g.files else "net16_state.npz")
+        net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"}, strict=True)
+        return net.eval()
+    return ops, net_for
 
 
 def level_errors(g, ids, levels, x16):
@@ -42,6 +46,13 @@ def level_errors(g, ids, levels, x16):
 
 def test_the_records_cover_the_clouds():
     g0, g1, c2 = golden("c2_chain_all.npz"), golden("c2_chain_all_seed1.npz"), golden("c2_x16.npz")
+    gt = golden("c2_chain_all_trained.npz")
+    assert str(gt["weights"]) == "net16_trained.npz" and [int(q) for q in gt["patch_ids"]] == list(range(48))
+    np.testing.assert_array_equal(gt["cloud"], g0["cloud"])          # same cloud, other weights: other outputs
+    assert not np.allclose(gt["p0_l4_out"], g0["p0_l4_out"], atol=1e-3)
+    st, sr = golden("net16_trained.npz"), golden("net16_state.npz")
+    moved = [k for k in sr.files if k != "meta" and np.abs(st[k] - sr[k]).max() > 1e-3]
+    assert len(moved) >= 100, len(moved)                              # levels 1-3 trained (120 of 160 tensors moved)
     assert [int(q) for q in g0["patch_ids"]] == list(range(48))
     assert [int(q) for q in g1["patch_ids"]] == list(range(16))
     # seed 0 IS the c2_x16.npz run: same cloud, same outer patches, same final points per patch
@@ -63,9 +74,9 @@ def test_the_records_cover_the_clouds():
 
 @pytest.mark.parametrize("name", list(SAMPLES))
 def test_chain_all_replayed_is_within_1e5_with_no_unexplained_flip(modules, name):
-    ops, net = modules
+    ops, net_for = modules
     g, ids = golden(name), SAMPLES[name]
-    chain, levels, x16 = run_chain_all(ops, net, g, ids, torch.device("cpu"), "replay")
+    chain, levels, x16 = run_chain_all(ops, net_for(g), g, ids, torch.device("cpu"), "replay")
     assert chain.graph_calls == 16 and chain.levels_closed == 3
     err = level_errors(g, ids, levels, x16)
     print("%s, CPU stand-in, replay: rows forced to the reference's set %s; max |dx| per outer patch %s and level:\n%s"
@@ -76,9 +87,9 @@ def test_chain_all_replayed_is_within_1e5_with_no_unexplained_flip(modules, name
 
 @pytest.mark.parametrize("name", list(SAMPLES))
 def test_chain_all_on_its_own_departs_only_at_named_flips(modules, name):
-    ops, net = modules
+    ops, net_for = modules
     g, ids = golden(name), SAMPLES[name]
-    chain, levels, x16 = run_chain_all(ops, net, g, ids, torch.device("cpu"), "record")
+    chain, levels, x16 = run_chain_all(ops, net_for(g), g, ids, torch.device("cpu"), "record")
     err = level_errors(g, ids, levels, x16)
     for i, q in enumerate(ids):
         flip = first_flip_all(chain, g, i, q)

@@ -25,10 +25,10 @@ from conftest import golden, pkg
 pytestmark = pytest.mark.gpu
 
 
-def _net(dev):
+def _net(dev, weights="net16_state.npz"):
     ups = pkg("network.upsampler")
     net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
-    state = golden("net16_state.npz")
+    state = golden(weights)
     net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
     return net.to(dev).eval()
 
@@ -158,7 +158,16 @@ def test_c2_chain_on_device_departs_only_at_named_flips(dev):
 
 
 # ---- (r6) ALL 48 outer patches of the C2 cloud + 16 of a second cloud, compact record ---------------
-@pytest.mark.parametrize("name", ["c2_chain_all.npz", "c2_chain_all_seed1.npz"])
+# ... and all 48 again under TRAINED weights (tests/golden/net16_trained.npz = the product's Net after
+# 600 C3 training steps on the device, tools/train_weights.py; the record = the REFERENCE's Python under those weights)
+CHAIN_ALL = ["c2_chain_all.npz", "c2_chain_all_seed1.npz", "c2_chain_all_trained.npz"]
+
+
+def _weights_of(g):
+    return str(g["weights"]) if "weights" in g.files else "net16_state.npz"
+
+
+@pytest.mark.parametrize("name", CHAIN_ALL)
 def test_c2_chain_all_replayed_on_device(dev, name):
     """Every outer patch of the C2 cloud (and 16 of the seed-1 cloud) through all four levels on the HIP path, every
     discrete choice of the reference's run replayed from the compact record (tests/chain_replay.py, ChainAll: the
@@ -169,7 +178,7 @@ def test_c2_chain_all_replayed_on_device(dev, name):
     ops = pkg("network.operations")
     g = golden(name)
     ids = [int(q) for q in g["patch_ids"]]
-    net = _net(dev)
+    net = _net(dev, _weights_of(g))
     worst, forced = 0.0, {}
     for s in range(0, len(ids), 16):
         part = ids[s:s + 16]
@@ -185,7 +194,7 @@ def test_c2_chain_all_replayed_on_device(dev, name):
           "(tight) set: %s" % (name, len(ids), worst, {k: v for k, v in sorted(forced.items()) if v}))
 
 
-@pytest.mark.parametrize("name", ["c2_chain_all.npz", "c2_chain_all_seed1.npz"])
+@pytest.mark.parametrize("name", CHAIN_ALL)
 def test_c2_chain_all_on_device_every_patch_is_exact_or_has_a_named_first_flip(dev, name):
     """The HIP path's OWN choices on every recorded outer patch: the first choice that differs from the reference's is
     named, every level before it is within 1e-5, and a patch without a flip is within 1e-5 through level 4 -- no patch
@@ -195,7 +204,7 @@ def test_c2_chain_all_on_device_every_patch_is_exact_or_has_a_named_first_flip(d
     ops = pkg("network.operations")
     g = golden(name)
     ids = [int(q) for q in g["patch_ids"]]
-    net = _net(dev)
+    net = _net(dev, _weights_of(g))
     clean = 0
     for s in range(0, len(ids), 16):
         part = ids[s:s + 16]

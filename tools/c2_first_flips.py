@@ -18,10 +18,13 @@ from chain_replay import first_flip_all, run_chain_all        # noqa: E402
 ops = importlib.import_module("3pu_pytorch_amd.network.operations")
 ups = importlib.import_module("3pu_pytorch_amd.network.upsampler")
 dev = torch.device("cuda", 0)
-state = np.load(os.path.join(ROOT, "tests", "golden", "net16_state.npz"))
-net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
-net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
-net = net.to(dev).eval()
+
+
+def net_with(weights):
+    state = np.load(os.path.join(ROOT, "tests", "golden", weights))
+    net = ups.Net(max_up_ratio=16, step_ratio=2, knn=32, growth_rate=12, dense_n=3, fm_knn=5)
+    net.load_state_dict({k: torch.from_numpy(state[k]) for k in state.files if k != "meta"})
+    return net.to(dev).eval()
 
 
 def errors(g, ids, levels, x16):
@@ -34,10 +37,12 @@ def errors(g, ids, levels, x16):
     return err
 
 
-for name in ("c2_chain_all.npz", "c2_chain_all_seed1.npz"):
+for name in ("c2_chain_all.npz", "c2_chain_all_seed1.npz", "c2_chain_all_trained.npz"):
     g = np.load(os.path.join(ROOT, "tests", "golden", name))
     ids = [int(q) for q in g["patch_ids"]]
-    print("== %s (cloud seed %d, %d outer patches)" % (name, int(g["cloud_seed"]), len(ids)))
+    weights = str(g["weights"]) if "weights" in g.files else "net16_state.npz"
+    net = net_with(weights)
+    print("== %s (cloud seed %d, %d outer patches, weights %s)" % (name, int(g["cloud_seed"]), len(ids), weights))
     counts = {}
     for s in range(0, len(ids), 16):
         part = ids[s:s + 16]
