@@ -21,6 +21,8 @@
 // GEMM only by the summation order (tests compare at 1e-5).
 #include "tpu3_dev.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -550,6 +552,187 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 }
 
 
+// (r6) SPLIT-bf16 flavour of the tail (TPU3_SPLIT_BF16=1; VERDICT r5 item 7, tools/split_mfma_probe.hip): fp32
+// arithmetic on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 terms, x = x1 + x2 + x3
+// (8 + 8 + 8 mantissa bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), each subtraction exact), and a
+// product w x becomes the six partial products whose magnitude can reach the fp32 result's last bits (w1 x1, w1 x2,
+// w2 x1, w1 x3, w2 x2, w3 x1; the three left out are below 2^-32 relative), accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16 -- 16x the fp32 MFMA's rate per instruction, 6 instructions for 8 of the 16x16x4 ones, and
+// the splits are VALU work the matrix pipe does not wait for.  Same register-to-register dataflow as the fp16 flavour
+// above (two accumulator tiles = the B operand of one slab pair); the weights are split once per workgroup into three
+// bf16 arrays in LDS (157 KB for layers 2 and 3); the 64 -> 3 layer stays on v_mfma_f32_16x16x4_f32 (16 instructions,
+// and its weights would not fit).  The result is NOT bit-identical to the fp32 kernel's -- products are exact in both,
+// the fp32 accumulation order differs -- but as accurate (probe: 1.2x / 1.0x the fp32 kernel's error against fp64).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+constexpr int RB_S = 136;                 // bf16 row stride of the 128-wide weight rows (conflict-free 8-byte reads)
+constexpr int RB_S4 = 68;                 // fp32 row stride of W4, FOUR rows (row 3 = zeros, read by every point >= 3)
+
+constexpr size_t rb_lds_bytes()
+{
+    return ((size_t)3 * RT_C2 * RB_S + 3 * RT_C3 * RB_S) * 2 + (4 * RB_S4 + RT_C2 + RT_C3 + 16 + RT_RMAX * RT_C1) * 4;
+}
+
+__device__ __forceinline__ void rb_split3(const v4f lo, const v4f hi, bf8 &t1, bf8 &t2, bf8 &t3)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? lo[j] : hi[j - 4];
+        const __bf16 a = (__bf16)x;
+        const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        t1[j] = a; t2[j] = b; t3[j] = (__bf16)r2;
+    }
+}
+
+__device__ __forceinline__ bf8 rb_w8(const __bf16 *w, int m, int S, int q)
+{
+    const bf4 lo = *(const bf4 *)(w + m * RB_S + 32 * S + 4 * q), hi = *(const bf4 *)(w + m * RB_S + 32 * S + 16 + 4 * q);
+    bf8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = lo[j];
+        r[4 + j] = hi[j];
+    }
+    return r;
+}
+
+// the six partial products of one (output tile, slab pair), smallest first
+#define RB_MFMA6(acc, A1, A2, A3, X1, X2, X3)                                        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, X1, acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, X3, acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, X2, acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, X1, acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, X2, acc, 0, 0, 0);             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, X1, acc, 0, 0, 0);
+
+__global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    __bf16 *w2 = (__bf16 *)ldsb;                  // [3][128][136]
+    __bf16 *w3 = w2 + 3 * RT_C2 * RB_S;           // [3][64][136]
+    float *w4 = (float *)(w3 + 3 * RT_C3 * RB_S); // [4][68] fp32, row 3 zero
+    float *b2 = w4 + 4 * RB_S4;                   // [128]
+    float *b3 = b2 + RT_C2;                       // [64]
+    float *b4 = b3 + RT_C3;                       // [16]
+    float *cc = b4 + 16;                          // [r][128]
+    const int tid = threadIdx.x;
+    auto stage3 = [&](__bf16 *dst, int rows, const float *src, int i) __attribute__((always_inline)) {
+        const float x = src[i];
+        const __bf16 p1 = (__bf16)x;
+        const float r1 = x - (float)p1;
+        const __bf16 p2 = (__bf16)r1;
+        const int o = (i >> 7) * RB_S + (i & 127);
+        dst[o] = p1;
+        dst[rows * RB_S + o] = p2;
+        dst[2 * rows * RB_S + o] = (__bf16)(r1 - (float)p2);
+    };
+    for (int i = tid; i < RT_C2 * RT_C1; i += blockDim.x)
+        stage3(w2, RT_C2, a.w2, i);
+    for (int i = tid; i < RT_C3 * RT_C2; i += blockDim.x)
+        stage3(w3, RT_C3, a.w3, i);
+    for (int i = tid; i < 4 * RT_C3; i += blockDim.x)
+        w4[(i >> 6) * RB_S4 + (i & 63)] = (i >> 6) < RT_C4 ? a.w4[i] : 0.f;
+    for (int i = tid; i < RT_C2; i += blockDim.x)
+        b2[i] = a.b2[i];
+    for (int i = tid; i < RT_C3; i += blockDim.x)
+        b3[i] = a.b3[i];
+    for (int i = tid; i < 16; i += blockDim.x)
+        b4[i] = i < RT_C4 ? a.b4[i] : 0.f;
+    for (int i = tid; i < a.r * RT_C1; i += blockDim.x)
+        cc[i] = a.c[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    const long ntiles = (a.m + 15) >> 4;
+    const __bf16 *w2a = w2, *w2b = w2 + RT_C2 * RB_S, *w2c = w2 + 2 * RT_C2 * RB_S;
+    const __bf16 *w3a = w3, *w3b = w3 + RT_C3 * RB_S, *w3c = w3 + 2 * RT_C3 * RB_S;
+    for (long tile = (long)blockIdx.x * nw + wave; tile < ntiles; tile += (long)gridDim.x * nw) {
+        const long row = tile * 16 + pt;
+        const long rowc = row < a.m ? row : a.m - 1;
+        v4f av[RT_C1 / 16];
+#pragma unroll
+        for (int s = 0; s < RT_C1 / 16; ++s)
+            av[s] = ld4(a.a + rowc * RT_C1 + 16 * s + 4 * q);
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (q == 0) {
+            rx = a.res[rowc * 3 + 0]; ry = a.res[rowc * 3 + 1]; rz = a.res[rowc * 3 + 2];
+        }
+        for (int j = 0; j < a.r; ++j) {
+            // layer 2: 128 -> 128 on relu(a + c_j), split per slab pair just before its products
+            v4f t1[RT_C2 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C2 / 16; ++t)
+                t1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < RT_C1 / 32; ++S) {
+                v4f v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u] = av[2 * S + u] + ld4(cc + j * RT_C1 + 16 * (2 * S + u) + 4 * q);
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+                bf8 x1, x2, x3;
+                rb_split3(v[0], v[1], x1, x2, x3);
+#pragma unroll
+                for (int t = 0; t < RT_C2 / 16; ++t) {
+                    const bf8 a1 = rb_w8(w2a, 16 * t + pt, S, q), a2 = rb_w8(w2b, 16 * t + pt, S, q),
+                              a3 = rb_w8(w2c, 16 * t + pt, S, q);
+                    RB_MFMA6(t1[t], a1, a2, a3, x1, x2, x3)
+                    if ((t & 3) == 3)
+                        __builtin_amdgcn_sched_barrier(0);      // four independent chains at a time: their 48 operand
+                                                                // registers, not the whole slab pair's 96
+                }
+            }
+            // layer 3: 128 -> 64 on relu(t1 + b2)
+            v4f t2[RT_C3 / 16];
+#pragma unroll
+            for (int t = 0; t < RT_C3 / 16; ++t)
+                t2[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < RT_C2 / 32; ++S) {
+                v4f v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u] = t1[2 * S + u] + ld4(b2 + 16 * (2 * S + u) + 4 * q);
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+                bf8 x1, x2, x3;
+                rb_split3(v[0], v[1], x1, x2, x3);
+#pragma unroll
+                for (int t = 0; t < RT_C3 / 16; ++t) {
+                    const bf8 a1 = rb_w8(w3a, 16 * t + pt, S, q), a2 = rb_w8(w3b, 16 * t + pt, S, q),
+                              a3 = rb_w8(w3c, 16 * t + pt, S, q);
+                    RB_MFMA6(t2[t], a1, a2, a3, x1, x2, x3)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // layer 4: 64 -> 3 on relu(t2 + b3), fp32 operands (slab s of the B operand IS accumulator tile s)
+            v4f o = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < RT_C3 / 16; ++s) {
+                v4f v = t2[s] + ld4(b3 + 16 * s + 4 * q);
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                const v4f w = ld4(w4 + min(pt, 3) * RB_S4 + 16 * s + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], v[k], o, 0, 0, 0);
+            }
+            if (q == 0 && row < a.m) {          // lanes 0-15 hold outputs 0..3 of their point
+                float *dst = a.out + (row * a.r + j) * 3;
+                dst[0] = (o.x + b4[0]) + rx;
+                dst[1] = (o.y + b4[1]) + ry;
+                dst[2] = (o.z + b4[2]) + rz;
+            }
+        }
+    }
+}
+#undef RB_MFMA6
+
 // ---------------------------------------------------------------------------------------------
 // y[m, cout] = x[m, cin] W^T + b with cout = 16 NT <= 128 (the per-point half of up_layer1: 264 -> 128)
 // ---------------------------------------------------------------------------------------------
@@ -841,6 +1024,17 @@ extern "C" int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const 
         if (e != hipSuccess) return (int)e;
         if (blocks > 512) blocks = 512;         // two persistent workgroups per CU (55 KB of weights each)
         hipLaunchKernelGGL(regress_tail_f16_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, t);
+        return tpu3_launch_status();
+    }
+    // (r6) TPU3_SPLIT_BF16=1: fp32 operands as three bf16 terms on the bf16 matrix pipe (regress_tail_sb_kernel)
+    static const bool split_bf16 = getenv("TPU3_SPLIT_BF16") && atoi(getenv("TPU3_SPLIT_BF16")) != 0;
+    if (split_bf16) {
+        const size_t ldsb = rb_lds_bytes();
+        hipError_t eb = hipFuncSetAttribute((const void *)regress_tail_sb_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (eb != hipSuccess) return (int)eb;
+        if (blocks > 256) blocks = 256;         // one persistent workgroup per CU (157 KB of split weights)
+        hipLaunchKernelGGL(regress_tail_sb_kernel, dim3((unsigned)blocks), dim3(512), ldsb, (hipStream_t)stream, t);
         return tpu3_launch_status();
     }
     const size_t lds = rt_lds_floats() * sizeof(float);

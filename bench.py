@@ -188,10 +188,24 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
     if shp:
         ex = sum(m * rr * 2.0 * (128 * 128 + 128 * 64 + 64 * 16) for m, rr in shp)
         ach = ex / (ms * 1e-3) / 1e12
-        out.append({"kernel": "regress_tail_kernel (128->128->64->3, fp32 MFMA), %d launches/step" % len(shp),
-                    "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
-                    "basis": "executed MFMA FLOPs (last layer padded 3 -> 16 rows)", "ms_per_step": ms, "ms_per_step_min_max": spread,
-                    "executed_flop_per_step": ex, "traffic": tr("regress_tail_kernel")})
+        split = os.environ.get("TPU3_SPLIT_BF16", "0") not in ("0", "")
+        if split:
+            # six v_mfma_f32_16x16x32_bf16 per (output tile, slab pair) in layers 2 and 3, fp32 MFMAs in layer 4: the
+            # EXECUTED matrix FLOP are 6x the layers' 2 * cin * cout per row, priced on the bf16 peak
+            ex_b = sum(m * rr * 2.0 * 6 * (128 * 128 + 128 * 64) for m, rr in shp)
+            out.append({"kernel": "regress_tail_sb_kernel (128->128->64->3, fp32 operands as 3 bf16 terms, 6 partial products on "
+                                  "v_mfma_f32_16x16x32_bf16; TPU3_SPLIT_BF16=1), %d launches/step" % len(shp),
+                        "bound": "mfma", "achieved": ex_b / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ex_b / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF,
+                        "basis": "executed bf16 MFMA FLOPs (6 partial products per fp32 product) against the dense bf16 peak; "
+                                 "on the fp32 model (2 * cin * cout per row) the kernel delivers %.1f TFLOP/s = %.2f of the fp32 "
+                                 "MFMA peak" % (ach, ach / FP32_PEAK_TF),
+                        "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex_b, "traffic": None})
+        else:
+            out.append({"kernel": "regress_tail_kernel (128->128->64->3, fp32 MFMA), %d launches/step" % len(shp),
+                        "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
+                        "basis": "executed MFMA FLOPs (last layer padded 3 -> 16 rows)", "ms_per_step": ms,
+                        "ms_per_step_min_max": spread, "executed_flop_per_step": ex, "traffic": tr("regress_tail_kernel")})
     ms, shp, spread = kt.total("linear_wide")
     if shp:
         # executed: per 16 rows 17 slabs x 8 output tiles x 4 MFMAs (264 channels padded to 272)
@@ -897,7 +911,11 @@ def main():
             + "upsampled points/sec (16x, 312-pt patches, 5000->80000)",
             "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if patch_mode else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if patch_mode else "weak", "vs_baseline": None,
+            # (TPU3_SPLIT_BF16=1, opt-in: the regressor tail's fp32 operands as three bf16 terms each on the bf16 matrix
+            # pipe, fp32 accumulate -- profiles/r06_split_bf16_end_to_end.txt)
+            "dtype": ("f32 (3xbf16 split operands in the regressor tail, fp32 accumulate)"
+                      if os.environ.get("TPU3_SPLIT_BF16", "0") not in ("0", "") else "f32"),
             "data": "synthetic",
             "config": {"workload": "C2: %d cloud(s)/GPU x %d pts, num_point=%d, up_ratio=%d (4 levels), "
                                    "%d outer patches, knn=32, random-init weights, Poisson-sphere input"
