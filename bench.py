@@ -719,6 +719,18 @@ def main():
     backend = os.environ.get("TPU3_BENCH_BACKEND", "nccl")
     if os.environ.get("TPU3_BENCH_ONE_DEVICE"):
         local_rank = 0
+    # (r6) first contact with an N-GPU node: say plainly what is wrong instead of failing inside set_device / RCCL
+    ndev = torch.cuda.device_count()
+    if ndev < local_rank + 1:
+        raise SystemExit("bench.py rank %d: LOCAL_RANK=%d but this process sees %d ROCm device(s) "
+                         "(HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r): launch one rank per visible GPU "
+                         "(--nproc-per-node <= %d), or set TPU3_BENCH_ONE_DEVICE=1 for a functional run on one device"
+                         % (rank, local_rank, ndev, os.environ.get("HIP_VISIBLE_DEVICES"),
+                            os.environ.get("ROCR_VISIBLE_DEVICES"), max(ndev, 1)))
+    if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and rank == 0:
+        print("bench.py: HSA_ENABLE_IPC_MODE_LEGACY is %r, not '0' -- RCCL's intra-node transport needs dmabuf IPC on "
+              "this driver (hipIpcGetMemHandle: invalid argument otherwise)" % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+              file=sys.stderr)
     # the device is bound BEFORE any allocation or communicator exists (RCCL binds its communicator to the current
     # device; device_id makes the binding explicit and lets init create the communicator eagerly)
     torch.cuda.set_device(local_rank)
@@ -848,10 +860,26 @@ def main():
         fence()
         dt = (time.perf_counter() - t1) / 10
         total_bytes = part.numel() * 4 * world
+        # every rank's device as the runtime names it (uuid, PCI bus id, name): two ranks on ONE device -- a mis-set
+        # HIP_VISIBLE_DEVICES -- would show here, not as a mysteriously halved number
+        props = torch.cuda.get_device_properties(dev)
+        mine = "rank %d: cuda:%d %s uuid=%s pci=%s" % (rank, local_rank, props.name, getattr(props, "uuid", "?"),
+                                                      getattr(props, "pci_bus_id", "?"))
+        names = [None] * dist.get_world_size()
+        dist.all_gather_object(names, mine)
         comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "allgather_bytes_total": total_bytes, "allgather_ms": dt * 1e3,
                 "allgather_bus_GBps": (world - 1) / world * total_bytes / dt / 1e9,
-                "forced_at_world_size_1": bool(force_dist and world == 1)}
+                "forced_at_world_size_1": bool(force_dist and world == 1),
+                "rank_devices": names,
+                "distinct_devices": len({n.split("uuid=")[-1] for n in names}) if not os.environ.get("TPU3_BENCH_ONE_DEVICE") else 1,
+                "expectation": ("weak scaling over clouds: N x the 1-GPU value at the same --clouds (one %.1f MB all-gather "
+                                "per step, ~0.4 ms at 150 GB/s per xGMI link against a >200 ms step); DESIGN section 6"
+                                % (total_bytes / 1e6)) if not patch_mode else
+                               ("strong scaling over the 48 outer patches of ONE cloud: ~(network stages / N + replicated "
+                                "final FPS) per cloud, < 2x at N = 8; DESIGN section 6")}
+        if world > 1 and not os.environ.get("TPU3_BENCH_ONE_DEVICE"):
+            assert comm["distinct_devices"] == world, "ranks share a device: %r" % (names,)
 
     op_ms = float(np.mean([a.elapsed_time(b) for a, b in timing])) if timing else None
     fps_ms = None

@@ -75,6 +75,10 @@ def test_bench_eight_ranks_dry_run_equals_one_rank():
     eight = _bench(8, ["--clouds", "1"], timeout=1500)
     assert eight["n_gpus"] == 8 and eight["scaling"] == "weak"
     assert eight["comm"]["world_size"] == 8 and eight["comm"]["backend"] == "gloo"
+    # (r6) first-contact fields: every rank names its device, and the line states what scaling to expect
+    assert len(eight["comm"]["rank_devices"]) == 8 and all("uuid=" in d for d in eight["comm"]["rank_devices"])
+    assert [d.split(":")[0] for d in eight["comm"]["rank_devices"]] == ["rank %d" % i for i in range(8)]
+    assert "weak scaling" in eight["comm"]["expectation"]
     assert eight["comm"]["allgather_bytes_total"] == 8 * 1 * 3 * 80000 * 4
     assert eight["config"]["clouds_per_gpu"] == 1 and eight["value"] > 0
     one = _bench(1, ["--clouds", "8"])
