@@ -60,7 +60,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TF = 157.3           # fp32 vector = fp32 MFMA dense peak
 F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA peak
-PROFILE_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json")]
+PROFILE_TRAFFIC = [os.path.join(ROOT, "profiles", n) for n in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json")]
 
 
 def pkg(sub=None):
