@@ -132,6 +132,139 @@ __global__ __launch_bounds__(256) void fb_permute_kernel(FbArgs a0, const uint32
     a.skey[w] = live ? tpu3_fps_tiekey((int)o, lb) : 0xFFFFFFFFu;
 }
 
+// (r6) The four launches in front of the register-resident per-level kernels -- bounding box, Morton keys, a rocPRIM
+// segmented radix sort (three kernels, 0.32 ms for one cloud's 48 sets of 24 960 points) and the permutation -- as ONE
+// kernel: a 1024-thread workgroup per set bins its points by a 15-bit Morton cell (32 cells per axis of the set's box)
+// with an LDS counting sort -- 32 768 counters packed two to a word (a set holds <= 25 600 points: 16 bits), the
+// atomic's return value is the point's arrival rank inside its cell -- and writes the (x, y, z, running distance) rows
+// and tie keys in that order.  The order INSIDE a cell is the arrival order (differs from run to run); the samples do
+// not depend on it: the bucketed FPS is exact for any order, only its pruning quality depends on buckets being
+// compact -- ~8 points per cell on a surface, so a lane's bucket of 7 - 25 consecutive points spans a few cells either
+// way.  Slots past the live size repeat the last live row with temp = -1, as fb_permute_kernel leaves them.
+constexpr int FB_BIN_PPT = 25;           // points per thread: 25 600 / 1024
+
+__device__ __forceinline__ uint32_t fb_spread5(uint32_t v)
+{
+    v &= 0x1Fu;
+    v = (v | (v << 8)) & 0x100Fu;
+    v = (v | (v << 4)) & 0x10C3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void fb_bin_kernel(FbArgs a0)
+{
+    __shared__ uint32_t cnt[16384];     // cell c: bits [16 (c & 1), +16) of word c >> 1
+    __shared__ float red[6][16];
+    __shared__ float box[6];
+    __shared__ int wsum[16];
+    const FbArgs a = fb_elem(a0, blockIdx.x);
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n <= 0)
+        return;
+    const float *__restrict__ xyz = a.xyz;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < n; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = xyz[(size_t)i * 3 + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float l = -tpu3_wave_max_f32(-lo[c]), h = tpu3_wave_max_f32(hi[c]);
+        if (lane == 0) {
+            red[c][wave] = l;
+            red[3 + c][wave] = h;
+        }
+    }
+    for (int i = tid; i < 16384; i += 1024)
+        cnt[i] = 0u;
+    __syncthreads();
+    if (tid < 6) {
+        float v = red[tid][0];
+        for (int w = 1; w < 16; ++w)
+            v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        box[tid] = v;
+        a.bbox[tid] = v;
+    }
+    __syncthreads();
+    float sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ext = box[3 + c] - box[c];
+        sc[c] = ext > 0.f ? 32.f / ext : 0.f;
+    }
+    uint32_t cr[FB_BIN_PPT];            // cell << 16 | rank
+#pragma unroll
+    for (int j = 0; j < FB_BIN_PPT; ++j) {
+        const int i = tid + j * 1024;
+        cr[j] = 0u;
+        if (i < n) {
+            uint32_t cell = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float q = (xyz[(size_t)i * 3 + c] - box[c]) * sc[c];
+                q = fminf(fmaxf(q, 0.f), 31.f);
+                cell |= fb_spread5((uint32_t)q) << c;
+            }
+            const uint32_t old = atomicAdd(&cnt[cell >> 1], (cell & 1u) ? 0x10000u : 1u);
+            cr[j] = (cell << 16) | ((cell & 1u) ? old >> 16 : old & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 32 768 counts: thread t owns words 16 t .. 16 t + 15 (cells 32 t .. 32 t + 31)
+    {
+        uint32_t w[16];
+        int sum = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            w[u] = cnt[16 * tid + u];
+            sum += (int)(w[u] & 0xFFFFu) + (int)(w[u] >> 16);
+        }
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            inc += lane >= d ? o : 0;
+        }
+        if (lane == 63)
+            wsum[wave] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int k = 0; k < wave; ++k)
+            run += wsum[k];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c0 = (int)(w[u] & 0xFFFFu), c1 = (int)(w[u] >> 16);
+            cnt[16 * tid + u] = (uint32_t)run | ((uint32_t)(run + c0) << 16);      // the two cells' first positions
+            run += c0 + c1;
+        }
+    }
+    __syncthreads();
+    const int lb = a.lb;
+#pragma unroll
+    for (int j = 0; j < FB_BIN_PPT; ++j) {
+        const int i = tid + j * 1024;
+        if (i < n) {
+            const uint32_t cell = cr[j] >> 16, word = cnt[cell >> 1];
+            const int pos = (int)((cell & 1u) ? word >> 16 : word & 0xFFFFu) + (int)(cr[j] & 0xFFFFu);
+            a.sp[pos] = make_float4(xyz[(size_t)i * 3 + 0], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2], a.temp[i]);
+            a.skey[pos] = tpu3_fps_tiekey(i, lb);
+        }
+    }
+    __syncthreads();                    // (the workgroup's own global writes are visible to it behind the barrier)
+    if (n < a.npad) {
+        const float4 last = a.sp[n - 1];
+        for (int i = n + tid; i < a.npad; i += 1024) {
+            a.sp[i] = make_float4(last.x, last.y, last.z, -1.0f);
+            a.skey[i] = 0xFFFFFFFFu;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fb_writeback_kernel(FbArgs a0)
 {
     const FbArgs a = fb_elem(a0, blockIdx.y);
@@ -1992,10 +2125,16 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         a0.tt = (float *)(f + p.fl_rec + p.fl_bm + p.fl_ba);
     }
 
+    // (r6) sets of the register-resident per-level kernels: bounding box, order and permutation in one launch
+    static const bool bin_on = !(getenv("TPU3_FPS_BIN") && atoi(getenv("TPU3_FPS_BIN")) == 0);
+    const bool binned = bin_on && p.rb_rows && n <= 1024 * FB_BIN_PPT;
+    if (binned)
+        hipLaunchKernelGGL(fb_bin_kernel, dim3(b), dim3(1024), 0, s, a0);
+    size_t tb = p.sort_temp;
+    if (!binned) {
     hipLaunchKernelGGL(fb_bbox_kernel, dim3(b), dim3(1024), 0, s, a0);
     hipLaunchKernelGGL(fb_morton_kernel, dim3((unsigned)((a0.sort_stride + 255) / 256), b), dim3(256), 0, s, a0, k_in,
                        v_in, k64_in);
-    size_t tb = p.sort_temp;
     if (p.global64) {
         const hipError_t se = rocprim::radix_sort_pairs((void *)sort_tmp, tb, k64_in, k64_out, v_in, v_out,
                                                         (size_t)b * a0.sort_stride, 0, 32 + p.ebits, s);
@@ -2021,6 +2160,7 @@ int fb_run(hipStream_t s, int b, int n, int m, const int32_t *n_arr, const int32
         }
     }
     hipLaunchKernelGGL(fb_permute_kernel, dim3((p.npad + 255) / 256, b), dim3(256), 0, s, a0, v_out);
+    }
     if (p.rb_rows && n > 1024 * 4 && m >= 256) {
         // a lane per bucket of R Morton-consecutive points (rl_main_kernel)
         a0.prof = g_level_stats;
