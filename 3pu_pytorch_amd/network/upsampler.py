@@ -218,6 +218,7 @@ class Net(torch.nn.Module):
                 layers._PACK_CACHES.pop(m, None)
             elif isinstance(m, Level):
                 _FOLD_CACHES.pop(m, None)
+                _CODE_CACHES.pop(m, None)
         return self
 
     def set_mlp_precision(self, precision, activations=None):
@@ -364,6 +365,7 @@ class _SkipTrain(torch.autograd.Function):
 # fold plans per Level (Level._fold_plan): held outside the modules -- a plan carries a stream event, which neither
 # copy.deepcopy(net) nor torch.save(net) may meet
 _FOLD_CACHES = weakref.WeakKeyDictionary()
+_CODE_CACHES = weakref.WeakKeyDictionary()      # Level._code_term
 
 
 class Level(torch.nn.Module):
@@ -622,6 +624,27 @@ class Level(torch.nn.Module):
 
         return self._regress(x, xyz_normalized, B, N)
 
+    def _code_term(self, code, w, cin):
+        """W_c code_j of the regressor's first layer for a 1-d code: (r,1) * (1,128), a constant of the weights --
+        cached per Level like the fold plan (weight version + address; built on one stream, other streams order
+        themselves behind the build), one launch per set of weights instead of one per Level call."""
+        if not code.is_cuda:
+            return code[0].t() * w[:, cin:].t()
+        key = (w._version, w.data_ptr(), code.data_ptr(), code.dtype, cin)
+        here = torch.cuda.current_stream(code.device)
+        hit = _CODE_CACHES.get(self)
+        if hit is not None and hit[0] == key:
+            if hit[2] != here.cuda_stream:
+                here.wait_event(hit[3])
+                hit[1].record_stream(here)
+            return hit[1]
+        with torch.no_grad():
+            c = (code[0].t() * w[:, cin:].t()).contiguous()
+        done = torch.cuda.Event()
+        done.record(here)
+        _CODE_CACHES[self] = (key, c, here.cuda_stream, done)
+        return c
+
     def _regress(self, x, xyz_normalized, B, N):
         point_features = x
         # feature expansion: every point r times, followed by its 1-d / 2-d code (:350-361)
@@ -652,7 +675,7 @@ class Level(torch.nn.Module):
             if code_length == 1:
                 # a 1-d code: W_c code_j is ONE product per entry -- an outer product, bit for bit what the (r,1) x
                 # (1,128) GEMM gives, without a vendor GEMM launch per Level call on the inference path
-                c = code[0].t() * w[:, cin:].t()                                          # (r,1) * (1,128)
+                c = self._code_term(code, w, cin)                                         # (r,1) * (1,128)
             else:
                 c = torch.nn.functional.linear(code[0].t().contiguous(), w[:, cin:])      # (r,128)
             up2, fc1, fc2 = self.up_layer.up_layer2, self.fc_layer1, self.fc_layer2
