@@ -2176,7 +2176,12 @@ extern "C" int tpu3_knn_graph_self_f32(tpu3_stream_t stream, int b, int n, int c
     if (r) return r;
     // (r5) the exact sorted kernel runs whenever the first pass raised uws[2] -- duplicated rows, but also a computed
     // distance <= 0 to a DIFFERENT row (features far from the origin: the oracle's slot 0 is then not the query
-    // itself) or a truncation collision three slots deep -- not only when the hash pass found duplicates
+    // itself) or a truncation collision three slots deep -- not only when the hash pass found duplicates.
+    // COST (advisor, r5): the flag is one word for the whole launch, so a single undecidable row makes the brute-force
+    // kernel recompute EVERY patch of the launch (3840 patches: ~2 ms instead of 0.4), and the hash / dup passes above run
+    // even when only the collision raised it.  Correct, and rare on feature rows (0 events in every bench step and in
+    // the 112-patch chained replays); a per-patch flag array would confine the recomputation -- not built: the
+    // inference path uses the optimistic entry point, whose caller recomputes the whole call anyway.
     a.mode = 0; a.gate = 2;
     return dispatch_insert(s, b, a);
 }

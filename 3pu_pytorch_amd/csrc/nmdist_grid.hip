@@ -280,27 +280,43 @@ __device__ __forceinline__ float nmg_point_box(float x, float y, float z, const 
 // update of the eight runs only when some lane may take one of them.
 // (First version: the rows through SCALAR loads straight from memory -- zero vector traffic, but eight dependent
 // round trips per tile with nothing to hide them behind at 2.4 waves per SIMD: 7.6 us per tile, 671 us per 80 000^2.)
-__device__ __forceinline__ void nmg_search_tile(const float4 *rows, float x, float y, float z, float &best, int &besti)
+// (r6b) PACKED: the wave's LDS slice holds the tile as candidate PAIRS -- eight words per pair: x0 x1 y0 y1 z0 z1 i0 i1 --
+// so that two ds_read_b128 deliver register pairs v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 can take as they are: the
+// three subtractions and the mul / fma / fma of the reference's expression run on TWO candidates per instruction (each
+// half is the IEEE operation of the scalar instruction: same bits), 3 + 0.5 instructions per pair instead of 6.6.
+typedef float nmg_f2 __attribute__((ext_vector_type(2)));
+typedef float nmg_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void nmg_search_tile(const nmg_f4 *pairs, float x, float y, float z, float &best, int &besti)
 {
+    const nmg_f2 xx = {x, x}, yy = {y, y}, zz = {z, z};
 #pragma unroll 2
-    for (int j = 0; j < NMG_TILE; j += 8) {
-        float4 c[8];
-        float d[8];
+    for (int j = 0; j < NMG_TILE / 2; j += 4) {          // four pairs = eight candidates per step
+        nmg_f4 xy[4], zi[4];
+        nmg_f2 d[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            c[u] = rows[j + u];
+        for (int u = 0; u < 4; ++u) {
+            xy[u] = pairs[2 * (j + u)];
+            zi[u] = pairs[2 * (j + u) + 1];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            d[u] = tpu3_sqdist3(c[u].x - x, c[u].y - y, c[u].z - z);
-        const float m8 = __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3])),
-                                         __builtin_fminf(__builtin_fminf(d[4], d[5]), __builtin_fminf(d[6], d[7])));
+        for (int u = 0; u < 4; ++u) {
+            const nmg_f2 dx = xy[u].xy - xx, dy = xy[u].zw - yy, dz = zi[u].xy - zz;
+            d[u] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+        }
+        const float m8 = __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0].x, d[0].y), __builtin_fminf(d[1].x, d[1].y)),
+                                         __builtin_fminf(__builtin_fminf(d[2].x, d[2].y), __builtin_fminf(d[3].x, d[3].y)));
         if (__builtin_amdgcn_ballot_w64(m8 <= best)) {             // (NaN distances: dropped by fminf, never taken)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = __float_as_int(c[u].w);
-                const bool take = (d[u] < best) | ((d[u] == best) & (k < besti));
-                best = take ? d[u] : best;
-                besti = take ? k : besti;
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float dv = h ? d[u].y : d[u].x;
+                    const int k = __float_as_int(h ? zi[u].w : zi[u].z);
+                    const bool take = (dv < best) | ((dv == best) & (k < besti));
+                    best = take ? dv : best;
+                    besti = take ? k : besti;
+                }
             }
         }
     }
@@ -348,8 +364,8 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
     int besti = 0x7FFFFFFF;
     uint32_t U = 0x7F800000u;                                   // bits of the wave's largest best (distances are >= 0)
     int st_super = 0, st_tile = 0, st_search = 0;
-    __shared__ float4 stage[4][NMG_TILE];
-    float4 *mine = stage[threadIdx.x >> 6];
+    __shared__ float stage[4][NMG_TILE * 4];
+    float *mine = stage[threadIdx.x >> 6];
     int pre_t = -1;                                             // the tile whose rows are already on their way
     float4 pre_row = make_float4(0.f, 0.f, 0.f, 0.f);
     // search tile t; `next` (>= 0): the tile most likely to be searched after it -- its rows are requested now
@@ -359,8 +375,11 @@ __global__ __launch_bounds__(256) void nmg_query_kernel(NmgArgs a)
         pre_t = next;
         if (next >= 0)
             pre_row = CR[(size_t)next * NMG_TILE + lane];
-        mine[lane] = row;
-        nmg_search_tile(mine, me.x, me.y, me.z, best, besti);
+        {   // candidate `lane` of the tile into its half of pair lane / 2
+            float *w = mine + (lane >> 1) * 8 + (lane & 1);
+            w[0] = row.x; w[2] = row.y; w[4] = row.z; w[6] = row.w;
+        }
+        nmg_search_tile((const nmg_f4 *)mine, me.x, me.y, me.z, best, besti);
         U = tpu3_wave_max_u32(live ? __float_as_uint(best) : 0u);
     };
     // ---- seed: the tile with the smallest bound (any of them), so that U is tight before the sweep ----
