@@ -779,6 +779,30 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
     };
 
+    // One sample folded into the lane's R running distances.  (r6) The distance chain runs on PACKED fp32 -- two points per
+    // v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, each half the IEEE operation of the scalar instruction (same bits):
+    // 3 R + R minima instead of 6 R + R instructions per sample and lane; the update is the phase in which the four waves
+    // of a SIMD queue for its VALU (docs/kernels/fps_register_resident_levels.md).
+    typedef float rl_f2 __attribute__((ext_vector_type(2)));
+    auto fold_sample = [&](float qx, float qy, float qz) __attribute__((always_inline)) {
+        const rl_f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        rb_static_for<0, R / 2>([&](auto pc_) __attribute__((always_inline)) {
+            constexpr int j = 2 * decltype(pc_)::value;
+            const rl_f2 X = {px[j], px[j + 1]}, Y = {py[j], py[j + 1]};
+            const rl_f2 Z = {ld_z(std::integral_constant<int, j>{}), ld_z(std::integral_constant<int, j + 1>{})};
+            const rl_f2 dx = X - qx2, dy = Y - qy2, dz = Z - qz2;
+            const rl_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+            pt[j] = tpu3_min1(d.x, pt[j]);
+            pt[j + 1] = tpu3_min1(d.y, pt[j + 1]);
+            if constexpr (ZL && (j / 2) % 4 == 3)
+                __builtin_amdgcn_sched_barrier(0);      // (eight LDS reads in flight, not all R: registers)
+        });
+        if constexpr (R % 2 == 1) {
+            constexpr int j = R - 1;
+            pt[j] = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(std::integral_constant<int, j>{}) - qz), pt[j]);
+        }
+    };
+
     // fold the first nj current samples into the buckets they reach.  A sample that does not reach a bucket (box
     // distance >= the bucket's maximum) cannot lower any of its distances, so a reached wave updates all of its
     // lanes unconditionally; a wave no sample reaches does nothing.
@@ -794,12 +818,7 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
                 continue;
             touched = true;
             if (PROF) pc[5] += 1;
-            rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                pt[j] = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
-                if constexpr (ZL && j % 8 == 7)
-                    __builtin_amdgcn_sched_barrier(0);      // (eight LDS reads in flight, not all R: registers)
-            });
+            fold_sample(qx, qy, qz);
         }
         if (touched)
             lane_scan();
@@ -1011,11 +1030,7 @@ __global__ __launch_bounds__(NW * 64, ((R <= 7 && NW == 16) ? 8 : 4)) void rl_ma
                 }
                 if (J > 1) {                            // every sample but the last one updates `temp`
                     for (int i = 0; i + 1 < J; ++i) {
-                        const float qx = rl(sx, i), qy = rl(sy, i), qz = rl(sz, i);
-                        rb_static_for<0, R>([&](auto jc) __attribute__((always_inline)) {
-                            constexpr int j = decltype(jc)::value;
-                            pt[j] = tpu3_min1(tpu3_sqdist3(px[j] - qx, py[j] - qy, ld_z(jc) - qz), pt[j]);
-                        });
+                        fold_sample(rl(sx, i), rl(sy, i), rl(sz, i));
                     }
                 }
                 break;
