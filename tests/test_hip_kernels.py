@@ -574,6 +574,56 @@ def test_nmdistance_backward(orc, dev):
     np.testing.assert_allclose(gx2.cpu().numpy(), r2, rtol=1e-5, atol=1e-5)
 
 
+# ---- (r6) the steps between the eval path's kernels (csrc/glue.hip) against their torch formulation ------------------
+def test_glue_kernels_equal_their_torch_formulation(dev):
+    """The launches that replaced the ATen glue of the eval path (reference upsampler.py:63-79, :147, :158; main.py:242,
+    :380): each against the torch expressions it stands for, on the shapes of a level -- bit for bit, except that the
+    outlier mask may differ for a distance within rounding of 5 * mean(d) (the kernel sums in double; asserted: at most
+    one point per cloud, none on these inputs)."""
+    ops = pkg("network.operations")
+    be = ops.BACKEND
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, N, k, r = 48, 2496, 312, 2
+    xyz = torch.randn((B, N, 3), device=dev, generator=g)
+    xyz[3, 100:140] += 40.0                                   # a far clump: its members fail the outlier test
+    _, closest, _ = ops.knn_query(2, xyz, xyz, unique=False, want_grouped=False)
+    cell = torch.zeros((), dtype=torch.int64, device=dev)
+    xyz_f, count, patch_num, old_count, m_count = be.repatch_filter(closest, xyz, k, r, cell)
+    d = closest[:, :, 1]
+    mask = d < (5 * torch.mean(d, dim=1, keepdim=True))
+    ref_count = mask.sum(dim=1).to(torch.int32)
+    assert int((count - ref_count).abs().max()) <= 1
+    same = count == ref_count
+    assert bool(same.all())                                   # (none borderline on these inputs)
+    assert int(count[3]) < N and int(count.min()) >= int(0.8 * N)
+    order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)
+    ref_f = torch.gather(xyz, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(xyz_f, ref_f)                          # kept first in order, dropped behind in order
+    ref_pn = torch.floor(ref_count.to(torch.float64) / k * 5).to(torch.int32).clamp_(min=1)
+    assert torch.equal(patch_num, ref_pn) and torch.equal(old_count, ref_pn * k) and torch.equal(m_count, ref_pn * k * r)
+    assert int(cell) == int((ref_count < k).sum())
+    # seeds: slots beyond a cloud's patch count repeat its last live patch
+    P = int(N / k * 5)
+    seed_idx = torch.randint(0, int(count.min()), (B, P), device=dev, generator=g, dtype=torch.int32)
+    seeds = be.repatch_seeds(seed_idx, patch_num, xyz_f)
+    slot = torch.minimum(torch.arange(P, device=dev).view(1, P), (patch_num - 1).view(B, 1).long())
+    ref_seeds = torch.gather(xyz_f, 1, torch.gather(seed_idx.long(), 1, slot).unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(seeds, ref_seeds)
+    # gather of xyz rows, both output layouts
+    idx = torch.randint(0, N, (B, 1248), device=dev, generator=g, dtype=torch.int32)
+    ref_g = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(be.gather_xyz(xyz, idx), ref_g)
+    assert torch.equal(be.gather_xyz(xyz, idx, nchw_out=True), ref_g.transpose(2, 1).contiguous())
+    # normalise (channel-last) = the NCHW kernel on the transposed input; de-normalise = multiply, then add
+    patches = torch.randn((96, 312, 3), device=dev, generator=g) * 0.3 + 1.0
+    n_cl, c_cl, r_cl = be.normalize_cl(patches)
+    n_ref, c_ref, r_ref = be.normalize(patches.transpose(2, 1).contiguous())
+    assert torch.equal(n_cl, n_ref.transpose(2, 1).contiguous())
+    assert torch.equal(c_cl, c_ref.view(-1, 3)) and torch.equal(r_cl, r_ref.view(-1))
+    up = torch.randn((96, 624, 3), device=dev, generator=g)
+    assert torch.equal(be.denormalize(up, r_cl, c_cl), up * r_cl.view(-1, 1, 1) + c_cl.view(-1, 1, 3))
+
+
 # ---- kNN grouping (a8) -----------------------------------------------------------------------
 def _knn_check(orc, dev, k, q, p, unique, layout=None):
     ops = pkg("network.operations")
