@@ -163,16 +163,30 @@ class Net(torch.nn.Module):
 
     def _index_rows(self, B, P, dev):
         """(arange(B), repeat_interleave(arange(B), P)) as int32 device tensors, cached per shape: the owner tables of a
-        level's launches are constants of the call shape (two launches per level otherwise)."""
+        level's launches are constants of the call shape (two launches per level otherwise).  The tables are BUILT by
+        kernels on one stream; pipeline.upsample runs sub-batches of the same net on several streams, so every other
+        stream orders itself behind the build (an event, as for the fold plans) -- a table read before it is written
+        would be an out-of-range owner index."""
         cache = self.__dict__.setdefault("_owner_tables", {})
         key = (B, P, dev.type, dev.index)
         hit = cache.get(key)
+        on_device = dev.type == "cuda"
+        here = torch.cuda.current_stream(dev) if on_device else None
         if hit is None:
             each = torch.arange(B, dtype=torch.int32, device=dev)
-            hit = cache[key] = (each, torch.repeat_interleave(each, P) if P > 1 else each)
+            owner = torch.repeat_interleave(each, P) if P > 1 else each
+            done = None
+            if on_device:
+                done = torch.cuda.Event()
+                done.record(here)
+            hit = cache[key] = (each, owner, here.cuda_stream if on_device else None, done)
             if len(cache) > 64:
                 cache.pop(next(iter(cache)))
-        return hit
+        elif on_device and hit[2] != here.cuda_stream:
+            here.wait_event(hit[3])
+            hit[0].record_stream(here)
+            hit[1].record_stream(here)
+        return hit[0], hit[1]
 
     def _note_small_clouds(self, n):
         """n: 0-d device tensor.  Added to the scalar of the current (device, stream): kernels of different
