@@ -58,6 +58,10 @@ SIGNATURES = {
     "tpu3_gather_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_scatter_add_rows_f32": (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _i, _vp]),
     "tpu3_linear_wide_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i]),
+    "tpu3_split_bf16": (_i, [_i]),
+    "tpu3_linear_wide_split_bytes": (ctypes.c_size_t, [_i]),
+    "tpu3_linear_wide_split_bf16": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "tpu3_linear_wide_sb_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _i]),
     "tpu3_linear_lift_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i]),
     "tpu3_linear_wgrad_f32": (_i, [_vp, ctypes.c_long, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _sz]),
     "tpu3_linear_wgrad_workspace_bytes": (_sz, [ctypes.c_long]),

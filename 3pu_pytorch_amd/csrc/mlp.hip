@@ -647,91 +647,149 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
     const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int pt = lane & 15, q = lane >> 4;
     const long ntiles = (a.m + 15) >> 4;
-    const __bf16 *w2a = w2, *w2b = w2 + RT_C2 * RB_S, *w2c = w2 + 2 * RT_C2 * RB_S;
-    const __bf16 *w3a = w3, *w3b = w3 + RT_C3 * RB_S, *w3c = w3 + 2 * RT_C3 * RB_S;
-    for (long tile = (long)blockIdx.x * nw + wave; tile < ntiles; tile += (long)gridDim.x * nw) {
-        const long row = tile * 16 + pt;
-        const long rowc = row < a.m ? row : a.m - 1;
-        v4f av[RT_C1 / 16];
+    // one LANE base per array (row pt, k quad q), laundered: folded back into "w2 + a large constant" every operand
+    // would get its own address register (offsets beyond the 16-bit immediate), ~60 of them spilled around the loop
+    auto lane_base = [&](const __bf16 *w) __attribute__((always_inline)) {
+        uint32_t o = (uint32_t)(uintptr_t)(w + pt * RB_S + 4 * q);
+        asm volatile("" : "+v"(o));
+        return (const __attribute__((address_space(3))) __bf16 *)(uintptr_t)o;
+    };
+    const auto w2a = lane_base(w2), w2b = lane_base(w2 + RT_C2 * RB_S), w2c = lane_base(w2 + 2 * RT_C2 * RB_S);
+    const auto w3a = lane_base(w3), w3b = lane_base(w3 + RT_C3 * RB_S), w3c = lane_base(w3 + 2 * RT_C3 * RB_S);
+    // operand of output tile t, slab pair S: the lane's two k quads
+    auto w8 = [](const __attribute__((address_space(3))) __bf16 *base, int t, int S) __attribute__((always_inline)) {
+        const bf4 lo = *(const __attribute__((address_space(3))) bf4 *)(base + 16 * t * RB_S + 32 * S);
+        const bf4 hi = *(const __attribute__((address_space(3))) bf4 *)(base + 16 * t * RB_S + 32 * S + 16);
+        return (bf8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    // The tile's rows (32 registers) and residuals are fetched a TILE ahead: into the registers the second layer has
+    // just finished with, while the third and fourth run (for more than two replicas the row is read again per pair).
+    const long tstep = (long)gridDim.x * nw;
+    v4f av[RT_C1 / 16];
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    auto fetch = [&](long tile, bool res_too) __attribute__((always_inline)) {
+        const long r = min(tile * 16 + pt, a.m - 1);
 #pragma unroll
         for (int s = 0; s < RT_C1 / 16; ++s)
-            av[s] = ld4(a.a + rowc * RT_C1 + 16 * s + 4 * q);
-        float rx = 0.f, ry = 0.f, rz = 0.f;
-        if (q == 0) {
-            rx = a.res[rowc * 3 + 0]; ry = a.res[rowc * 3 + 1]; rz = a.res[rowc * 3 + 2];
+            av[s] = ld4(a.a + r * RT_C1 + 16 * s + 4 * q);
+        if (res_too && q == 0) {
+            rx = a.res[r * 3 + 0]; ry = a.res[r * 3 + 1]; rz = a.res[r * 3 + 2];
         }
-        for (int j = 0; j < a.r; ++j) {
-            // layer 2: 128 -> 128 on relu(a + c_j), split per slab pair just before its products
-            v4f t1[RT_C2 / 16];
+    };
+    {
+        const long first = (long)blockIdx.x * nw + wave;
+        if (first < ntiles)
+            fetch(first, true);
+    }
+    for (long tile = (long)blockIdx.x * nw + wave; tile < ntiles; tile += tstep) {
+        const long row = tile * 16 + pt;
+        const float cx = rx, cy = ry, cz = rz;
+        // TWO replicas of a point at a time (the step ratio is 2: all of them): relu(a + c_j) differs, the weights do
+        // not, so one A operand read from LDS feeds both (0.25 instead of 0.5 ds_read_b128-equivalents per MFMA: LDS
+        // was this kernel's bound), and the six products of a (tile, slab pair) run PRODUCT-major over a pair of
+        // output tiles x two replicas -- four independent accumulators between two MFMAs on the same one.
+        for (int j0 = 0; j0 < a.r; j0 += 2) {
+            const int jr[2] = {j0, min(j0 + 1, a.r - 1)};       // (odd r: the last one twice, its store once)
+            if (j0 > 0)
+                fetch(tile, false);
+            // layer 2: 128 -> 128 on relu(a + c_j)
+            v4f t1[2][RT_C2 / 16];
 #pragma unroll
-            for (int t = 0; t < RT_C2 / 16; ++t)
-                t1[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int t = 0; t < RT_C2 / 16; ++t)
+                    t1[jj][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#define RB_P(ACC, AU, XV)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                      \
+            ACC[jj][tg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[AU][t], XV[jj], ACC[jj][tg + t], 0, 0, 0);
 #pragma unroll
             for (int S = 0; S < RT_C1 / 32; ++S) {
-                v4f v[2];
+                bf8 x1[2], x2[2], x3[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    v[u] = av[2 * S + u] + ld4(cc + j * RT_C1 + 16 * (2 * S + u) + 4 * q);
-                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
-                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                for (int jj = 0; jj < 2; ++jj) {
+                    v4f v[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        v[u] = av[2 * S + u] + ld4(cc + jr[jj] * RT_C1 + 16 * (2 * S + u) + 4 * q);
+                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                        v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                    }
+                    rb_split3(v[0], v[1], x1[jj], x2[jj], x3[jj]);
                 }
-                bf8 x1, x2, x3;
-                rb_split3(v[0], v[1], x1, x2, x3);
 #pragma unroll
-                for (int t = 0; t < RT_C2 / 16; ++t) {
-                    const bf8 a1 = rb_w8(w2a, 16 * t + pt, S, q), a2 = rb_w8(w2b, 16 * t + pt, S, q),
-                              a3 = rb_w8(w2c, 16 * t + pt, S, q);
-                    RB_MFMA6(t1[t], a1, a2, a3, x1, x2, x3)
-                    if ((t & 3) == 3)
-                        __builtin_amdgcn_sched_barrier(0);      // four independent chains at a time: their 48 operand
-                                                                // registers, not the whole slab pair's 96
+                for (int tg = 0; tg < RT_C2 / 16; tg += 2) {
+                    bf8 A[3][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        A[0][t] = w8(w2a, tg + t, S);
+                        A[1][t] = w8(w2b, tg + t, S);
+                        A[2][t] = w8(w2c, tg + t, S);
+                    }
+                    RB_P(t1, 2, x1) RB_P(t1, 0, x3) RB_P(t1, 1, x2) RB_P(t1, 1, x1) RB_P(t1, 0, x2) RB_P(t1, 0, x1)
+                    __builtin_amdgcn_sched_barrier(0);      // (one group's operand registers at a time)
                 }
             }
+            if (j0 + 2 >= a.r)
+                fetch(tile + tstep < ntiles ? tile + tstep : tile, true);
             // layer 3: 128 -> 64 on relu(t1 + b2)
-            v4f t2[RT_C3 / 16];
+            v4f t2[2][RT_C3 / 16];
 #pragma unroll
-            for (int t = 0; t < RT_C3 / 16; ++t)
-                t2[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int t = 0; t < RT_C3 / 16; ++t)
+                    t2[jj][t] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int S = 0; S < RT_C2 / 32; ++S) {
-                v4f v[2];
+                bf8 x1[2], x2[2], x3[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    v[u] = t1[2 * S + u] + ld4(b2 + 16 * (2 * S + u) + 4 * q);
-                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
-                    v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
-                }
-                bf8 x1, x2, x3;
-                rb_split3(v[0], v[1], x1, x2, x3);
+                for (int jj = 0; jj < 2; ++jj) {
+                    v4f v[2];
 #pragma unroll
-                for (int t = 0; t < RT_C3 / 16; ++t) {
-                    const bf8 a1 = rb_w8(w3a, 16 * t + pt, S, q), a2 = rb_w8(w3b, 16 * t + pt, S, q),
-                              a3 = rb_w8(w3c, 16 * t + pt, S, q);
-                    RB_MFMA6(t2[t], a1, a2, a3, x1, x2, x3)
+                    for (int u = 0; u < 2; ++u) {
+                        v[u] = t1[jj][2 * S + u] + ld4(b2 + 16 * (2 * S + u) + 4 * q);
+                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                        v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                    }
+                    rb_split3(v[0], v[1], x1[jj], x2[jj], x3[jj]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tg = 0; tg < RT_C3 / 16; tg += 2) {
+                    bf8 A[3][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        A[0][t] = w8(w3a, tg + t, S);
+                        A[1][t] = w8(w3b, tg + t, S);
+                        A[2][t] = w8(w3c, tg + t, S);
+                    }
+                    RB_P(t2, 2, x1) RB_P(t2, 0, x3) RB_P(t2, 1, x2) RB_P(t2, 1, x1) RB_P(t2, 0, x2) RB_P(t2, 0, x1)
+                    __builtin_amdgcn_sched_barrier(0);      // (one group's operand registers at a time)
+                }
             }
+#undef RB_P
             // layer 4: 64 -> 3 on relu(t2 + b3), fp32 operands (slab s of the B operand IS accumulator tile s)
-            v4f o = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < RT_C3 / 16; ++s) {
-                v4f v = t2[s] + ld4(b3 + 16 * s + 4 * q);
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                const v4f w = ld4(w4 + min(pt, 3) * RB_S4 + 16 * s + 4 * q);
+            for (int jj = 0; jj < 2; ++jj) {
+                v4f o = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], v[k], o, 0, 0, 0);
-            }
-            if (q == 0 && row < a.m) {          // lanes 0-15 hold outputs 0..3 of their point
-                float *dst = a.out + (row * a.r + j) * 3;
-                dst[0] = (o.x + b4[0]) + rx;
-                dst[1] = (o.y + b4[1]) + ry;
-                dst[2] = (o.z + b4[2]) + rz;
+                for (int s = 0; s < RT_C3 / 16; ++s) {
+                    v4f v = t2[jj][s] + ld4(b3 + 16 * s + 4 * q);
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    const v4f w = ld4(w4 + min(pt, 3) * RB_S4 + 16 * s + 4 * q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], v[k], o, 0, 0, 0);
+                }
+                if (q == 0 && row < a.m && (jj == 0 || j0 + 1 < a.r)) {      // lanes 0-15 hold outputs 0..3 of their point
+                    float *dst = a.out + (row * a.r + jr[jj]) * 3;
+                    dst[0] = (o.x + b4[0]) + cx;
+                    dst[1] = (o.y + b4[1]) + cy;
+                    dst[2] = (o.z + b4[2]) + cz;
+                }
             }
         }
     }
 }
-#undef RB_MFMA6
 
 // ---------------------------------------------------------------------------------------------
 // y[m, cout] = x[m, cin] W^T + b with cout = 16 NT <= 128 (the per-point half of up_layer1: 264 -> 128)
@@ -839,6 +897,168 @@ __global__ __launch_bounds__(64 * LW_WAVES) void linear_wide_kernel(WideArgs a)
     }
 }
 
+// (r6) SPLIT-bf16 flavour of the 264 -> 128 layer (TPU3_SPLIT_BF16=1, with regress_tail_sb_kernel): every fp32 operand
+// as three bf16 terms, six partial products per (output tile, 32-channel slab) on v_mfma_f32_16x16x32_bf16.  The split
+// weights (3 x 128 x 288 bf16 = 221 KB) do not fit LDS, so this is a GEMM main loop: a small pre-pass splits W once per
+// call into slab-major order [slab][term][tile][k octet][output][8 k], a workgroup walks 128-row blocks, and per block the nine
+// weight slabs (24 KB each) stream through a two-slot LDS ring one slab ahead (global -> registers -> LDS, one barrier
+// per slab) while every wave keeps TWO 16-row tiles: an A operand read from LDS feeds two MFMAs (0.25 ds_read_b128 per
+// MFMA -- the tail kernel's 0.5 made LDS its bound).  The rows come straight from memory, one slab ahead, 32 contiguous
+// bytes per lane, and are split in registers just before their products.  Channels 264 .. 287 of the last slab are
+// zeros on both sides.  Not bit-identical to linear_wide_kernel (fp32 accumulation order), as accurate.
+constexpr int WSB_WAVES = 4, WSB_RT = 2, WSB_ROWS = WSB_WAVES * WSB_RT * 16;
+constexpr int WSB_TG = 2;                           // output tiles whose products are interleaved
+constexpr int WSB_RESIDENT = 2;                     // workgroups per compute unit (207 registers: two waves per SIMD)
+constexpr int WSB_SLAB = 3 * 128 * 32;              // bf16 elements of one weight slab
+
+struct WideSbArgs {
+    long m;
+    int cin, xs, ys, nsb;
+    const float *x, *b;
+    const __bf16 *ws;                               // [nsb][3][8 tiles][4 k octets][16 outputs][8 k]
+    float *y;
+};
+
+__global__ __launch_bounds__(256) void wide_split_kernel(int cin, int ws, int nsb, const float *__restrict__ w,
+                                                         __bf16 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nsb * 128 * 32)
+        return;
+    const int S = i >> 12, o = (i >> 5) & 127, k = i & 31, ch = 32 * S + k;
+    const float x = ch < cin ? w[(size_t)o * ws + ch] : 0.f;
+    const __bf16 p1 = (__bf16)x;
+    const float r1 = x - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    // inside a (term, 16-output tile): [k octet q][output pt][8 k] -- lane 16 q + pt of the consumer reads 16 bytes at
+    // 16 * lane, the one ds_read_b128 pattern without bank conflicts (rows of 64 bytes at [pt][q] conflict two ways)
+    __bf16 *dst = out + (size_t)S * WSB_SLAB + (((o >> 4) * 4 + (k >> 3)) * 16 + (o & 15)) * 8 + (k & 7);
+    dst[0] = p1;
+    dst[128 * 32] = p2;
+    dst[2 * 128 * 32] = (__bf16)(r1 - (float)p2);
+}
+
+template <int NSB>
+__global__ __launch_bounds__(64 * WSB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_wide_sb_kernel(WideSbArgs a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][WSB_SLAB];         // 48 KB: the weight slab ring
+    __shared__ __attribute__((aligned(16))) float bl[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pt = lane & 15, q = lane >> 4;
+    if (tid < 128)
+        bl[tid] = a.b ? a.b[tid] : 0.f;
+    constexpr int WCH = WSB_SLAB * 2 / 16 / (64 * WSB_WAVES);               // 16-byte chunks of a slab per thread (6)
+    const long nblocks = (a.m + WSB_ROWS - 1) / WSB_ROWS;
+    constexpr int nsb = NSB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const float *xr[WSB_RT];
+        long row[WSB_RT];
+#pragma unroll
+        for (int rt = 0; rt < WSB_RT; ++rt) {
+            row[rt] = blk * WSB_ROWS + (wave * WSB_RT + rt) * 16 + pt;
+            xr[rt] = a.x + (row[rt] < a.m ? row[rt] : a.m - 1) * (long)a.xs + 8 * q;
+        }
+        // (the loads are NOT masked here: a select on the loaded value would make the wave wait for it at once; slab
+        // lanes beyond cin read the row's first channels instead and are zeroed when the slab is consumed)
+        auto load_x = [&](int S, v4f (&v)[WSB_RT][2]) __attribute__((always_inline)) {
+            const bool ok = 32 * S + 8 * q + 8 <= a.cin;                    // cin % 8 == 0 (checked by the entry)
+#pragma unroll
+            for (int rt = 0; rt < WSB_RT; ++rt) {
+                const float *p = xr[rt] + (ok ? 32 * S : 0);
+                v[rt][0] = *(const v4f *)p;
+                v[rt][1] = *((const v4f *)p + 1);
+            }
+        };
+        // (the staging registers are plain scalars handed around by value: as an array captured by the lambdas they
+        // were "promoted" into LDS, a round trip per slab)
+        struct WReg { uint4 v0, v1, v2, v3, v4, v5; };
+        static_assert(WCH == 6, "six 16-byte chunks of a slab per thread");
+        auto load_w = [&](int S) __attribute__((always_inline)) {
+            const uint4 *src = (const uint4 *)(a.ws + (size_t)S * WSB_SLAB) + tid;
+            constexpr int ST = 64 * WSB_WAVES;
+            return WReg{src[0], src[ST], src[2 * ST], src[3 * ST], src[4 * ST], src[5 * ST]};
+        };
+        auto store_w = [&](int slot, const WReg &r) __attribute__((always_inline)) {
+            uint4 *dst = (uint4 *)wl[slot] + tid;
+            constexpr int ST = 64 * WSB_WAVES;
+            dst[0] = r.v0; dst[ST] = r.v1; dst[2 * ST] = r.v2; dst[3 * ST] = r.v3; dst[4 * ST] = r.v4; dst[5 * ST] = r.v5;
+        };
+        // the rows TWO slabs ahead (a slab's products last ~1 us: less than a loaded memory system's latency), in three
+        // register sets that take turns (the loop is unrolled by three: a copy from set to set would wait for the load)
+        v4f xb[3][WSB_RT][2];
+        WReg wreg = load_w(0);
+        load_x(0, xb[0]);
+        load_x(nsb > 1 ? 1 : 0, xb[1]);
+        store_w(0, wreg);
+        __syncthreads();
+        v4f acc[8][WSB_RT];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int rt = 0; rt < WSB_RT; ++rt)
+                acc[t][rt] = zero;
+        auto step = [&](int S, v4f (&cur)[WSB_RT][2], v4f (&fut)[WSB_RT][2]) __attribute__((always_inline)) {
+            // the weights FIRST: the wait for them at the end of the step then leaves the rows' loads in flight
+            // (vmcnt counts in issue order);
+            // (both UNCONDITIONAL -- the last steps fetch the last slab again: behind a branch the wait-count pass
+            // must assume the loads were not issued and waits for everything)
+            wreg = load_w(min(S + 1, nsb - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(min(S + 2, nsb - 1), fut);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = 32 * S + 8 * q + 8 <= a.cin;
+            bf8 x1[WSB_RT], x2[WSB_RT], x3[WSB_RT];
+#pragma unroll
+            for (int rt = 0; rt < WSB_RT; ++rt)
+                rb_split3(ok ? cur[rt][0] : zero, ok ? cur[rt][1] : zero, x1[rt], x2[rt], x3[rt]);
+            // Products in PRODUCT-major order over a group of WSB_TG output tiles x two row tiles: four independent
+            // accumulators between two MFMAs on the same one (a dependent pair with anything issued in between costs
+            // a ~40-cycle bubble: MI355X guide, cycle table), the group's six A operands read in one batch
+            const __bf16 *wa = wl[S & 1] + 8 * lane;
+#pragma unroll
+            for (int tg = 0; tg < 8; tg += WSB_TG) {
+                bf8 A[3][WSB_TG];
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int t = 0; t < WSB_TG; ++t)
+                        A[u][t] = *(const bf8 *)(wa + (8 * u + (tg + t)) * 512);
+#define WSB_P(AU, XV)                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < WSB_TG; ++t)                                                        \
+        _Pragma("unroll") for (int rt = 0; rt < WSB_RT; ++rt)                                                 \
+            acc[tg + t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[AU][t], XV[rt], acc[tg + t][rt], 0, 0, 0);
+                WSB_P(2, x1) WSB_P(0, x3) WSB_P(1, x2) WSB_P(1, x1) WSB_P(0, x2) WSB_P(0, x1)
+#undef WSB_P
+            }
+            // (the fence keeps the compiler from merging this with the loads above: it would wait for the next slab's
+            // global loads at the TOP of the step, before the products that are there to hide them)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            store_w((S + 1) & 1, wreg);
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int S = 0; S < nsb; S += 3) {
+            step(S, xb[0], xb[2]);
+            if (S + 1 < nsb)
+                step(S + 1, xb[1], xb[0]);
+            if (S + 2 < nsb)
+                step(S + 2, xb[2], xb[1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < WSB_RT; ++rt) {
+            if (row[rt] < a.m) {
+                float *yr = a.y + row[rt] * (long)a.ys + 4 * q;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    *(v4f *)(yr + 16 * t) = acc[t][rt] + *(const v4f *)(bl + 16 * t + 4 * q);
+            }
+        }
+    }
+}
+#undef RB_MFMA6
+
 // ---------------------------------------------------------------------------------------------
 // y[m, cout] = act(x[m, cin] W^T + b) for a handful of input channels (the 3 -> 24 lift of a Level)
 // ---------------------------------------------------------------------------------------------
@@ -884,6 +1104,21 @@ __global__ __launch_bounds__(256) void linear_lift_kernel(LiftArgs a)
 
 } // namespace
 
+// split-bf16 arithmetic of the regressor's matrix layers (regress_tail_sb_kernel, linear_wide_sb_kernel): default from
+// TPU3_SPLIT_BF16 (unset = SPLIT_BF16_DEFAULT), switched at run time by tpu3_split_bf16
+#ifndef SPLIT_BF16_DEFAULT
+#define SPLIT_BF16_DEFAULT 1
+#endif
+static int g_split_bf16 = getenv("TPU3_SPLIT_BF16") ? atoi(getenv("TPU3_SPLIT_BF16")) != 0 : SPLIT_BF16_DEFAULT;
+
+extern "C" int tpu3_split_bf16(int on)
+{
+    const int old = g_split_bf16;
+    if (on >= 0)
+        g_split_bf16 = on != 0;
+    return old;
+}
+
 extern "C" int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                                     const float *w, int w_stride, const float *bias, float *y, int y_stride)
 {
@@ -904,6 +1139,42 @@ extern "C" int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int c
     if (blocks > 256) blocks = 256;                 // persistent: one workgroup per CU holds the weights
     hipLaunchKernelGGL((linear_wide_kernel<NT, NSL>), dim3((unsigned)blocks), dim3(64 * LW_WAVES), lds,
                        (hipStream_t)stream, a);
+    return tpu3_launch_status();
+}
+
+// (r6) split-bf16 flavour of tpu3_linear_wide_f32 in two steps, so that the split of W is paid once per set of weights:
+// tpu3_linear_wide_split_bf16 writes the slab-major three-term image (tpu3_linear_wide_split_bytes(cin) bytes, 16-byte
+// aligned), tpu3_linear_wide_sb_f32 consumes it.
+extern "C" size_t tpu3_linear_wide_split_bytes(int cin)
+{
+    return cin > 0 ? (size_t)((cin + 31) / 32) * WSB_SLAB * sizeof(__bf16) : 0;
+}
+
+extern "C" int tpu3_linear_wide_split_bf16(tpu3_stream_t stream, int cin, int cout, const float *w, int w_stride, void *ws)
+{
+    if (cin <= 0 || cout != 128 || w_stride < cin) return cout > 0 && cout != 128 ? TPU3_ELIMIT : TPU3_EINVAL;
+    if (!w || !ws || ((uintptr_t)ws & 15)) return TPU3_EINVAL;
+    const int nsb = (cin + 31) / 32;
+    hipLaunchKernelGGL(wide_split_kernel, dim3((nsb * 128 * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, cin,
+                       w_stride, nsb, w, (__bf16 *)ws);
+    return tpu3_launch_status();
+}
+
+extern "C" int tpu3_linear_wide_sb_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                                       const void *ws, const float *bias, float *y, int y_stride)
+{
+    if (m < 0 || cin <= 0 || cout <= 0) return TPU3_EINVAL;
+    if (x_stride < cin || y_stride < cout) return TPU3_EINVAL;
+    if (cout != 128 || cin % 8 || cin <= 256 || cin > 288 || x_stride % 8 || y_stride % 4) return TPU3_ELIMIT;     // nine slabs
+    if (m == 0) return TPU3_OK;
+    if (!x || !ws || !y) return TPU3_EINVAL;
+    if (((uintptr_t)x & 31) || (((uintptr_t)y | (uintptr_t)bias | (uintptr_t)ws) & 15)) return TPU3_ELIMIT;
+    static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    WideSbArgs sa{m, cin, x_stride, y_stride, (cin + 31) / 32, x, bias, (const __bf16 *)ws, y};
+    long blocks = (m + WSB_ROWS - 1) / WSB_ROWS;
+    const long cap = (long)cus * WSB_RESIDENT;          // what is resident at once: a third wave of workgroups would run alone at the end
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(linear_wide_sb_kernel<9>, dim3((unsigned)blocks), dim3(64 * WSB_WAVES), 0, (hipStream_t)stream, sa);
     return tpu3_launch_status();
 }
 
@@ -1026,9 +1297,9 @@ extern "C" int tpu3_regress_tail_f32(tpu3_stream_t stream, long m, int r, const 
         hipLaunchKernelGGL(regress_tail_f16_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, t);
         return tpu3_launch_status();
     }
-    // (r6) TPU3_SPLIT_BF16=1: fp32 operands as three bf16 terms on the bf16 matrix pipe (regress_tail_sb_kernel)
-    static const bool split_bf16 = getenv("TPU3_SPLIT_BF16") && atoi(getenv("TPU3_SPLIT_BF16")) != 0;
-    if (split_bf16) {
+    // (r6) split-bf16 arithmetic (tpu3_split_bf16 / TPU3_SPLIT_BF16): fp32 operands as three bf16 terms on the bf16
+    // matrix pipe (regress_tail_sb_kernel)
+    if (g_split_bf16) {
         const size_t ldsb = rb_lds_bytes();
         hipError_t eb = hipFuncSetAttribute((const void *)regress_tail_sb_kernel,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);

@@ -22,7 +22,12 @@ from .. import sampling
 import collections
 import os
 import warnings
+import weakref
 _DEBUG_UWS = bool(os.environ.get("TPU3_DEBUG_UWS"))
+# split-bf16 arithmetic (tpu3_split_bf16 / TPU3_SPLIT_BF16, with the regressor tail in csrc/mlp.hip): up_layer1's per-point
+# half on the bf16 matrix pipe with three-term operands; TPU3_SPLIT_BF16_WIDE=0 keeps this layer on the fp32 kernel
+_SPLIT_BF16_WIDE = os.environ.get("TPU3_SPLIT_BF16_WIDE", "1") not in ("0", "")
+_WIDE_SPLIT_CACHE = {}      # id(weight tensor) -> (weak reference, (version, address, row stride, cin), image, stream, event)
 
 # Every place where the network leaves a hand-written kernel for the generic PyTorch-ROCm formulation
 # (a shape the fused kernel does not cover: k not a multiple of 16, other channel counts, r > 4 ...)
@@ -586,10 +591,49 @@ class HipBackend(object):
         m = x.numel() // cin
         y = torch.empty(x.shape[:-1] + (cout,), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
+            if _SPLIT_BF16_WIDE and cin % 8 == 0 and not (x.data_ptr() & 31) and L.lib().tpu3_split_bf16(-1):
+                # fp32 operands as three bf16 terms (csrc/mlp.hip, linear_wide_sb_kernel)
+                ws = self._wide_split(weight, cin)
+                L.check(L.lib().tpu3_linear_wide_sb_f32(L.stream_of(x), m, cin, cout, L.ptr(x), cin, L.ptr(ws),
+                                                        L.ptr(bias), L.ptr(y), cout), "tpu3_linear_wide_sb_f32")
+                return y
             L.check(L.lib().tpu3_linear_wide_f32(L.stream_of(x), m, cin, cout, L.ptr(x), cin, L.ptr(weight),
                                                  weight.stride(0), L.ptr(bias), L.ptr(y), cout),
                     "tpu3_linear_wide_f32")
         return y
+
+    def split_bf16(self, on=None):
+        """Arithmetic of the regressor's matrix layers: True = three-term bf16 operands on the bf16 matrix pipe, False =
+        fp32 matrix instructions; None = query.  Returns the previous setting (initially TPU3_SPLIT_BF16)."""
+        return bool(L.lib().tpu3_split_bf16(-1 if on is None else int(bool(on))))
+
+    def _wide_split(self, weight, cin):
+        """The slab-major three-term bf16 image of weight[:, :cin] (tpu3_linear_wide_split_bf16), cached per WEIGHT
+        TENSOR: the entry lives as long as the tensor the view comes from (a weak reference -- an address alone is
+        reused by the allocator) and is rebuilt when its version counter, address or layout changed; built on one
+        stream, other streams order themselves behind the build (as the fold plans and Level._code_term do)."""
+        base = weight._base if weight._base is not None else weight
+        key = (base._version, weight.data_ptr(), weight.stride(0), cin)
+        here = torch.cuda.current_stream(weight.device)
+        hit = _WIDE_SPLIT_CACHE.get(id(base))
+        if hit is not None and hit[0]() is base and hit[1] == key:
+            if hit[3] != here.cuda_stream:
+                here.wait_event(hit[4])
+                hit[2].record_stream(here)
+            return hit[2]
+        ws = torch.empty((int(L.lib().tpu3_linear_wide_split_bytes(cin)),), dtype=torch.uint8, device=weight.device)
+        L.check(L.lib().tpu3_linear_wide_split_bf16(here.cuda_stream, cin, weight.size(0), L.ptr(weight), weight.stride(0),
+                                                    L.ptr(ws)), "tpu3_linear_wide_split_bf16")
+        done = torch.cuda.Event()
+        done.record(here)
+        ident = id(base)
+        _WIDE_SPLIT_CACHE[ident] = (weakref.ref(base, lambda _r, i=ident: _WIDE_SPLIT_CACHE.pop(i, None)), key, ws,
+                                    here.cuda_stream, done)
+        return ws
+
+    def invalidate_split_weights(self):
+        """Drop the cached split images (after an edit of a weight the version counter cannot see: `param.data`)."""
+        _WIDE_SPLIT_CACHE.clear()
 
     def linear_lift(self, x, weight, bias, relu, also=None):
         """Per-point linear layer with <= 8 input channels (the 3 -> 24 lift of a Level): x (..., C_in)

@@ -223,7 +223,8 @@ class Net(torch.nn.Module):
 
     def invalidate_weight_caches(self):
         """Drop every blob DERIVED from the weights: the packed DenseEdgeConv operand tables
-        (layers.DenseEdgeConv._operand_pack) and the folded prep convolutions (Level._fold_plan).  Both are keyed by the
+        (layers.DenseEdgeConv._operand_pack), the folded prep convolutions (Level._fold_plan) and the split-bf16 images of
+        up_layer1's weights (operations.HipBackend._wide_split).  All are keyed by the
         parameters' version counters and addresses, which `optimizer.step()`, `load_state_dict` and every in-place
         tensor method bump; an edit through `param.data` (p.data.copy_(), p.data.mul_()) bumps neither, so call this
         after one.  (The unpacked kernels read the weights at every launch; only the cached blobs can go stale.)"""
@@ -233,6 +234,8 @@ class Net(torch.nn.Module):
             elif isinstance(m, Level):
                 _FOLD_CACHES.pop(m, None)
                 _CODE_CACHES.pop(m, None)
+        if hasattr(operations.BACKEND, "invalidate_split_weights"):
+            operations.BACKEND.invalidate_split_weights()       # split-bf16 images of up_layer1's weights
         return self
 
     def set_mlp_precision(self, precision, activations=None):

@@ -367,8 +367,10 @@ class GraphedUpsample(object):
 
     def _weights_key(self):
         ps = list(self.net.parameters())
+        be = operations.BACKEND
         return (tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps),
-                tuple(getattr(m, "mlp_precision", None) for m in self.net.modules() if hasattr(m, "mlp_precision")))
+                tuple(getattr(m, "mlp_precision", None) for m in self.net.modules() if hasattr(m, "mlp_precision")),
+                be.split_bf16() if hasattr(be, "split_bf16") else None)     # (the capture bakes the kernel choice in)
 
     def invalidate(self):
         """Forget the captured graph (after a weight edit the version counters cannot see)."""

@@ -386,6 +386,21 @@ int tpu3_linear_small_st_f32(tpu3_stream_t stream, long m, int cin, int cout, co
 int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
                          const float *w, int w_stride, const float *bias, float *y, int y_stride);
 
+/* (r6) The same layer with every fp32 operand as three bf16 terms, six partial products each on
+ * v_mfma_f32_16x16x32_bf16 (opt-in: TPU3_SPLIT_BF16=1 on the Python side; as accurate as the fp32 kernel against fp64,
+ * not bit-identical to it).  tpu3_linear_wide_split_bf16 writes the slab-major image of W[:, :cin] once per set of
+ * weights (tpu3_linear_wide_split_bytes(cin) bytes, 16-byte aligned); tpu3_linear_wide_sb_f32 takes it in place of w.
+ * cout = 128, cin and x_stride multiples of 8, x 32-byte aligned (else TPU3_ELIMIT). */
+/* Arithmetic of the regressor's matrix layers (tpu3_regress_tail_f32 with mfma = TPU3_MFMA_F32, and -- on the Python side
+ * -- the choice between tpu3_linear_wide_f32 and tpu3_linear_wide_sb_f32): on = 1 three-term bf16 operands on
+ * v_mfma_f32_16x16x32_bf16, on = 0 the fp32 matrix instructions (bit-identical to an fmaf chain), on < 0 query only.
+ * Returns the previous setting; the initial one comes from TPU3_SPLIT_BF16. */
+int tpu3_split_bf16(int on);
+size_t tpu3_linear_wide_split_bytes(int cin);
+int tpu3_linear_wide_split_bf16(tpu3_stream_t stream, int cin, int cout, const float *w, int w_stride, void *ws);
+int tpu3_linear_wide_sb_f32(tpu3_stream_t stream, long m, int cin, int cout, const float *x, int x_stride,
+                            const void *ws, const float *bias, float *y, int y_stride);
+
 /* Per-point linear layer with a handful of INPUT channels, inference: the 3 -> 24 coordinate lift that opens
  * every Level (network/upsampler.py:209 `layer0 = Conv2d(3, 24, [1, 1], activation=None)`, applied at :288):
  *   y[i, 0..cout) = act(W x[i, 0..cin) + bias); optionally the same row is also stored at y2 (the slice of the

@@ -1177,10 +1177,21 @@ def test_gather_neighbours_forward_and_backward(dev, idx_dtype):
     assert (gx - x.grad).abs().max() < 1e-4 * max(1.0, float(x.grad.abs().max()))
 
 
-@pytest.mark.parametrize("m,cin", [(5000, 264), (17, 264), (1, 260), (4099, 272)])
-def test_linear_wide_matches_torch(dev, m, cin):
-    """tpu3_linear_wide_f32 (per-point half of up_layer1, 264 -> 128) against torch in fp64; the weight is a
-    column slice of the (128, 265) convolution weight like at its call site."""
+@pytest.fixture(params=["fp32", "split_bf16"])
+def regressor_form(request):
+    """The two arithmetic forms of the regressor's matrix layers (tpu3_split_bf16): the test body runs under each, the
+    setting of the process is restored afterwards."""
+    be = pkg("network.operations").BACKEND
+    old = be.split_bf16(request.param == "split_bf16")
+    yield request.param
+    be.split_bf16(old)
+
+
+@pytest.mark.parametrize("m,cin", [(5000, 264), (17, 264), (1, 260), (4099, 272), (128 * 700 + 3, 264)])
+def test_linear_wide_matches_torch(dev, m, cin, regressor_form):
+    """tpu3_linear_wide_f32 / tpu3_linear_wide_sb_f32 (per-point half of up_layer1, 264 -> 128) against torch in fp64;
+    the weight is a column slice of the (128, 265) convolution weight like at its call site.  (17, 264) after
+    (5000, 264): a new weight tensor at a recycled address must not find the previous one's split image.)"""
     ops = pkg("network.operations")
     g = torch.Generator(device="cpu").manual_seed(m + cin)
     x = torch.randn(m, cin, generator=g).to(dev)
@@ -1295,9 +1306,9 @@ def test_linear_wgrad_matches_torch(dev, m, cin, cout):
         assert torch.allclose(gb, conv.bias.grad, rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize("m,r", [(312, 2), (1000, 2), (17, 4), (4096 * 3 + 5, 1)])
-def test_regress_tail_matches_torch(dev, m, r):
-    """tpu3_regress_tail_f32 against the unfused torch formulation (fp64 reference)."""
+@pytest.mark.parametrize("m,r", [(312, 2), (1000, 2), (17, 4), (4096 * 3 + 5, 1), (40000, 3)])
+def test_regress_tail_matches_torch(dev, m, r, regressor_form):
+    """tpu3_regress_tail_f32 (both arithmetic forms) against the unfused torch formulation (fp64 reference)."""
     ops = pkg("network.operations")
     g = torch.Generator(device="cpu").manual_seed(m)
     a = torch.randn(m, 128, generator=g).to(dev)
@@ -1315,6 +1326,52 @@ def test_regress_tail_matches_torch(dev, m, r):
     ref = (h @ d(w4).t() + d(b4) + d(res).unsqueeze(1)).reshape(m * r, 3)
     assert out.shape == (m * r, 3)
     assert (out.double() - ref).abs().max() < 2e-5
+
+
+def test_split_bf16_forms_are_as_accurate_as_fp32(dev):
+    """The split-bf16 form of the two regressor kernels against their fp32 form on inputs with a wide dynamic range
+    (rows scaled over four decades, zero channels, weights of mixed magnitude): each within 1.5x the fp32 kernel's own
+    error against fp64 (+ 1e-6), the two within 1e-5 of each other relative to the row's magnitude -- and not
+    bit-identical (the switch really selects another kernel)."""
+    ops = pkg("network.operations")
+    be = ops.BACKEND
+    g = torch.Generator(device="cpu").manual_seed(11)
+    m = 20000
+    scale = 10.0 ** (torch.rand(m, 1, generator=g) * 4 - 2)
+    x = (torch.randn(m, 264, generator=g) * scale).to(dev)
+    x[:, 40:60] = 0
+    w = (torch.randn(128, 265, generator=g) * 10.0 ** (torch.rand(128, 1, generator=g) * 2 - 1.5) / 16).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    a_in = torch.randn(m, 128, generator=g).to(dev) * 3
+    c = torch.randn(2, 128, generator=g).to(dev)
+    w2 = (torch.randn(128, 128, generator=g) / 11).to(dev)
+    w3 = (torch.randn(64, 128, generator=g) / 11).to(dev)
+    w4 = (torch.randn(3, 64, generator=g) / 8).to(dev)
+    b2, b3, b4 = (torch.randn(n, generator=g).to(dev) for n in (128, 64, 3))
+    res = torch.randn(m, 3, generator=g).to(dev)
+    d = lambda t: t.double()
+    ref_wide = d(x) @ d(w[:, :264]).t() + d(b)
+    h = torch.relu(d(a_in).unsqueeze(1) + d(c).unsqueeze(0))
+    h = torch.relu(h @ d(w2).t() + d(b2))
+    h = torch.relu(h @ d(w3).t() + d(b3))
+    ref_tail = (h @ d(w4).t() + d(b4) + d(res).unsqueeze(1)).reshape(m * 2, 3)
+    old = be.split_bf16()
+    try:
+        out = {}
+        for form in (False, True):
+            be.split_bf16(form)
+            out[form] = (be.linear_wide(x, w[:, :264], b), be.regress_tail(a_in, c, w2, b2, w3, b3, w4, b4, res))
+    finally:
+        be.split_bf16(old)
+    for k, ref, name in ((0, ref_wide, "linear_wide"), (1, ref_tail, "regress_tail")):
+        e32 = float((d(out[False][k]) - ref).abs().max())
+        esb = float((d(out[True][k]) - ref).abs().max())
+        rel = float(((out[True][k] - out[False][k]).abs().max(1)[0] / (ref.abs().max(1)[0] + 1e-3)).max())
+        print("%s: max |err| vs fp64: fp32 form %.3e, split-bf16 form %.3e; forms differ by %.2e of the row's largest output"
+              % (name, e32, esb, rel))
+        assert esb <= 1.5 * e32 + 1e-6, (name, esb, e32)
+        assert rel < 1e-5, (name, rel)
+        assert not torch.equal(out[True][k], out[False][k]), name
 
 
 @pytest.mark.parametrize("m,cin,cout,relu", [(5000, 84, 24, True), (777, 204, 24, True), (4099, 144, 24, False),
