@@ -188,21 +188,22 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
     if shp:
         ex = sum(m * rr * 2.0 * (128 * 128 + 128 * 64 + 64 * 16) for m, rr in shp)
         ach = ex / (ms * 1e-3) / 1e12
-        split = os.environ.get("TPU3_SPLIT_BF16", "0") not in ("0", "")
+        split = bool(ops.BACKEND.split_bf16())
         if split:
             # six v_mfma_f32_16x16x32_bf16 per (output tile, slab pair) in layers 2 and 3, fp32 MFMAs in layer 4: the
             # EXECUTED matrix FLOP are 6x the layers' 2 * cin * cout per row, priced on the bf16 peak
             ex_b = sum(m * rr * 2.0 * 6 * (128 * 128 + 128 * 64) for m, rr in shp)
             out.append({"kernel": "regress_tail_sb_kernel (128->128->64->3, fp32 operands as 3 bf16 terms, 6 partial products on "
-                                  "v_mfma_f32_16x16x32_bf16; TPU3_SPLIT_BF16=1), %d launches/step" % len(shp),
+                                  "v_mfma_f32_16x16x32_bf16; two replicas per weight operand), %d launches/step" % len(shp),
                         "bound": "mfma", "achieved": ex_b / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": ex_b / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF,
                         "basis": "executed bf16 MFMA FLOPs (6 partial products per fp32 product) against the dense bf16 peak; "
                                  "on the fp32 model (2 * cin * cout per row) the kernel delivers %.1f TFLOP/s = %.2f of the fp32 "
                                  "MFMA peak" % (ach, ach / FP32_PEAK_TF),
-                        "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex_b, "traffic": None})
+                        "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex_b,
+                        "traffic": tr("regress_tail_sb_kernel")})
         else:
-            out.append({"kernel": "regress_tail_kernel (128->128->64->3, fp32 MFMA), %d launches/step" % len(shp),
+            out.append({"kernel": "regress_tail_kernel (128->128->64->3, fp32 MFMA; TPU3_SPLIT_BF16=0), %d launches/step" % len(shp),
                         "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                         "basis": "executed MFMA FLOPs (last layer padded 3 -> 16 rows)", "ms_per_step": ms,
                         "ms_per_step_min_max": spread, "executed_flop_per_step": ex, "traffic": tr("regress_tail_kernel")})
@@ -211,7 +212,25 @@ def other_rooflines(ops, pipe, net, clouds, npnt, r, traffic, reps=5):
         # executed: per 16 rows 17 slabs x 8 output tiles x 4 MFMAs (264 channels padded to 272)
         ex = sum(-(-m // 16) * 17 * 8 * 4 * 2048.0 for m, cin, cout in shp)
         ach = ex / (ms * 1e-3) / 1e12
-        out.append({"kernel": "linear_wide_kernel (up_layer1 per point, 264 -> 128, fp32 MFMA), %d launches/step" % len(shp),
+        if bool(ops.BACKEND.split_bf16()) and os.environ.get("TPU3_SPLIT_BF16_WIDE", "1") not in ("0", ""):
+            # per 16 rows: 9 slabs of 32 channels (264 padded to 288) x 8 output tiles x 6 partial products of 16384 FLOP
+            ex_b = sum(-(-m // 16) * 9 * 8 * 6 * 16384.0 for m, cin, cout in shp)
+            alg = sum(m * 2.0 * cin * cout for m, cin, cout in shp)
+            byt = sum(m * 4.0 * (cin + cout) for m, cin, cout in shp)
+            out.append({"kernel": "linear_wide_sb_kernel (up_layer1 per point, 264 -> 128, fp32 operands as 3 bf16 terms, 6 partial "
+                                  "products on v_mfma_f32_16x16x32_bf16, weight slabs through an LDS ring), %d launches/step" % len(shp),
+                        "bound": "mfma", "achieved": ex_b / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ex_b / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF,
+                        "basis": "executed bf16 MFMA FLOPs (6 partial products per fp32 product, 264 of 288 k slots useful) against "
+                                 "the dense bf16 peak; on the fp32 model (2 * cin * cout per row) %.1f TFLOP/s = %.2f of the fp32 MFMA "
+                                 "peak; its rows in and out are %.0f GB/s = %.2f of the HBM peak" % (
+                                     alg / (ms * 1e-3) / 1e12, alg / (ms * 1e-3) / 1e12 / FP32_PEAK_TF,
+                                     byt / (ms * 1e-3) / 1e9, byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                        "ms_per_step": ms, "ms_per_step_min_max": spread, "executed_flop_per_step": ex_b,
+                        "traffic": tr("linear_wide_sb_kernel")})
+            ms = None
+    if shp and ms is not None:
+        out.append({"kernel": "linear_wide_kernel (up_layer1 per point, 264 -> 128, fp32 MFMA; TPU3_SPLIT_BF16=0), %d launches/step" % len(shp),
                     "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF,
                     "basis": "executed v_mfma_f32_16x16x4 FLOPs (264 of 272 k slots useful)", "ms_per_step": ms, "ms_per_step_min_max": spread,
                     "executed_flop_per_step": ex, "traffic": tr("linear_wide_kernel")})
@@ -940,10 +959,10 @@ def main():
             "value": total_points / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if patch_mode else "weak", "vs_baseline": None,
-            # (TPU3_SPLIT_BF16=1, opt-in: the regressor tail's fp32 operands as three bf16 terms each on the bf16 matrix
-            # pipe, fp32 accumulate -- profiles/r06_split_bf16_end_to_end.txt)
-            "dtype": ("f32 (3xbf16 split operands in the regressor tail, fp32 accumulate)"
-                      if os.environ.get("TPU3_SPLIT_BF16", "0") not in ("0", "") else "f32"),
+            # (r6, the default since the end-to-end gain passed 10 ms: the regressor's two matrix kernels take their fp32
+            # operands as three bf16 terms each on the bf16 matrix pipe, fp32 accumulate; everything else is fp32
+            # arithmetic; TPU3_SPLIT_BF16=0 restores fp32 matrix instructions -- profiles/r06_split_bf16_end_to_end.txt)
+            "dtype": "f32 (3xbf16 split operands, fp32 accumulate)" if ops.BACKEND.split_bf16() else "f32",
             "data": "synthetic",
             "config": {"workload": "C2: %d cloud(s)/GPU x %d pts, num_point=%d, up_ratio=%d (4 levels), "
                                    "%d outer patches, knn=32, random-init weights, Poisson-sphere input"

@@ -42,5 +42,5 @@ lpass WRITE_SIZE WRITE_SIZE
 tail -1 $O/bench_default.json | cut -c1-300
 python tools/kstats.py $O/kernel_stats_single_stream.csv 5 16
 python tools/kstats.py $O/kernel_stats_losses.csv 20 30
-grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|knn_graph\|knn_slab\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
+grep -h "fl_main\|fm_main\|dec_fused\|regress_tail\|linear_small\|linear_wide\|wide_split\|knn_graph\|knn_slab\|rl_main\|skip_" $O/pmc_*_by_kernel.txt | cut -c1-260
 rm -rf gpurun_out/prof

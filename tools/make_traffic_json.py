@@ -54,7 +54,7 @@ def find(tab, key):
 
 
 others, mfma = {}, {}
-for key in ("dec_fused", "knn_graph_key_kernel", "knn_graph_slab_kernel", "knn_slab_order_kernel", "regress_tail_kernel", "linear_small_kernel", "linear_wide_kernel",
+for key in ("dec_fused", "knn_graph_key_kernel", "knn_graph_slab_kernel", "knn_slab_order_kernel", "regress_tail_kernel", "regress_tail_sb_kernel", "linear_small_kernel", "linear_wide_kernel", "linear_wide_sb_kernel",
             "linear_lift_kernel", "skip_", "rl_main_kernel", "knn_insert_kernel", "knn_select_kernel", "knn_dup_lds"):
     f, w = find(F, key), find(Wr, key)
     if f and w:
