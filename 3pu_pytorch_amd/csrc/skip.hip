@@ -49,6 +49,7 @@ struct SkipArgs {
     float *dist;                     // scratch (B,n,2K): spatial then feature distances
     float *mins;                     // scratch (B,n,2): min_k of either
     float *wout;                     // training: (B,n,K) receives the normalised weights, else null
+    int debug_phase;                 // (TPU3_DEBUG_SKIP_PHASE, timing probes only: 1 = the distance phase alone, 2 = the update alone)
 };
 
 // workgroup -> (patch, slice).  Workgroups are dealt round-robin to the 8 XCDs, each with its own
@@ -491,9 +492,11 @@ __global__ __launch_bounds__(SKF_THREADS) void skip_fused_kernel(SkipArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_sm[];
     float *ds = sk_sm, *mn = sk_sm + (size_t)a.n * K * 2;
-    skip_dist_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (const T *)a.feat, ds, mn);
+    if (a.debug_phase != 2)
+        skip_dist_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (const T *)a.feat, ds, mn);
     __syncthreads();
-    skip_apply_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, ds, mn);
+    if (a.debug_phase != 1)
+        skip_apply_body<K, VEC, TAIL, T, SKF_THREADS, true>(a, a.idx, (T *)a.feat, (const T *)a.prev_feat, ds, mn);
 }
 
 // (r4, measured and removed -- commit cc6a076 has the kernels): a DPP ROW of 16 lanes per point, four points per wave
@@ -515,6 +518,8 @@ int skip_launch(hipStream_t s, int blocks, const SkipArgs &a, bool vec, bool hal
     const size_t lds = (size_t)a.n * (K + 1) * 8;
     if (g_skip_fused && (vec || half) && !a.wout && lds <= 64 * 1024) {
         SkipArgs f = a;
+        static const int dbg_phase = getenv("TPU3_DEBUG_SKIP_PHASE") ? atoi(getenv("TPU3_DEBUG_SKIP_PHASE")) : 0;
+        f.debug_phase = dbg_phase;
         const int patches = blocks / a.slices;
         f.slices = 1;
         f.slice_len = a.n;
@@ -690,7 +695,7 @@ int skip_forward(hipStream_t s, int b, int n, int k, int c, const float *xyz, vo
     const int remap = per ? (b / per / 8) * 8 * per * slices : 0;
     float *dist = (float *)workspace;
     SkipArgs a{n, k, c, feat_stride, m, xyz, feat, prev_xyz, prev_feat, pts_of, idx, idx_elem_size == 8, scale,
-               per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k, wout};
+               per, remap, slices, slice_len, dist, dist + (size_t)b * n * 2 * k, wout, 0};
     // float4 rows: every row start must be 16-byte aligned (fp16 rows: four channels = 8 bytes per lane)
     const bool half = store == TPU3_STORE_F16;
     const uintptr_t amask = half ? 7 : 15;
