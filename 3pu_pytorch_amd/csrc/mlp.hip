@@ -565,12 +565,23 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 // the fp32 accumulation order differs -- but as accurate (probe: 1.2x / 1.0x the fp32 kernel's error against fp64).
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-constexpr int RB_S = 136;                 // bf16 row stride of the 128-wide weight rows (conflict-free 8-byte reads)
+constexpr int RB_S = 128;                 // bf16 elements per weight row; in LDS the rows are stored OPERAND-major (rb_slot): a lane's eight k
+                                          // values of an (output tile, slab pair) are 16 contiguous bytes at 16 * lane -- one conflict-free
+                                          // ds_read_b128 (two ds_read_b64 per operand reach a fifth of their rate at two waves per SIMD)
 constexpr int RB_S4 = 68;                 // fp32 row stride of W4, FOUR rows (row 3 = zeros, read by every point >= 3)
 
 constexpr size_t rb_lds_bytes()
 {
     return ((size_t)3 * RT_C2 * RB_S + 3 * RT_C3 * RB_S) * 2 + (4 * RB_S4 + RT_C2 + RT_C3 + 16 + RT_RMAX * RT_C1) * 4;
+}
+
+// LDS position of weight (output row m, input channel ch) of a 128-input layer: [output tile][slab pair S][k quad q][row pt][8],
+// the eight being the lane's k slots of the slab pair: channels 32 S + 4 q + (0..3) and 32 S + 16 + 4 q + (0..3) -- the two
+// accumulator quads the B operand is made of
+__device__ __forceinline__ int rb_slot(int m, int ch)
+{
+    const int S = ch >> 5, w = ch & 31, half = w >> 4, q = (w & 15) >> 2, j = w & 3;
+    return ((((m >> 4) * (RB_S / 32) + S) * 4 + q) * 16 + (m & 15)) * 8 + half * 4 + j;
 }
 
 __device__ __forceinline__ void rb_split3(const v4f lo, const v4f hi, bf8 &t1, bf8 &t2, bf8 &t3)
@@ -586,18 +597,6 @@ __device__ __forceinline__ void rb_split3(const v4f lo, const v4f hi, bf8 &t1, b
     }
 }
 
-__device__ __forceinline__ bf8 rb_w8(const __bf16 *w, int m, int S, int q)
-{
-    const bf4 lo = *(const bf4 *)(w + m * RB_S + 32 * S + 4 * q), hi = *(const bf4 *)(w + m * RB_S + 32 * S + 16 + 4 * q);
-    bf8 r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[j] = lo[j];
-        r[4 + j] = hi[j];
-    }
-    return r;
-}
-
 // the six partial products of one (output tile, slab pair), smallest first
 #define RB_MFMA6(acc, A1, A2, A3, X1, X2, X3)                                        \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, X1, acc, 0, 0, 0);             \
@@ -610,8 +609,8 @@ __device__ __forceinline__ bf8 rb_w8(const __bf16 *w, int m, int S, int q)
 __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    __bf16 *w2 = (__bf16 *)ldsb;                  // [3][128][136]
-    __bf16 *w3 = w2 + 3 * RT_C2 * RB_S;           // [3][64][136]
+    __bf16 *w2 = (__bf16 *)ldsb;                  // [3][128 x 128 in rb_slot order]
+    __bf16 *w3 = w2 + 3 * RT_C2 * RB_S;           // [3][64 x 128 in rb_slot order]
     float *w4 = (float *)(w3 + 3 * RT_C3 * RB_S); // [4][68] fp32, row 3 zero
     float *b2 = w4 + 4 * RB_S4;                   // [128]
     float *b3 = b2 + RT_C2;                       // [64]
@@ -623,7 +622,7 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
         const __bf16 p1 = (__bf16)x;
         const float r1 = x - (float)p1;
         const __bf16 p2 = (__bf16)r1;
-        const int o = (i >> 7) * RB_S + (i & 127);
+        const int o = rb_slot(i >> 7, i & 127);
         dst[o] = p1;
         dst[rows * RB_S + o] = p2;
         dst[2 * rows * RB_S + o] = (__bf16)(r1 - (float)p2);
@@ -647,20 +646,18 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
     const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int pt = lane & 15, q = lane >> 4;
     const long ntiles = (a.m + 15) >> 4;
-    // one LANE base per array (row pt, k quad q), laundered: folded back into "w2 + a large constant" every operand
+    // one LANE base per array (16 bytes per lane), laundered: folded back into "w2 + a large constant" every operand
     // would get its own address register (offsets beyond the 16-bit immediate), ~60 of them spilled around the loop
     auto lane_base = [&](const __bf16 *w) __attribute__((always_inline)) {
-        uint32_t o = (uint32_t)(uintptr_t)(w + pt * RB_S + 4 * q);
+        uint32_t o = (uint32_t)(uintptr_t)(w + 8 * lane);
         asm volatile("" : "+v"(o));
         return (const __attribute__((address_space(3))) __bf16 *)(uintptr_t)o;
     };
     const auto w2a = lane_base(w2), w2b = lane_base(w2 + RT_C2 * RB_S), w2c = lane_base(w2 + 2 * RT_C2 * RB_S);
     const auto w3a = lane_base(w3), w3b = lane_base(w3 + RT_C3 * RB_S), w3c = lane_base(w3 + 2 * RT_C3 * RB_S);
-    // operand of output tile t, slab pair S: the lane's two k quads
+    // operand of output tile t, slab pair S: the lane's eight k slots, one ds_read_b128
     auto w8 = [](const __attribute__((address_space(3))) __bf16 *base, int t, int S) __attribute__((always_inline)) {
-        const bf4 lo = *(const __attribute__((address_space(3))) bf4 *)(base + 16 * t * RB_S + 32 * S);
-        const bf4 hi = *(const __attribute__((address_space(3))) bf4 *)(base + 16 * t * RB_S + 32 * S + 16);
-        return (bf8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return *(const __attribute__((address_space(3))) bf8 *)(base + (t * (RB_S / 32) + S) * 512);
     };
     // The tile's rows (32 registers) and residuals are fetched a TILE ahead: into the registers the second layer has
     // just finished with, while the third and fourth run (for more than two replicas the row is read again per pair).
@@ -702,7 +699,16 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
 #define RB_P(ACC, AU, XV)                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
         _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                      \
-            ACC[jj][tg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[AU][t], XV[jj], ACC[jj][tg + t], 0, 0, 0);
+            ACC[jj][tg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aq[cur][AU][t], XV[jj], ACC[jj][tg + t], 0, 0, 0);
+            // the weight operands of a group of two output tiles are read one group AHEAD of their products (two register
+            // sets): read just before use, every group began with an LDS round trip that two waves per SIMD do not hide
+            // -- an ablation without the reads ran at 0.35 instead of 0.69 ms per chunk
+#define RB_LA(BUF, WA, WB, WC, TG, SS)                                                                         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                           \
+        Aq[BUF][0][t] = w8(WA, (TG) + t, SS); Aq[BUF][1][t] = w8(WB, (TG) + t, SS); Aq[BUF][2][t] = w8(WC, (TG) + t, SS); \
+    }
+            bf8 Aq[2][3][2];
+            RB_LA(0, w2a, w2b, w2c, 0, 0)
 #pragma unroll
             for (int S = 0; S < RT_C1 / 32; ++S) {
                 bf8 x1[2], x2[2], x3[2];
@@ -718,16 +724,16 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
                     rb_split3(v[0], v[1], x1[jj], x2[jj], x3[jj]);
                 }
 #pragma unroll
-                for (int tg = 0; tg < RT_C2 / 16; tg += 2) {
-                    bf8 A[3][2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        A[0][t] = w8(w2a, tg + t, S);
-                        A[1][t] = w8(w2b, tg + t, S);
-                        A[2][t] = w8(w2c, tg + t, S);
+                for (int g = 0; g < RT_C2 / 32; ++g) {
+                    const int gi = S * (RT_C2 / 32) + g, cur = gi & 1, tg = 2 * g;
+                    if (gi + 1 < (RT_C1 / 32) * (RT_C2 / 32)) {
+                        RB_LA(cur ^ 1, w2a, w2b, w2c, 2 * ((g + 1) % (RT_C2 / 32)), S + (g + 1) / (RT_C2 / 32))
+                    } else {
+                        RB_LA(cur ^ 1, w3a, w3b, w3c, 0, 0)         // the third layer's first group
                     }
+                    __builtin_amdgcn_sched_barrier(0);      // (the reads FIRST: left to itself the scheduler issues them last)
                     RB_P(t1, 2, x1) RB_P(t1, 0, x3) RB_P(t1, 1, x2) RB_P(t1, 1, x1) RB_P(t1, 0, x2) RB_P(t1, 0, x1)
-                    __builtin_amdgcn_sched_barrier(0);      // (one group's operand registers at a time)
+                    __builtin_amdgcn_sched_barrier(0);      // (two groups' operand registers at a time)
                 }
             }
             if (j0 + 2 >= a.r)
@@ -754,19 +760,18 @@ __global__ __launch_bounds__(512) void regress_tail_sb_kernel(TailArgs a)
                     rb_split3(v[0], v[1], x1[jj], x2[jj], x3[jj]);
                 }
 #pragma unroll
-                for (int tg = 0; tg < RT_C3 / 16; tg += 2) {
-                    bf8 A[3][2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        A[0][t] = w8(w3a, tg + t, S);
-                        A[1][t] = w8(w3b, tg + t, S);
-                        A[2][t] = w8(w3c, tg + t, S);
+                for (int g = 0; g < RT_C3 / 32; ++g) {
+                    const int gi = S * (RT_C3 / 32) + g, cur = gi & 1, tg = 2 * g;      // (sixteen groups before: even)
+                    if (gi + 1 < (RT_C2 / 32) * (RT_C3 / 32)) {
+                        RB_LA(cur ^ 1, w3a, w3b, w3c, 2 * ((g + 1) % (RT_C3 / 32)), S + (g + 1) / (RT_C3 / 32))
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                     RB_P(t2, 2, x1) RB_P(t2, 0, x3) RB_P(t2, 1, x2) RB_P(t2, 1, x1) RB_P(t2, 0, x2) RB_P(t2, 0, x1)
-                    __builtin_amdgcn_sched_barrier(0);      // (one group's operand registers at a time)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #undef RB_P
+#undef RB_LA
             // layer 4: 64 -> 3 on relu(t2 + b3), fp32 operands (slab s of the B operand IS accumulator tile s)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
