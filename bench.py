@@ -34,6 +34,8 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
                     the reference's own Python driver for the same cloud and weights (tests/golden/c2_x16.npz)
   value_1cloud      BASELINE's C2 read literally: ONE cloud at a time (the faster of eager / hipGraph replay) -> points/s
   value_8clouds     config C4's per-rank share: 8 clouds per GPU per step -> points/s
+  value_fp32_matrix_instructions   the same step with the regressor's two matrix kernels on the fp32 matrix instructions
+                    (TPU3_SPLIT_BF16=0) instead of the default three-term bf16 operands: what `dtype` names, side by side
   extras            latency_ms_1cloud (+ _eager), ms_per_step_8clouds, train_step_ms (C3: B = 32, ratio 16),
                     chamfer_80k_ms, c5 (stress) ...
 """
@@ -1081,6 +1083,24 @@ def main():
                 line["rooflines_train"] = "failed: %s" % (str(e).splitlines()[0][:160])
             assert ops.BACKEND.graph_dup_events() == 0 and int(net.small_cloud_events) == 0, \
                 "an optimistic kNN graph / small-cloud event in the untimed extras: their numbers are not final"
+            if ops.BACKEND.split_bf16() and not multi and not patch_mode:
+                # the SAME step with the regressor's two matrix kernels on the fp32 matrix instructions (TPU3_SPLIT_BF16=0),
+                # next to `value`: what the split-bf16 default buys, measured in this process on this box
+                was = ops.BACKEND.split_bf16(False)
+                try:
+                    for _ in range(2):
+                        step()
+                    fence()
+                    k_alt = max(1, min(args.steps, 10))
+                    t_alt = time.perf_counter()
+                    for _ in range(k_alt):
+                        step()
+                    fence()
+                    ms_alt = (time.perf_counter() - t_alt) / k_alt * 1e3
+                finally:
+                    ops.BACKEND.split_bf16(was)
+                line["value_fp32_matrix_instructions"] = C * N * r / (ms_alt * 1e-3)
+                line["ms_per_step_fp32_matrix_instructions"] = ms_alt
         if not args.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (bench contract)
             from oracle import cpu_baseline
             base, cpu_out = cpu_baseline.measure_c1()
