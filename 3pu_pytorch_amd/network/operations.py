@@ -932,6 +932,11 @@ class GatherFunction(torch.autograd.Function):
 gather_points = GatherFunction.apply
 
 
+# Set by pipeline._upsample while it enqueues one sub-batch on its stream: called with "network_done" just before a level's
+# resampling FPS is enqueued and with "resample_enqueued" just after (the stage boundaries the sub-batches are staggered at).
+STAGE_HOOK = None
+
+
 def fps(xyz, npoint, n_arr=None, m_arr=None):
     """Channel-last FPS: xyz (B,N,3) -> idx int32 (B,npoint); ragged counts optional."""
     return BACKEND.fps(xyz.contiguous(), npoint, n_arr, m_arr)

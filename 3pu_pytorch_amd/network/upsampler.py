@@ -328,7 +328,12 @@ class Net(torch.nn.Module):
             if P > 1:
                 # resample to num_point * curr_ratio points (reference :156-159)
                 num_output_point = num_point * curr_ratio
+                hook = operations.STAGE_HOOK
+                if hook is not None:
+                    hook("network_done")        # (pipeline._upsample: the stagger of concurrent sub-batches)
                 idx = operations.fps(merged, num_output_point, n_arr=m_count, m_arr=None)
+                if hook is not None:
+                    hook("resample_enqueued")
                 if merged.is_cuda and hasattr(be, "gather_xyz"):
                     xyz_cl = be.gather_xyz(merged, idx)
                 else:

@@ -142,7 +142,7 @@ def _any_rank(flag, device):
 @torch.no_grad()
 def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
              timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, check_small=None,
-             optimistic_graph=None):
+             optimistic_graph=None, stagger=None):
     """See _upsample.
     check_small: after enqueueing, synchronise, (i) recompute with the exact kNN-graph form if an optimistic graph
     call reported possibly duplicated feature rows, and (ii) raise if the outlier filter left some cloud with fewer
@@ -172,7 +172,7 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
             be.optimistic_graph = bool(optimistic)
         try:
             return _upsample(net, clouds, num_point, up_ratio, patch_num_ratio, shard, final_fps, timing, fps_stream,
-                             net_streams, sub_batch, fps_offset)
+                             net_streams, sub_batch, fps_offset, stagger)
         finally:
             if saved is not None:
                 be.optimistic_graph = saved
@@ -213,9 +213,13 @@ def upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, fi
     return out
 
 
+# Staggering of concurrent sub-batches (upsample(net_streams=...)): on by default, TPU3_STAGGER=0 turns it off (A/B runs)
+_STAGGER = int(os.environ.get("TPU3_STAGGER", "1")) != 0
+
+
 @torch.no_grad()
 def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, final_fps=True,
-              timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0):
+              timing=None, fps_stream=None, net_streams=None, sub_batch=4, fps_offset=0, stagger=None):
     """Upsample a batch of clouds (C,3,N) -> (C,3,N*up_ratio)  [main.py test() :360-380 without
     the file I/O].  `shard`: None (no distribution), "clouds" or "patches" (see module doc).
     Every rank passes the same `clouds` and receives the full result.
@@ -232,7 +236,9 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
     `sub_batch` clouds whose network stages run concurrently (round-robin over the streams).  The
     per-level resampling FPS is a latency chain on a few wavefronts per patch set while the kNN /
     DenseEdgeConv kernels are throughput-bound: one sub-batch's FPS hides under another's matrix
-    work."""
+    work.  `stagger` (default: on, TPU3_STAGGER=0 off): the sub-batches enter a level one behind the
+    other instead of in lockstep, and with a single `fps_stream` their join happens on THAT stream,
+    so the caller's next call does not wait for this one's last sub-batch."""
     C, _, N = clouds.shape
     rank, world = _world()
     # main.py:379-380: the one big FPS down to N * up_ratio points per cloud
@@ -262,14 +268,38 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         if split_fps:
             for f in fps_stream:
                 f.wait_stream(cur)                      # `result` is allocated on the current stream
+        mode = _STAGGER if stagger is None else bool(stagger)
+        prev_ev = None
         for i, lo in enumerate(range(0, C, per)):
             s = net_streams[i % len(net_streams)]
             with torch.cuda.stream(s):
-                sub = clouds[lo:lo + per]
-                _, patches, _ = extract_outer_patches(sub, num_point, patch_num_ratio)
-                P = patches.size(1)
-                up, _ = upsample_patches(net, patches.reshape(sub.size(0) * P, num_point, 3), up_ratio)
-                part = up.reshape(sub.size(0), P * up.size(1), 3)
+                my_ev = []
+                if mode:
+                    # STAGGER: a stage = a level's network kernels + its resampling FPS (operations.STAGE_HOOK marks
+                    # the boundaries).  Sub-batch i+1 enters stage k only when sub-batch i has left it (events, no host
+                    # synchronisation): the sub-batches spread over the stages instead of all reaching the same FPS
+                    # at once.  (The per-level FPS is not a few idle units to hide under other work -- its 16-wave
+                    # workgroups take a compute unit's whole register file each, 192 per 4-cloud sub-batch --, so the
+                    # gain is the smoother mix and, below, no drain per call: ~1 % of the bench step.)
+                    def hook(what, s=s, my_ev=my_ev, prev_ev=prev_ev):
+                        if what == "resample_enqueued":
+                            e = torch.cuda.Event()
+                            e.record(s)                             # this sub-batch has left stage len(my_ev)
+                            my_ev.append(e)
+                            if prev_ev is not None and len(my_ev) < len(prev_ev):
+                                s.wait_event(prev_ev[len(my_ev)])   # the next stage: after the sub-batch in front
+                    if prev_ev:
+                        s.wait_event(prev_ev[0])
+                    operations.STAGE_HOOK = hook
+                try:
+                    sub = clouds[lo:lo + per]
+                    _, patches, _ = extract_outer_patches(sub, num_point, patch_num_ratio)
+                    P = patches.size(1)
+                    up, _ = upsample_patches(net, patches.reshape(sub.size(0) * P, num_point, 3), up_ratio)
+                    part = up.reshape(sub.size(0), P * up.size(1), 3)
+                finally:
+                    operations.STAGE_HOOK = None
+                prev_ev = my_ev if mode else None
             if split_fps:
                 f = fps_stream[(fps_offset + i) % len(fps_stream)]
                 f.wait_stream(s)
@@ -281,6 +311,15 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
                 parts.append(part)
         if split_fps:
             return result
+        if mode and final_fps and fps_stream is not None and not isinstance(fps_stream, (list, tuple)):
+            # the join of the sub-batches on the FINAL-FPS stream, not on the caller's: the caller's next call then
+            # finds its network streams free as each finishes -- no drain of the staggered pipeline per call
+            for s in net_streams:
+                fps_stream.wait_stream(s)
+            for t in parts:
+                t.record_stream(fps_stream)
+            with torch.cuda.stream(fps_stream):
+                return final(torch.cat(parts, dim=0))
         for s in net_streams:
             cur.wait_stream(s)
         for t in parts:
@@ -296,7 +335,7 @@ def _upsample(net, clouds, num_point, up_ratio, patch_num_ratio=3, shard=None, f
         mine = clouds[ids]
         local = _upsample(net, mine, num_point, up_ratio, patch_num_ratio, shard=None, final_fps=final_fps,
                           timing=timing, fps_stream=fps_stream, net_streams=net_streams, sub_batch=sub_batch,
-                          fps_offset=fps_offset)
+                          fps_offset=fps_offset, stagger=stagger)
         for f in (fps_stream if isinstance(fps_stream, (list, tuple)) else [fps_stream]):
             if f is not None:
                 torch.cuda.current_stream().wait_stream(f)

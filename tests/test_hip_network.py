@@ -708,6 +708,20 @@ def test_pipeline_concurrent_sub_batches_and_side_stream(orc, dev):
     assert out.shape == ref.shape == (3, 3, 4000)
     for i in range(3):
         assert _set_close(orc, out[i:i + 1].cpu().numpy(), ref[i:i + 1].cpu().numpy()) >= 0.99
+    # (r6) the stagger of the sub-batches (on by default) only orders launches: the same bits with and without, with the
+    # join on the side stream or on the caller's, one cloud per sub-batch on three streams, and called twice in a row
+    torch.cuda.synchronize()
+    plain = pipe.upsample(net, clouds, 312, 4, 3, net_streams=nets, fps_stream=side, stagger=False)
+    side.synchronize()
+    assert torch.equal(plain, out)
+    nets3 = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    a = pipe.upsample(net, clouds, 312, 4, 3, net_streams=nets3, fps_stream=side, sub_batch=1, stagger=True)
+    b = pipe.upsample(net, clouds, 312, 4, 3, net_streams=nets3, fps_stream=side, sub_batch=1, stagger=True)
+    c = pipe.upsample(net, clouds, 312, 4, 3, net_streams=nets3, sub_batch=1, stagger=True)      # join on the caller's stream
+    torch.cuda.synchronize()
+    one = torch.cat([pipe.upsample(net, clouds[i:i + 1], 312, 4, 3) for i in range(3)])
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, one)
+    assert pkg("network.operations").STAGE_HOOK is None
 
 
 def test_full_size_config_c2_properties(orc, dev):
