@@ -799,10 +799,7 @@ def main():
     # side streams, used round-robin: the final FPS launches of consecutive steps occupy different
     # CUs (one per cloud) and overlap each other as well as the following steps' network stages
     sides = None if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(args.fps_streams)]
-    # (experiment knob) TPU3_BENCH_PRIO=k: the first k network streams get the high priority
-    n_hi = int(os.environ.get("TPU3_BENCH_PRIO", "0"))
-    nets = [torch.cuda.Stream(device=dev, priority=-1 if i < n_hi else 0)
-            for i in range(args.net_streams)] if args.net_streams > 1 else None
+    nets = [torch.cuda.Stream(device=dev) for _ in range(args.net_streams)] if args.net_streams > 1 else None
     counter = [0]
 
     split = sides is not None and nets is not None and args.fps_per_sub_batch and not patch_mode
