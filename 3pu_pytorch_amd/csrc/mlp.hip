@@ -564,7 +564,6 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 // and its weights would not fit).  The result is NOT bit-identical to the fp32 kernel's -- products are exact in both,
 // the fp32 accumulation order differs -- but as accurate (probe: 1.2x / 1.0x the fp32 kernel's error against fp64).
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 constexpr int RB_S = 128;                 // bf16 elements per weight row; in LDS the rows are stored OPERAND-major (rb_slot): a lane's eight k
                                           // values of an (output tile, slab pair) are 16 contiguous bytes at 16 * lane -- one conflict-free
                                           // ds_read_b128 (two ds_read_b64 per operand reach a fifth of their rate at two waves per SIMD)
@@ -918,7 +917,7 @@ constexpr int WSB_SLAB = 3 * 128 * 32;              // bf16 elements of one weig
 
 struct WideSbArgs {
     long m;
-    int cin, xs, ys, nsb;
+    int cin, xs, ys;
     const float *x, *b;
     const __bf16 *ws;                               // [nsb][3][8 tiles][4 k octets][16 outputs][8 k]
     float *y;
@@ -1175,7 +1174,7 @@ extern "C" int tpu3_linear_wide_sb_f32(tpu3_stream_t stream, long m, int cin, in
     if (!x || !ws || !y) return TPU3_EINVAL;
     if (((uintptr_t)x & 31) || (((uintptr_t)y | (uintptr_t)bias | (uintptr_t)ws) & 15)) return TPU3_ELIMIT;
     static const int cus = []() { int d = 0, v = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
-    WideSbArgs sa{m, cin, x_stride, y_stride, (cin + 31) / 32, x, bias, (const __bf16 *)ws, y};
+    WideSbArgs sa{m, cin, x_stride, y_stride, x, bias, (const __bf16 *)ws, y};
     long blocks = (m + WSB_ROWS - 1) / WSB_ROWS;
     const long cap = (long)cus * WSB_RESIDENT;          // what is resident at once: a third wave of workgroups would run alone at the end
     if (blocks > cap) blocks = cap;
