@@ -84,6 +84,39 @@ def test_argument_validation_without_gpu():
     assert lib.tpu3_interlevel_skip_workspace_bytes(3, 312, 5) == 3 * 312 * 12 * 4
     assert lib.tpu3_interlevel_skip_f32(None, 1, 312, 9, 264, 8, 8, 264, 8, 8, 10, None, 8, 4, 0.2, 0, None, 0) == -1
     assert lib.tpu3_fps_workspace_bytes(4, 1000) == 0 and lib.tpu3_fps_workspace_bytes(4, 30000) > 0
+    # (r6) the split-bf16 form of up_layer1's per-point half
+    assert lib.tpu3_linear_wide_split_bytes(264) == 9 * 3 * 128 * 32 * 2 and lib.tpu3_linear_wide_split_bytes(0) == 0
+    assert lib.tpu3_linear_wide_split_bf16(None, 264, 128, None, 265, 32) == -1                  # no weights
+    assert lib.tpu3_linear_wide_split_bf16(None, 264, 64, 32, 265, 32) == -2                     # 64 outputs
+    assert lib.tpu3_linear_wide_split_bf16(None, 264, 128, 32, 200, 32) == -1                    # stride < cin
+    assert lib.tpu3_linear_wide_sb_f32(None, 0, 264, 128, None, 264, None, None, None, 128) == 0
+    assert lib.tpu3_linear_wide_sb_f32(None, 4, 264, 128, 32, 264, None, None, 32, 128) == -1    # no split image
+    assert lib.tpu3_linear_wide_sb_f32(None, 4, 260, 128, 32, 264, 32, None, 32, 128) == -2      # cin % 8
+    assert lib.tpu3_linear_wide_sb_f32(None, 4, 264, 128, 48, 264, 32, None, 32, 128) == -2      # rows not 32-byte aligned
+    assert lib.tpu3_linear_wide_sb_f32(None, 4, 320, 128, 32, 320, 32, None, 32, 128) == -2      # beyond nine slabs
+    assert lib.tpu3_linear_wide_sb_f32(None, -1, 264, 128, 32, 264, 32, None, 32, 128) == -1
+
+
+def test_split_bf16_switch_and_environment():
+    """tpu3_split_bf16: query / set / previous value; the initial setting comes from TPU3_SPLIT_BF16 (unset: on -- the
+    regressor's default arithmetic since round 6), read once per process."""
+    import subprocess
+    import sys
+    lib = pkg("_lib").lib()
+    was = lib.tpu3_split_bf16(-1)
+    assert was in (0, 1)
+    assert lib.tpu3_split_bf16(0) == was and lib.tpu3_split_bf16(-1) == 0
+    assert lib.tpu3_split_bf16(1) == 0 and lib.tpu3_split_bf16(-1) == 1
+    lib.tpu3_split_bf16(was)
+    code = ("import importlib, sys; sys.path.insert(0, %r); L = importlib.import_module('3pu_pytorch_amd._lib'); "
+            "print(L.lib().tpu3_split_bf16(-1))" % ROOT)
+    for env_val, expect in ((None, "1"), ("0", "0"), ("1", "1")):
+        env = {k: v for k, v in os.environ.items() if k != "TPU3_SPLIT_BF16"}
+        if env_val is not None:
+            env["TPU3_SPLIT_BF16"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert out.stdout.strip().splitlines()[-1] == expect, (env_val, out.stdout)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
