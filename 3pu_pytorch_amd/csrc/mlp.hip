@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 }
 
 
-// (r6) SPLIT-bf16 flavour of the tail (TPU3_SPLIT_BF16=1; VERDICT r5 item 7, tools/split_mfma_probe.hip): fp32
+// (r6) SPLIT-bf16 flavour of the tail (the default; tpu3_split_bf16 / TPU3_SPLIT_BF16=0 select the fp32 kernel): fp32
 // arithmetic on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 terms, x = x1 + x2 + x3
 // (8 + 8 + 8 mantissa bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), each subtraction exact), and a
 // product w x becomes the six partial products whose magnitude can reach the fp32 result's last bits (w1 x1, w1 x2,
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void regress_tail_f16_kernel(TailArgs a)
 // v_mfma_f32_16x16x32_bf16 -- 16x the fp32 MFMA's rate per instruction, 6 instructions for 8 of the 16x16x4 ones, and
 // the splits are VALU work the matrix pipe does not wait for.  Same register-to-register dataflow as the fp16 flavour
 // above (two accumulator tiles = the B operand of one slab pair); the weights are split once per workgroup into three
-// bf16 arrays in LDS (157 KB for layers 2 and 3); the 64 -> 3 layer stays on v_mfma_f32_16x16x4_f32 (16 instructions,
+// bf16 arrays in LDS (147 KB for layers 2 and 3, operand-major: rb_slot); the 64 -> 3 layer stays on v_mfma_f32_16x16x4_f32 (16 instructions,
 // and its weights would not fit).  The result is NOT bit-identical to the fp32 kernel's -- products are exact in both,
 // the fp32 accumulation order differs -- but as accurate (probe: 1.2x / 1.0x the fp32 kernel's error against fp64).
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));

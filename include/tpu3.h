@@ -387,8 +387,8 @@ int tpu3_linear_wide_f32(tpu3_stream_t stream, long m, int cin, int cout, const 
                          const float *w, int w_stride, const float *bias, float *y, int y_stride);
 
 /* (r6) The same layer with every fp32 operand as three bf16 terms, six partial products each on
- * v_mfma_f32_16x16x32_bf16 (opt-in: TPU3_SPLIT_BF16=1 on the Python side; as accurate as the fp32 kernel against fp64,
- * not bit-identical to it).  tpu3_linear_wide_split_bf16 writes the slab-major image of W[:, :cin] once per set of
+ * v_mfma_f32_16x16x32_bf16 (the Python side's default since round 6; TPU3_SPLIT_BF16=0 / tpu3_split_bf16(0): off): as
+ * accurate as the fp32 kernel against fp64, not bit-identical to it.  tpu3_linear_wide_split_bf16 writes the slab-major image of W[:, :cin] once per set of
  * weights (tpu3_linear_wide_split_bytes(cin) bytes, 16-byte aligned); tpu3_linear_wide_sb_f32 takes it in place of w.
  * cout = 128, cin and x_stride multiples of 8, x 32-byte aligned (else TPU3_ELIMIT). */
 /* Arithmetic of the regressor's matrix layers (tpu3_regress_tail_f32 with mfma = TPU3_MFMA_F32, and -- on the Python side
